@@ -1,0 +1,142 @@
+/*
+ * worogen.h — C ABI of libworogen, the MI355X-native implementation of World Orogen's per-cell
+ * terrain pipeline (reference: raguilar011095/planet_heightmap_generation, js/terrain-post.js,
+ * js/simplex-noise.js, js/rng.js, js/sphere-mesh.js).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / HIP types.  The N-API shim
+ * (planet_heightmap_generation_amd/napi/worogen_napi.cc) and the Python ctypes loader
+ * (planet_heightmap_generation_amd/capi.py) bind exactly these symbols.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returning int returns 0 on success, non-zero on failure; the message is then
+ *     available from wo_last_error() (thread-local, valid until the next failing call on the thread).
+ *     The JS/Python hosts turn a non-zero status into a thrown Error/exception, which is how the
+ *     reference reports failures (exceptions caught by js/planet-worker.js:336-338).
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - "numRegions" is the reference's mesh.numRegions (requested N + 1: the pole cell is appended,
+ *     js/sphere-mesh.js:179-184).  CSR arrays are mesh.adjOffset (numRegions+1) / mesh.adjList.
+ *   - device entry points fail (never fall back to the CPU) when no HIP device is usable.
+ */
+#ifndef WOROGEN_H
+#define WOROGEN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WO_ABI_VERSION 1
+
+typedef struct wo_ctx wo_ctx;       /* one HIP device + stream + scratch pools                     */
+typedef struct wo_planet wo_planet; /* device-resident mesh + fields; mirrors the worker's retained
+                                       state W (js/planet-worker.js:22,277-292)                     */
+
+/* ---------------------------------------------------------------- status ---------------------- */
+int         wo_abi_version(void);
+const char* wo_last_error(void);
+/* number of usable HIP devices (0 when none / no driver); never fails */
+int         wo_device_count(void);
+
+/* ------------------------------------------------ host-side input producers (no GPU needed) --- */
+/* generateFibonacciSphere + pole append: js/sphere-mesh.js:9-37,179-181.  r_xyz has 3*(N+1) floats;
+ * `seed` is what the caller passes to makeRng (js/rng.js:3). */
+int wo_fib_sphere_points(int32_t N, double jitter, double seed, float* r_xyz);
+/* Spherical Delaunay of numRegions unit vectors == the reference's stereographic Delaunator run +
+ * addPoleToMesh (js/sphere-mesh.js:41-90,174-186).  triangles / halfedges have 3*(2*numRegions-4)
+ * entries, counter-clockwise seen from outside, same contract as Delaunator's arrays. */
+int wo_sphere_delaunay(int32_t numRegions, const float* r_xyz, int32_t* triangles, int32_t* halfedges);
+/* SphereMesh constructor's CSR (js/sphere-mesh.js:94-146).  adjTriList may be NULL. */
+int wo_mesh_csr(int32_t numRegions, int32_t numSides, const int32_t* triangles, const int32_t* halfedges,
+                int32_t* adjOffset, int32_t* adjList, int32_t* adjTriList);
+/* computeNeighborDist: js/sphere-mesh.js:191-203 */
+int wo_neighbor_dist(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList,
+                     const float* r_xyz, float* neighborDist);
+/* computeTriangleElevations: js/planet-worker.js:29-37 */
+int wo_triangle_elevations(int32_t numTriangles, const int32_t* triangles, const float* r_elevation,
+                           float* t_elevation);
+
+/* ------------------------------------------------ SimplexNoise (js/simplex-noise.js:5-54) ----- */
+/* constructor: perm[512] and permMod12[512] for makeRng(seed) (js/simplex-noise.js:8-14) */
+int wo_noise_tables(double seed, uint8_t* perm512, uint8_t* pm12_512);
+/* batch evaluation on the device.  kind: 0 noise3D, 1 fbm(octaves, persistence),
+ * 2 ridgedFbm(octaves, lacunarity=p0, gain=p1, offset=p2).  xyz: n interleaved double triples. */
+#define WO_NOISE_3D 0
+#define WO_NOISE_FBM 1
+#define WO_NOISE_RIDGED 2
+int wo_noise_eval(wo_ctx* ctx, double seed, int32_t kind, int32_t octaves, double p0, double p1, double p2,
+                  int64_t n, const double* xyz, double* out);
+
+/* ------------------------------------------------ context / planet handle --------------------- */
+wo_ctx* wo_ctx_create(int32_t device);              /* NULL on failure (see wo_last_error)        */
+void    wo_ctx_destroy(wo_ctx* ctx);
+/* Uploads the mesh once (the worker keeps mesh / r_xyz / neighborDist in W between commands,
+ * js/planet-worker.js:277-292).  neighborDist may be NULL: it is then computed on the device. */
+wo_planet* wo_planet_create(wo_ctx* ctx, int32_t numRegions, const int32_t* adjOffset,
+                            const int32_t* adjList, const float* r_xyz, const float* neighborDist);
+void       wo_planet_destroy(wo_planet* p);
+
+/* ------------------------------------------------ terrain-post, JS call surface --------------- */
+/* Each mutates r_elevation (host, numRegions floats) in place and returns nothing else, exactly like
+ * the five exports of js/terrain-post.js.  r_isOcean is numRegions bytes, read-only. */
+/* warpTerrain(mesh, r_elevation, r_xyz, seed, strength, r_hotspot?)   js/terrain-post.js:233 */
+int wo_warp_terrain(wo_planet* p, float* r_elevation, double seed, double strength, const float* r_hotspot);
+/* smoothElevation(mesh, r_elevation, r_isOcean, iterations, strength) js/terrain-post.js:317 */
+int wo_smooth_elevation(wo_planet* p, float* r_elevation, const uint8_t* r_isOcean, int32_t iterations, double strength);
+/* erodeComposite(mesh, r_elevation, r_xyz, r_isOcean, hIters, K, m, dt, tIters, talusSlope,
+ *                kThermal, gIters, glacialStrength, neighborDist)      js/terrain-post.js:369 */
+int wo_erode_composite(wo_planet* p, float* r_elevation, const uint8_t* r_isOcean,
+                       int32_t hIters, double K, double m, double dt,
+                       int32_t tIters, double talusSlope, double kThermal,
+                       int32_t gIters, double glacialStrength);
+/* sharpenRidges(mesh, r_elevation, r_isOcean, iterations, strength)   js/terrain-post.js:713 */
+int wo_sharpen_ridges(wo_planet* p, float* r_elevation, const uint8_t* r_isOcean, int32_t iterations, double strength);
+/* applySoilCreep(mesh, r_elevation, r_isOcean, iterations, strength)  js/terrain-post.js:758 */
+int wo_soil_creep(wo_planet* p, float* r_elevation, const uint8_t* r_isOcean, int32_t iterations, double strength);
+
+/* ------------------------------------------------ device-resident variants -------------------- */
+/* The "reapply" pattern (js/planet-worker.js:341-440): fields stay in HBM, only scalars arrive.
+ * wo_planet_upload sets the resident r_elevation (and r_isOcean when not NULL); the *_resident
+ * functions are the same passes as above without the H2D/D2H copies; all are asynchronous on the
+ * planet's stream until wo_planet_sync / wo_planet_download. */
+int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_isOcean);
+int wo_planet_download(wo_planet* p, float* r_elevation);
+/* r_isOcean[r] = r_elevation[r] <= 0 on the resident field (js/planet-worker.js:51-54) */
+int wo_planet_ocean_from_elevation(wo_planet* p);
+int wo_planet_download_ocean(wo_planet* p, uint8_t* r_isOcean);
+int wo_planet_sync(wo_planet* p);
+int wo_warp_terrain_resident(wo_planet* p, double seed, double strength, int32_t useHotspot);
+int wo_planet_upload_hotspot(wo_planet* p, const float* r_hotspot);
+int wo_smooth_elevation_resident(wo_planet* p, int32_t iterations, double strength);
+int wo_erode_composite_resident(wo_planet* p, int32_t hIters, double K, double m, double dt,
+                                int32_t tIters, double talusSlope, double kThermal,
+                                int32_t gIters, double glacialStrength);
+int wo_sharpen_ridges_resident(wo_planet* p, int32_t iterations, double strength);
+int wo_soil_creep_resident(wo_planet* p, int32_t iterations, double strength);
+/* Synthetic bench terrain: e = 0.9*fbm(1.5p,5) - 0.12 + 0.25*ridged(3p,4)*max(0,fbm(1.5p,5))
+ * with SimplexNoise(seed), written to the resident elevation; isOcean = e <= 0. */
+int wo_planet_synthetic_terrain(wo_planet* p, double seed);
+
+/* ------------------------------------------------ measurement ------------------------------- */
+/* HIP-event stopwatch on the planet's stream (the stream every kernel of the path is launched on). */
+int wo_timer_start(wo_planet* p);
+int wo_timer_stop_ms(wo_planet* p, double* ms);   /* records, synchronises the stop event, returns elapsed */
+/* Per-kernel-family HIP-event profiling: when enabled every launch is bracketed by events on the
+ * planet's stream (slower; used by bench.py's roofline pass only). */
+int wo_profile_enable(wo_planet* p, int32_t on);
+int wo_profile_reset(wo_planet* p);
+/* Fills up to cap entries; returns the number of families through *count. names[i] points to static
+ * storage.  total_ms / launches are per family since the last reset. */
+int wo_profile_report(wo_planet* p, int32_t cap, const char** names, double* total_ms, int64_t* launches,
+                      int32_t* count);
+/* Stage timings of the last erodeComposite call, same {stage, ms} shape the reference ships in
+ * _postTiming (js/planet-worker.js:42-93). */
+int wo_last_stage_timing(wo_planet* p, int32_t cap, const char** stages, double* ms, int32_t* count);
+/* Counters of the last erodeComposite call (land cells, dependency rounds, ...), for DESIGN/bench. */
+int wo_last_erode_stats(wo_planet* p, int32_t cap, const char** names, double* values, int32_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WOROGEN_H */

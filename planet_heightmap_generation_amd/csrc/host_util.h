@@ -1,0 +1,47 @@
+// Host-side helpers shared by the native (non-kernel) parts of libworogen.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <thread>
+#include <vector>
+
+namespace wo {
+
+inline int host_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (n > 64) n = 64;
+    return (int)n;
+}
+
+// Static-chunked parallel loop over [0, n). fn(begin, end, tid).
+template <class F>
+inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
+    int nt = host_threads();
+    if (n < min_chunk * 2 || nt == 1) { fn((int64_t)0, n, 0); return; }
+    int64_t chunks = std::min<int64_t>(nt, (n + min_chunk - 1) / min_chunk);
+    std::vector<std::thread> th;
+    th.reserve(chunks);
+    for (int64_t c = 0; c < chunks; ++c) {
+        int64_t b = n * c / chunks, e = n * (c + 1) / chunks;
+        th.emplace_back([=, &fn]() { fn(b, e, (int)c); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// Park-Miller LCG exactly as the reference seeds and steps it (js/rng.js:3-6).
+struct ParkMiller {
+    double s;
+    explicit ParkMiller(double seed) {
+        double v = std::abs(std::floor(seed * 9301.0 + 49297.0));
+        s = std::fmod(v, 2147483646.0) + 1.0;
+    }
+    inline double next() {
+        s = std::fmod(s * 16807.0, 2147483647.0);
+        return (s - 1.0) / 2147483646.0;
+    }
+};
+
+}  // namespace wo
