@@ -1,0 +1,131 @@
+"""ctypes loader for the CPU oracle (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg — never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_DIR = Path(__file__).resolve().parent
+LIB_PATH = _DIR / "_build" / "liboracle.so"
+_lib = None
+_i32, _f64, _p, _i64 = C.c_int32, C.c_double, C.c_void_p, C.c_int64
+
+
+def build() -> None:
+    subprocess.run(["make", "-s", "-C", str(_DIR)], check=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        L = C.CDLL(str(LIB_PATH))
+        L.wo_or_noise_init.argtypes = [_f64, _p, _p]
+        L.wo_or_noise_batch.argtypes = [_f64, C.c_int, C.c_int, _f64, _f64, _f64, _i64, _p, _p]
+        L.wo_or_synthetic_terrain.argtypes = [_i32, _p, _f64, _p]
+        L.wo_or_rng_seed.argtypes = [_f64, _p]
+        L.wo_or_rng_next.argtypes = [_p]
+        L.wo_or_rng_next.restype = _f64
+        L.wo_or_cell_noise_hash.argtypes = [_i32]
+        L.wo_or_cell_noise_hash.restype = C.c_uint32
+        L.wo_or_warp_terrain.argtypes = [_i32, _p, _p, _p, _p, _f64, _f64, _p]
+        for f in ("wo_or_smooth_elevation", "wo_or_sharpen_ridges", "wo_or_soil_creep"):
+            getattr(L, f).argtypes = [_i32, _p, _p, _p, _p, _i32, _f64]
+        L.wo_or_priority_flood_carve.argtypes = [_i32, _p, _p, _p, _p, _f64]
+        L.wo_or_erode_composite.argtypes = [_i32, _p, _p, _p, _p, _p, _i32, _f64, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def rng_values(seed: float, count: int) -> np.ndarray:
+    st = C.c_double(0.0)
+    lib().wo_or_rng_seed(float(seed), C.byref(st))
+    return np.array([lib().wo_or_rng_next(C.byref(st)) for _ in range(count)], dtype=np.float64)
+
+
+def noise_tables(seed: float):
+    p, m = np.empty(512, np.uint8), np.empty(512, np.uint8)
+    lib().wo_or_noise_init(float(seed), _ptr(p), _ptr(m))
+    return p, m
+
+
+def noise_batch(seed, kind, xyz, octaves=5, p0=2.0 / 3.0, p1=0.5, p2=1.0) -> np.ndarray:
+    xyz = _c(xyz, np.float64).reshape(-1, 3)
+    out = np.empty(xyz.shape[0], np.float64)
+    lib().wo_or_noise_batch(float(seed), int(kind), int(octaves), float(p0), float(p1), float(p2), xyz.shape[0], _ptr(xyz), _ptr(out))
+    return out
+
+
+def synthetic_terrain(r_xyz, seed) -> np.ndarray:
+    r_xyz = _c(r_xyz, np.float32)
+    out = np.empty(r_xyz.size // 3, np.float32)
+    lib().wo_or_synthetic_terrain(out.size, _ptr(r_xyz), float(seed), _ptr(out))
+    return out
+
+
+class Mesh:
+    """Minimal holder of the three members the path reads (js/sphere-mesh.js:144-145)."""
+
+    def __init__(self, adjOffset, adjList):
+        self.adjOffset = _c(adjOffset, np.int32)
+        self.adjList = _c(adjList, np.int32)
+        self.numRegions = self.adjOffset.size - 1
+
+
+def warp_terrain(mesh, r_elevation, r_xyz, seed, strength, r_hotspot=None):
+    e = _c(r_elevation, np.float32).copy()
+    xyz = _c(r_xyz, np.float32)
+    hot = None if r_hotspot is None else _c(r_hotspot, np.float32)
+    lib().wo_or_warp_terrain(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(e), _ptr(xyz), float(seed), float(strength), _ptr(hot))
+    return e
+
+
+def _jacobi(fn, mesh, r_elevation, r_isOcean, iterations, strength):
+    e = _c(r_elevation, np.float32).copy()
+    oc = _c(r_isOcean, np.uint8)
+    getattr(lib(), fn)(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(e), _ptr(oc), int(iterations), float(strength))
+    return e
+
+
+def smooth_elevation(mesh, e, oc, iterations, strength):
+    return _jacobi("wo_or_smooth_elevation", mesh, e, oc, iterations, strength)
+
+
+def sharpen_ridges(mesh, e, oc, iterations, strength):
+    return _jacobi("wo_or_sharpen_ridges", mesh, e, oc, iterations, strength)
+
+
+def soil_creep(mesh, e, oc, iterations, strength):
+    return _jacobi("wo_or_soil_creep", mesh, e, oc, iterations, strength)
+
+
+def priority_flood_carve(mesh, r_elevation, r_isOcean, carveStrength):
+    e = _c(r_elevation, np.float32).copy()
+    oc = _c(r_isOcean, np.uint8)
+    lib().wo_or_priority_flood_carve(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(e), _ptr(oc), float(carveStrength))
+    return e
+
+
+def erode_composite(mesh, r_elevation, r_xyz, r_isOcean, hIters, K, m, dt, tIters, talusSlope, kThermal,
+                    gIters, glacialStrength, neighborDist):
+    e = _c(r_elevation, np.float32).copy()
+    xyz, oc, nd = _c(r_xyz, np.float32), _c(r_isOcean, np.uint8), _c(neighborDist, np.float32)
+    lib().wo_or_erode_composite(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(e), _ptr(xyz), _ptr(oc),
+                                int(hIters), float(K), float(m), float(dt), int(tIters), float(talusSlope), float(kThermal),
+                                int(gIters), float(glacialStrength), _ptr(nd))
+    return e
