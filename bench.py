@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — Mcells·iter/s of the terrain-post erosion stack (BASELINE.json metric) on MI355X.
+
+A *step* is one pass of the hot path over one planet: restore the resident synthetic terrain, then
+warpTerrain(0.75) -> isOcean = elev <= 0 -> erodeComposite(hIters=200, K=3e-4, m=0.5, dt=1, tIters=200,
+talus=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5) -> applySoilCreep(3, 0.1125)
+(BASELINE config 3: "10M cells, same stack + FBM domain warp + glacial carve, 1xMI355X").
+Inputs (mesh, r_xyz, neighborDist, elevation) are resident in HBM before the timed region; the two
+priority-flood calls per step run on the host by design and are inside the timed region.
+
+  value = numRegions * 200 iterations * steps * n_gpus / wall / 1e6          [Mcells·iter/s, whole job]
+
+N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks timing),
+one independent planet per rank with seed = 1 + rank (BASELINE config 5, ensemble; no data-path collective)
+-> "scaling": "weak".
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel family, HIP-event timed) and
+`cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only) objects.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+# SURVEY 8(d) algorithmic bytes per pass, per kernel family (L = land cells, N = numRegions, d = 6).
+# value = (bytes per land cell, bytes per cell); launches_per_pass comes from the measured launch counts.
+ALGO_BYTES = {
+    "sort_radix(hipcub)": (8.0, 0.0),      # key in + rank out
+    "sort_keys": (8.0, 0.0),
+    "rank_scatter": (8.0, 0.0),
+    "receivers": (68.0, 4.0),              # own elev, adjOffset, adjList, nb elev, dist, writes + target fill
+    "flow_init": (8.0, 4.0),
+    "flow_snap": (16.0, 0.0),              # flow family: 16 B/land cell per pass
+    "flow_apply": (16.0, 0.0),
+    "flow_final": (16.0, 4.0),
+    "solve_setup": (45.0, 0.0),            # solve family: 45 B/land cell per pass
+    "solve_round": (45.0, 0.0),
+    "solve_final": (8.0, 4.0),
+    "thermal_excess": (62.0, 4.0),         # thermal: 106 B/land cell + 4 B/cell split over its two passes
+    "thermal_apply": (106.0, 4.0),
+    "soil_creep": (82.0 * 0.8, 4.0),       # 82 B per interior-land cell and iteration
+    "warp_terrain": (0.0, 20.0 + 100.0 * 24),   # ~20 + 100*hops B/cell, ~24 hops at 10M
+}
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5)
+WARP, CREEP = 0.75, (3, 0.1125)
+
+
+def build_inputs(cells: int, seed: int):
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    t0 = time.time()
+    mesh, xyz, nd = S.build_sphere(cells, 0.75, seed)
+    return mesh, xyz, nd, time.time() - t0
+
+
+def one_step(pl, seed, params, iters_scale=None):
+    p = dict(params)
+    pl.restore_state()
+    pl.warp_terrain_resident(seed, WARP)
+    pl.ocean_from_elevation()
+    pl.erode_composite_resident(p["hIters"], p["K"], p["m"], p["dt"], p["tIters"], p["talusSlope"], p["kThermal"], p["gIters"],
+                                p["glacialStrength"])
+    pl.apply_soil_creep_resident(*CREEP)
+
+
+def cpu_baseline(mesh, xyz, nd, seed, budget_iters: int):
+    """CPU oracle (oracle/*.c, single thread) on the same planet, same stack, `budget_iters` composite
+    iterations instead of 200 (bounded sample)."""
+    from oracle import pyoracle as O
+    om = O.Mesh(mesh.adjOffset, mesh.adjList)
+    e0 = O.synthetic_terrain(xyz, seed)
+    t0 = time.time()
+    e = O.warp_terrain(om, e0, xyz, seed, WARP)
+    oc = (e <= 0).astype(np.uint8)
+    g = max(1, min(PARAMS["gIters"], budget_iters // 2))
+    e = O.erode_composite(om, e, xyz, oc, budget_iters, PARAMS["K"], PARAMS["m"], PARAMS["dt"], budget_iters, PARAMS["talusSlope"],
+                          PARAMS["kThermal"], g, PARAMS["glacialStrength"], nd)
+    e = O.soil_creep(om, e, oc, *CREEP)
+    dt = time.time() - t0
+    return dict(value=mesh.numRegions * budget_iters / dt / 1e6, unit="Mcells·iter/s", cores=1, kind="port",
+                sample=f"same {mesh.numRegions}-cell planet and stack, {budget_iters} composite iterations (g={g}) instead of 200, "
+                       f"{dt:.1f} s on one host core; includes warp + 2 priority floods + creep")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=10_000_000)
+    ap.add_argument("--iters", type=int, default=200, help="composite iterations per step (200 = BASELINE config)")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+
+    from planet_heightmap_generation_amd import terrain_post as TP
+    params = dict(PARAMS)
+    if args.iters != 200:
+        params.update(hIters=args.iters, tIters=args.iters, gIters=min(10, max(1, args.iters // 20)))
+    seed = 1 + rank
+    mesh, xyz, nd, t_mesh = build_inputs(args.cells, seed)
+    pl = TP.Planet(mesh, xyz, nd, device=local_rank)
+    pl.synthetic_terrain(seed)
+    pl.save_state()
+    pl.sync()
+    N = mesh.numRegions
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        pl.sync()
+
+    for _ in range(args.warmup):
+        one_step(pl, seed, params)
+    barrier()
+    t0 = time.perf_counter()
+    pl.timer_start()
+    for _ in range(args.steps):
+        one_step(pl, seed, params)
+    ev_ms = pl.timer_stop_ms()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    stats = pl.last_erode_stats()
+    stages = pl.last_stage_timing()
+    L = int(stats.get("land_cells", 0))
+    iters = max(params["hIters"], params["tIters"], params["gIters"])
+
+    roofline = None
+    if rank == 0 and not args.no_profile:
+        # separate pass with every launch bracketed by HIP events on the planet's stream
+        pl.profile_reset()
+        pl.profile_enable(True)
+        one_step(pl, seed, params)
+        pl.profile_enable(False)
+        rep = pl.profile_report()
+        fam, (ms, launches) = max(rep.items(), key=lambda kv: kv[1][0])
+        per_land, per_cell = ALGO_BYTES.get(fam, (0.0, 0.0))
+        passes = max(1, iters if fam not in ("soil_creep", "warp_terrain") else (3 if fam == "soil_creep" else 1))
+        if fam.startswith("sort"):
+            passes = int(stats.get("sorts", iters))
+        bytes_per_pass = per_land * L + per_cell * N
+        launches_per_pass = launches / passes
+        avg_launch_s = ms / 1e3 / launches
+        achieved = bytes_per_pass / launches_per_pass / avg_launch_s / 1e9
+        roofline = dict(bound="hbm", kernel=fam, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=None, launches=launches, avg_launch_us=avg_launch_s * 1e6,
+                        algorithmic_bytes_per_launch=bytes_per_pass / launches_per_pass,
+                        families_ms={k: round(v[0], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])})
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters)
+
+    if rank == 0:
+        value = N * iters * args.steps * world / wall / 1e6
+        out = {
+            "metric": "Mcells·iter/s, terrain-post erosion stack", "value": value, "unit": "Mcells·iter/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3: {N} cells (Fibonacci sphere {args.cells}+pole, jitter 0.75, seed 1+rank), "
+                                   f"warp 0.75 + erodeComposite(h={params['hIters']},t={params['tIters']},g={params['gIters']}) + creep x3, "
+                                   f"one planet per GPU", "cells": N, "land_cells": L, "iterations": iters,
+                       "parallelism": f"ensemble x{world} (no collective on the data path)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stage_ms_last_step": {k: round(v, 2) for k, v in stages.items()},
+            "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "hip_event_ms_per_step": ev_ms / args.steps,
+        }
+        print(json.dumps(out))
+    pl.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

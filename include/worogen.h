@@ -106,6 +106,10 @@ int wo_planet_download(wo_planet* p, float* r_elevation);
 int wo_planet_ocean_from_elevation(wo_planet* p);
 int wo_planet_download_ocean(wo_planet* p, uint8_t* r_isOcean);
 int wo_planet_sync(wo_planet* p);
+/* Keep / bring back a device-side copy of (r_elevation, r_isOcean): the worker's W.prePostElev that every
+ * "reapply" starts from (js/planet-worker.js:353); D2D copies on the planet's stream. */
+int wo_planet_save_state(wo_planet* p);
+int wo_planet_restore_state(wo_planet* p);
 int wo_warp_terrain_resident(wo_planet* p, double seed, double strength, int32_t useHotspot);
 int wo_planet_upload_hotspot(wo_planet* p, const float* r_hotspot);
 int wo_smooth_elevation_resident(wo_planet* p, int32_t iterations, double strength);

@@ -49,6 +49,8 @@ SIGNATURES = {
     "wo_planet_ocean_from_elevation": (C.c_int, [_p]),
     "wo_planet_download_ocean": (C.c_int, [_p, _p]),
     "wo_planet_sync": (C.c_int, [_p]),
+    "wo_planet_save_state": (C.c_int, [_p]),
+    "wo_planet_restore_state": (C.c_int, [_p]),
     "wo_warp_terrain_resident": (C.c_int, [_p, _c_f64, _c_f64, _c_i32]),
     "wo_planet_upload_hotspot": (C.c_int, [_p, _p]),
     "wo_smooth_elevation_resident": (C.c_int, [_p, _c_i32, _c_f64]),

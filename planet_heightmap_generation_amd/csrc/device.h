@@ -1,0 +1,129 @@
+// Device-side state of libworogen: context (device + stream), planet (resident mesh + fields + scratch),
+// launch / profiling helpers.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "erode_ops.h"
+#include "wo_internal.h"
+
+namespace wo {
+
+struct HipError { std::string msg; };
+
+#define WO_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            throw ::wo::HipError{std::string(#call) + " -> " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + \
+                                 std::to_string(__LINE__) + ")"};                                      \
+    } while (0)
+
+constexpr int WO_BLOCK = 256;
+inline int blocks_for(int64_t n, int maxBlocks = 1 << 20) {
+    int64_t b = (n + WO_BLOCK - 1) / WO_BLOCK;
+    if (b < 1) b = 1;
+    if (b > maxBlocks) b = maxBlocks;
+    return (int)b;
+}
+
+// Kernel families for HIP-event profiling (wo_profile_*) — one entry per distinct kernel of the path.
+enum Family : int {
+    FAM_COAST = 0, FAM_SMOOTH, FAM_SHARPEN, FAM_CREEP, FAM_WARP, FAM_NOISE, FAM_SYNTH, FAM_OCEAN,
+    FAM_SORT_KEYS, FAM_SORT_RADIX, FAM_RANK, FAM_RECEIVERS, FAM_FLOW_INIT, FAM_FLOW_SNAP, FAM_FLOW_APPLY, FAM_FLOW_FINAL,
+    FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
+    FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
+    FAM_MISC, FAM_COUNT
+};
+extern const char* const kFamilyNames[FAM_COUNT];
+
+}  // namespace wo
+
+struct wo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+};
+
+struct wo_planet {
+    wo_ctx* ctx = nullptr;
+    int32_t N = 0, E = 0, maxDeg = 0;
+    // host copies kept for the host-resident flood stage
+    std::vector<int32_t> h_off, h_adj;
+    std::vector<uint8_t> h_ocean;
+    bool h_ocean_valid = false;
+    float* h_pinned = nullptr;          // N floats, pinned
+    int32_t* h_count = nullptr;         // pinned scalar(s) for round-count read-back
+    wo::FloodScratch flood;
+
+    // resident mesh
+    int32_t *d_off = nullptr, *d_adj = nullptr;
+    float *d_dist = nullptr, *d_xyz = nullptr;
+    // resident fields
+    float *d_e = nullptr, *d_e2 = nullptr, *d_hot = nullptr, *d_orig = nullptr;
+    uint8_t *d_ocean = nullptr, *d_coast = nullptr;
+    bool hot_valid = false;
+    float* d_savedE = nullptr; uint8_t* d_savedOcean = nullptr; bool saved = false;
+    uint8_t* d_tables = nullptr;        // perm[512] + pm12[512]
+    // erode scratch (allocated on first erodeComposite)
+    bool scratch = false;
+    int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
+    uint32_t* d_keys[2] = {nullptr, nullptr};
+    float *d_cellDist = nullptr, *d_flow = nullptr, *d_selfOut = nullptr, *d_tOut = nullptr;
+    uint32_t *d_acc = nullptr, *d_snap = nullptr;
+    int32_t *d_jump = nullptr, *d_nj = nullptr;
+    int32_t *d_predSelf = nullptr, *d_predT = nullptr, *d_predT2 = nullptr, *d_doneAt = nullptr;
+    double* d_totalExcess = nullptr;
+    float *d_glac = nullptr, *d_iceFlow = nullptr;
+    int32_t *d_iceTarget = nullptr, *d_arank = nullptr;
+    uint8_t* d_iceUp = nullptr;
+    int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
+    void* d_sortTemp = nullptr; size_t sortTempBytes = 0;
+    int landCur = 0;                    // which of d_land[] holds the current order
+    int32_t L = 0;
+
+    // measurement
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool profiling = false;
+    struct Pending { int fam; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> eventPool;
+    double famMs[wo::FAM_COUNT] = {0};
+    int64_t famLaunches[wo::FAM_COUNT] = {0};
+    std::vector<std::pair<std::string, double>> stageTiming;
+    std::vector<std::pair<std::string, double>> erodeStats;
+
+    wo::Fields fields() const;
+};
+
+namespace wo {
+
+// profiling-aware launch: when p->profiling every launch is bracketed by events on the planet's stream
+hipEvent_t profile_event(wo_planet* p);
+void profile_resolve(wo_planet* p);
+
+template <class... KArgs, class... Args>
+inline void launch(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, int block, Args... args) {
+    hipStream_t s = p->ctx->stream;
+    if (p->profiling) {
+        hipEvent_t a = profile_event(p), b = profile_event(p);
+        WO_HIP(hipEventRecord(a, s));
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, args...);
+        WO_HIP(hipEventRecord(b, s));
+        p->pending.push_back({fam, a, b});
+        if (p->pending.size() >= 4096) profile_resolve(p);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, args...);
+    }
+}
+
+// sort.hip: stable descending sort of the land list by current elevation + rank scatter
+void sort_land_by_elevation(wo_planet* p);
+size_t sort_temp_bytes(int32_t n);
+
+}  // namespace wo

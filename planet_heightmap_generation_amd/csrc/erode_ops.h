@@ -1,0 +1,538 @@
+// Per-cell / per-task bodies of the terrain-post kernels (reference: js/terrain-post.js).
+//
+// Every function here is the body of one HIP kernel thread.  They are written against raw pointers in
+// a `Fields` struct so that the same code is (a) launched by the gfx950 kernels in kernels_*.hip and
+// (b) driven one thread at a time by the test-only emulator (tests/emu), which is how the parallel
+// re-formulations below were validated against the serial oracle in a container without a GPU.
+//
+// Numeric contract: arithmetic in double, stores narrow to float; -ffp-contract=off.
+//
+// How the order-defined reference loops are made parallel *without changing any result bit*:
+//
+//  * sort      landCells is kept as a device array; a stable LSD radix sort of (descending key, cell) run on
+//              the previous order IS V8's stable sort (ties keep their previous order).  rank[c] = position.
+//  * flow      flow values are integers (exact in f32), so only the *set* of contributions matters.
+//              F(c) = 1 + sum F(d) over donors ranked before c is a forest subtree size, computed by pointer
+//              doubling (A_{k+1}[c] = A_k[c] + sum_{jump_k[d]=c} A_k[d]); donors ranked after their receiver
+//              ("late" edges, ~1 %) are added once, un-forwarded, exactly as the serial pass leaves them.
+//  * solve     every turn of the ascending-order implicit solve is a task whose three inputs (own height,
+//              receiver height, receiver's receiver height) are each "the value left by the latest earlier
+//              event on that cell".  Events are single-assignment (selfOut / tOut per task), so the pass is
+//              a pure dataflow DAG executed in synchronous rounds: a task runs in round k when all (<=3) of
+//              its predecessor tasks finished in rounds < k.
+//  * thermal   delta[] is an f32 accumulator whose rounding depends on visiting order; each cell replays, in
+//              rank order, exactly the additions the serial loop would have applied to it.
+//  * glacial   ice accumulation = per-receiver f32 sums over donors in rank order (dataflow rounds); the
+//              in-place carve runs a task when no unfinished active cell within two hops has a lower rank,
+//              which makes concurrently running tasks touch disjoint cells and preserves every
+//              read-after-write / write-after-read order of the serial loop.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "noise.h"
+
+namespace wo {
+
+constexpr int WO_MAX_DEG = 24;          // planets with a larger vertex degree are rejected at creation
+constexpr int32_t WO_NOT_DONE = 0x7fffffff;
+
+struct Fields {
+    int32_t N;                 // numRegions
+    const int32_t* off;        // adjOffset [N+1]
+    const int32_t* adj;        // adjList   [E]
+    const float* dist;         // neighborDist [E]
+    const float* xyz;          // r_xyz [3N]
+    const uint8_t* ocean;      // r_isOcean [N]
+    const uint8_t* coast;      // land cell with >=1 ocean neighbour [N]
+    float* e;                  // r_elevation [N] (current)
+    float* e2;                 // second elevation buffer (Jacobi ping-pong)
+    // erodeComposite scratch
+    int32_t L;                 // land cells
+    int32_t* land;             // landCells in current order [L]
+    int32_t* rank;             // rank[c] = index of c in land, -1 for ocean [N]
+    int32_t* target;           // drainTarget [N]
+    float* cellDist;           // [N]
+    float* flow;               // [N]
+    uint32_t* accA; uint32_t* accB;     // pointer-doubling accumulators [N]
+    int32_t* jumpA; int32_t* jumpB;     // pointer-doubling ancestors [N]
+    // solve dataflow
+    int32_t* predSelf; int32_t* predT; int32_t* predT2;   // predecessor task (cell id) or -1 [N]
+    float* selfOut; float* tOut;        // event outputs [N]
+    int32_t* doneAt;                    // round in which the task finished, WO_NOT_DONE before [N]
+    // thermal
+    double* totalExcess;                // [N]
+    // glacial
+    float* glac;               // glacIdx [N]
+    int32_t* iceTarget;        // [N]
+    float* iceFlow;            // [N]
+    uint8_t* iceUp;            // numIceUpstream [N]
+    int32_t* arank;            // carve: rank if the cell is an active carve task else WO_NOT_DONE [N]
+};
+
+WO_HD inline double nd_or_eps(float d) { return (d == 0.0f || d != d) ? 1e-6 : (double)d; }   // `x || 1e-6`
+
+// sort key: descending elevation, -0 == +0 (comparator (a,b)=>e[b]-e[a], js/terrain-post.js:471)
+WO_HD inline uint32_t desc_key(float f) {
+    if (f == 0.0f) f = 0.0f;
+    union { float f; uint32_t u; } v; v.f = f;
+    uint32_t u = (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
+    return ~u;
+}
+WO_HD inline uint32_t asc_key(float f) { return ~desc_key(f); }
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi family (js/terrain-post.js:317-354, 713-751, 758-794, 690-706)
+// ------------------------------------------------------------------------------------------------
+WO_HD inline uint8_t coast_flag(const Fields& F, int32_t r) {
+    if (F.ocean[r]) return 0;
+    for (int32_t i = F.off[r]; i < F.off[r + 1]; ++i) if (F.ocean[F.adj[i]]) return 1;
+    return 0;
+}
+
+// smoothElevation, one iteration, cell r: returns the new value (js/terrain-post.js:332-350)
+WO_HD inline float smooth_cell(const Fields& F, const float* e, int32_t r, double strength) {
+    if (F.coast[r]) return e[r];
+    const double h = e[r];
+    double wSum = 0, hSum = 0;
+    for (int32_t i = F.off[r]; i < F.off[r + 1]; ++i) {
+        const double nh = e[F.adj[i]];
+        const double diff = fabs(nh - h);
+        const double w = 1 / (1 + diff * 8);
+        wSum += w;
+        hSum += nh * w;
+    }
+    if (wSum > 0) { const double avg = hSum / wSum; return (float)(h + (avg - h) * strength); }
+    return (float)h;
+}
+
+// sharpenRidges, one iteration (js/terrain-post.js:728-747); ocean cells keep their value
+WO_HD inline float sharpen_cell(const Fields& F, const float* e, const float* original, int32_t r, double strength) {
+    if (F.ocean[r]) return e[r];
+    const double h = e[r];
+    double sum = 0;
+    const int32_t count = F.off[r + 1] - F.off[r];
+    for (int32_t i = F.off[r]; i < F.off[r + 1]; ++i) sum += e[F.adj[i]];
+    if (count == 0) return (float)h;
+    const double avg = sum / count;
+    if (h > avg) {
+        double hn = h + (h - avg) * strength;
+        const double cap = (double)original[r] * 1.5;
+        if (hn > cap) hn = cap;
+        return (float)hn;
+    }
+    return (float)h;
+}
+
+// applySoilCreep, one iteration (js/terrain-post.js:777-791); only interior land moves
+WO_HD inline float creep_cell(const Fields& F, const float* e, int32_t r, double strength) {
+    if (F.ocean[r] || F.coast[r]) return e[r];
+    const double h = e[r];
+    double sum = 0; int32_t count = 0;
+    for (int32_t i = F.off[r]; i < F.off[r + 1]; ++i) {
+        const int32_t nb = F.adj[i];
+        if (!F.ocean[nb]) { sum += e[nb]; ++count; }
+    }
+    if (count == 0) return (float)h;
+    return (float)(h + (sum / count - h) * strength);
+}
+
+// post-loop glacial blend (js/terrain-post.js:690-706)
+WO_HD inline float glacial_blend_cell(const Fields& F, const float* e, int32_t r) {
+    if (F.ocean[r] || !(F.glac[r] > 0)) return e[r];
+    double sum = 0; int32_t count = 0;
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        if (!F.ocean[nb]) { sum += e[nb]; ++count; }
+    }
+    if (count > 0) { const double avg = sum / count; return (float)((double)e[r] + (avg - (double)e[r]) * 0.3); }
+    return e[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// warpTerrain (js/terrain-post.js:245-308): source cell of the greedy walk, then the blend
+// ------------------------------------------------------------------------------------------------
+WO_HD inline int32_t warp_source_cell(const Fields& F, const uint8_t* P, const uint8_t* M, int32_t r, double maxAmp) {
+    const double px = F.xyz[3 * r], py = F.xyz[3 * r + 1], pz = F.xyz[3 * r + 2];
+    double ex = -pz, ey = 0, ez = px;
+    const double elen = sqrt(ex * ex + ez * ez);
+    if (elen > 1e-10) { ex /= elen; ez /= elen; } else { ex = 1; ez = 0; }
+    const double nx = py * ez, ny = pz * ex - px * ez, nz = -py * ex;
+    double nlen = sqrt(nx * nx + ny * ny + nz * nz);
+    if (nlen == 0 || nlen != nlen) nlen = 1;
+    const double nnx = nx / nlen, nny = ny / nlen, nnz = nz / nlen;
+    const double freq = 4;
+    const double d1 = fbm(P, M, px * freq, py * freq, pz * freq, 5) * maxAmp;
+    const double d2 = fbm(P, M, px * freq + 31.7, py * freq + 47.3, pz * freq + 19.1, 5) * maxAmp;
+    double wx = px + ex * d1 + nnx * d2;
+    double wy = py + ey * d1 + nny * d2;
+    double wz = pz + ez * d1 + nnz * d2;
+    double wlen = sqrt(wx * wx + wy * wy + wz * wz);
+    if (wlen == 0 || wlen != wlen) wlen = 1;
+    wx /= wlen; wy /= wlen; wz /= wlen;
+    int32_t cur = r;
+    double bestDot = wx * px + wy * py + wz * pz;
+    for (;;) {
+        bool moved = false;
+        const int32_t iEnd = F.off[cur + 1];
+        for (int32_t i = F.off[cur]; i < iEnd; ++i) {
+            const int32_t nb = F.adj[i];
+            const double dot = wx * F.xyz[3 * nb] + wy * F.xyz[3 * nb + 1] + wz * F.xyz[3 * nb + 2];
+            if (dot > bestDot) { bestDot = dot; cur = nb; moved = true; }
+        }
+        if (!moved) break;
+    }
+    return cur;
+}
+
+WO_HD inline float warp_blend(float origF, float warpedF, double warpBias, bool useHot, float hotF) {
+    const double orig = origF, warped = warpedF;
+    double bias = warpBias;
+    if (useHot) {
+        double den = fabs(orig); if (den == 0) den = 1;
+        double hf = fabs((double)hotF) / den; if (hf > 1) hf = 1;
+        bias *= 1 - 0.8 * hf;
+    }
+    if (warped > orig) return (float)(orig + (warped - orig) * bias);
+    return (float)(warped + (orig - warped) * (1 - bias));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hydraulic: receivers (js/terrain-post.js:566-601)
+// ------------------------------------------------------------------------------------------------
+WO_HD inline void receiver_cell(const Fields& F, int32_t r) {
+    if (F.ocean[r]) { F.target[r] = -1; return; }
+    const double h = F.e[r];
+    int32_t bestNb = -1, bestJ = -1;
+    double bestDrop = -INFINITY;
+    const int32_t b = F.off[r], en = F.off[r + 1];
+    for (int32_t j = b; j < en; ++j) {
+        const int32_t nb = F.adj[j];
+        const double drop = h - (double)F.e[nb];
+        if (drop > bestDrop) { bestDrop = drop; bestNb = nb; bestJ = j; }
+    }
+    if (bestDrop <= 0) {
+        double minAscent = INFINITY;
+        for (int32_t j = b; j < en; ++j) {
+            const int32_t nb = F.adj[j];
+            const double ascent = (double)F.e[nb] - h;
+            if (ascent < minAscent) { minAscent = ascent; bestNb = nb; bestJ = j; }
+        }
+    }
+    F.target[r] = bestNb;
+    if (bestNb >= 0) { const float d = F.dist[bestJ]; F.cellDist[r] = (d == 0.0f || d != d) ? (float)1e-6 : d; }
+}
+
+// Flow (js/terrain-post.js:604-611).  fwd edge: receiver is land and ranked after the donor.
+WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
+    const int32_t t = F.target[r];
+    if (t < 0 || F.ocean[t]) return -1;
+    return (F.rank[r] < F.rank[t]) ? t : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hydraulic: implicit solve + deposition as dataflow (js/terrain-post.js:614-641)
+// Processing time of a land cell: tau = -rank (the serial loop walks landCells backwards), so
+// "earlier" == larger rank.
+// ------------------------------------------------------------------------------------------------
+// latest event on location x strictly before the turn of task r (exclusive of r itself):
+// events on x are x's own turn and the turns of its donors (neighbours n with target[n]==x).
+WO_HD inline int32_t latest_event_before(const Fields& F, int32_t x, int32_t r) {
+    const int32_t rr = F.rank[r];
+    int32_t best = -1, bestRank = -1;          // earlier == larger rank; want the smallest rank that is > rr
+    if (x != r && F.target[x] >= 0) { const int32_t k = F.rank[x]; if (k > rr) { best = x; bestRank = k; } }
+    for (int32_t j = F.off[x]; j < F.off[x + 1]; ++j) {
+        const int32_t n = F.adj[j];
+        if (n == r || F.ocean[n] || F.target[n] != x) continue;
+        const int32_t k = F.rank[n];
+        if (k > rr && (best < 0 || k < bestRank)) { best = n; bestRank = k; }
+    }
+    return best;
+}
+
+WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
+    F.doneAt[r] = WO_NOT_DONE;
+    if (F.ocean[r]) { F.predSelf[r] = F.predT[r] = F.predT2[r] = -1; return; }
+    const int32_t t = F.target[r];
+    F.predSelf[r] = latest_event_before(F, r, r);
+    int32_t pt = -1, pt2 = -1;
+    if (t >= 0 && !F.ocean[t]) {
+        pt = latest_event_before(F, t, r);
+        const int32_t t2 = F.target[t];
+        if (t2 >= 0 && !F.ocean[t2]) pt2 = latest_event_before(F, t2, r);
+    }
+    F.predT[r] = pt; F.predT2[r] = pt2;
+}
+
+// value of location x as left by event task p (p == x: own turn, else p deposited onto x); p < 0: initial
+WO_HD inline double event_value(const Fields& F, int32_t x, int32_t p) {
+    if (p < 0) return (double)F.e[x];
+    return (p == x) ? (double)F.selfOut[p] : (double)F.tOut[p];
+}
+
+// Returns true when the task ran (all predecessors finished in rounds < round).
+WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K, double m, double dt) {
+    const int32_t ps = F.predSelf[r], pt = F.predT[r], pt2 = F.predT2[r];
+    if (ps >= 0 && !(F.doneAt[ps] < round)) return false;
+    if (pt >= 0 && !(F.doneAt[pt] < round)) return false;
+    if (pt2 >= 0 && !(F.doneAt[pt2] < round)) return false;
+    const int32_t t = F.target[r];
+    const double er = event_value(F, r, ps);
+    if (t < 0) {       // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
+        F.selfOut[r] = (float)er; F.tOut[r] = 0; F.doneAt[r] = round; return true;
+    }
+    const double et = event_value(F, t, pt);
+    const double fl = F.flow[r];
+    const double pw = (m == 0.5) ? sqrt(fl) : pow(fl, m);
+    const double factor = K * pw * dt / (double)F.cellDist[r];
+    const double hr = et > 0 ? et : 0;
+    double hn = (er + factor * hr) / (1 + factor);
+    if (hn < hr) hn = hr;
+    if (hn < 0) hn = 0;
+    const double eroded = er - hn;
+    float tval = (float)et;
+    if (eroded > 0 && !F.ocean[t]) {
+        const int32_t t2 = F.target[t];
+        double slope = 0;
+        if (t2 >= 0 && F.cellDist[t] > 0) {
+            // t2 may be an ocean cell (never written here) or land (latest event before this turn)
+            const double et2 = F.ocean[t2] ? (double)F.e[t2] : event_value(F, t2, pt2);
+            slope = fabs(et - et2) / (double)F.cellDist[t];
+        }
+        const double depositFrac = 0.5 / (1 + slope * 50);
+        const double deposit = eroded * depositFrac;
+        tval = (float)(et + deposit);
+        if ((double)tval > hn) tval = (float)hn;
+    }
+    F.tOut[r] = tval;
+    F.selfOut[r] = (float)hn;
+    F.doneAt[r] = round;
+    return true;
+}
+
+// final height of land cell x after the pass = value left by the latest event on x
+WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
+    if (F.ocean[x]) return F.e[x];
+    int32_t best = -1, bestRank = 0x7fffffff;      // latest == smallest rank
+    if (F.target[x] >= 0) { best = x; bestRank = F.rank[x]; }
+    for (int32_t j = F.off[x]; j < F.off[x + 1]; ++j) {
+        const int32_t n = F.adj[j];
+        if (F.ocean[n] || F.target[n] != x) continue;
+        const int32_t k = F.rank[n];
+        if (k < bestRank) { best = n; bestRank = k; }
+    }
+    if (best < 0) return F.e[x];
+    return (best == x) ? F.selfOut[x] : F.tOut[best];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thermal (js/terrain-post.js:645-686) in exact gather form
+// ------------------------------------------------------------------------------------------------
+WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) {
+    double total = 0;
+    if (!F.ocean[r]) {
+        const double h = F.e[r];
+        for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+            const int32_t nb = F.adj[j];
+            if (F.ocean[nb]) continue;
+            const double nh = F.e[nb];
+            if (nh >= h) continue;
+            const double d = nd_or_eps(F.dist[j]);
+            const double slope = (h - nh) / d;
+            if (slope > talus) total += (slope - talus) * d;
+        }
+    }
+    F.totalExcess[r] = total;
+}
+
+// new height of cell c (reads F.e, the pre-thermal field)
+WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, double kThermal) {
+    if (F.ocean[c]) return F.e[c];
+    const double h = F.e[c];
+    const int32_t myRank = F.rank[c];
+    const double myTotal = F.totalExcess[c];
+    const double myTransfer = kThermal * myTotal * 0.5;
+    // incoming shares from higher land neighbours, with the rank of the sender's turn
+    double inShare[WO_MAX_DEG]; int32_t inRank[WO_MAX_DEG]; int nIn = 0;
+    double outShare[WO_MAX_DEG]; int nOut = 0;
+    for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        if (F.ocean[nb]) continue;
+        const double nh = F.e[nb];
+        const double d = nd_or_eps(F.dist[j]);
+        if (nh < h) {                       // c sends to nb on c's own turn
+            const double slope = (h - nh) / d;
+            if (slope > talus && myTotal > 0) {
+                const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
+                outShare[nOut++] = ((double)excess / myTotal) * myTransfer;
+            }
+        } else if (nh > h) {                // nb may send to c on nb's turn
+            const double slope = (nh - h) / d;
+            if (slope > talus) {
+                const double tot = F.totalExcess[nb];
+                if (tot > 0) {
+                    const float excess = (float)((slope - talus) * d);
+                    inShare[nIn] = ((double)excess / tot) * (kThermal * tot * 0.5);
+                    inRank[nIn] = F.rank[nb];
+                    ++nIn;
+                }
+            }
+        }
+    }
+    if (nIn == 0 && nOut == 0) return (float)(h + 0.0);   // e += delta with delta == 0 (also maps -0 -> +0 like the f32 add)
+    float delta = 0.0f;
+    bool ownDone = (nOut == 0);
+    int32_t last = -1;
+    for (;;) {
+        // next incoming event in rank order
+        int pick = -1; int32_t pr = 0x7fffffff;
+        for (int k = 0; k < nIn; ++k) if (inRank[k] > last && inRank[k] < pr) { pr = inRank[k]; pick = k; }
+        if (!ownDone && (pick < 0 || myRank < pr)) {
+            for (int k = 0; k < nOut; ++k) delta = (float)((double)delta - outShare[k]);
+            ownDone = true;
+            continue;
+        }
+        if (pick < 0) break;
+        delta = (float)((double)delta + inShare[pick]);
+        last = pr;
+    }
+    return (float)(h + (double)delta);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Glacial (js/terrain-post.js:410-433, 475-557)
+// ------------------------------------------------------------------------------------------------
+WO_HD inline double smoothstep_js(double x, double e0, double e1) {
+    double t = (x - e0) / (e1 - e0);
+    if (!(t < 1)) t = (t != t) ? t : 1;
+    if (!(t > 0)) t = (t != t) ? t : 0;
+    return t * t * (3 - 2 * t);
+}
+
+WO_HD inline float glac_index_cell(const Fields& F, int32_t r, double glacialStrength) {
+    if (F.ocean[r]) return 0.0f;
+    const double PI_ = 3.141592653589793;
+    const double thresholdLat = PI_ / 2 - glacialStrength * PI_ / 4.5;
+    double y = F.xyz[3 * r + 1];
+    if (y > 1) y = 1;
+    if (y < -1) y = -1;
+    const double polarDist = fabs(asin(y));
+    const double latFactor = smoothstep_js(polarDist, thresholdLat, PI_ / 2);
+    const double elevFactor = smoothstep_js(F.e[r], 0.5, 0.9);
+    const double latScale = smoothstep_js(polarDist, PI_ / 8, PI_ / 3);
+    const double a = latFactor, b = elevFactor * 0.3 * (0.3 + 0.7 * latScale);
+    return (float)((a > b ? a : b) * glacialStrength);
+}
+
+// ice receivers (js/terrain-post.js:481-492); also resets the per-iteration state of the cell
+WO_HD inline void ice_receiver_cell(const Fields& F, int32_t r) {
+    int32_t bestNb = -1;
+    if (!F.ocean[r] && F.glac[r] > 0) {
+        const double h = F.e[r];
+        double bestDrop = 0;
+        for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+            const int32_t nb = F.adj[j];
+            const double drop = h - (double)F.e[nb];
+            if (drop > bestDrop) { bestDrop = drop; bestNb = nb; }
+        }
+    }
+    F.iceTarget[r] = bestNb;
+    F.doneAt[r] = WO_NOT_DONE;
+}
+
+// ice accumulation task for cell t (js/terrain-post.js:495-503): iceFlow[t] = glac[t] (+ donors in rank
+// order, each add rounded to f32).  Ocean cells can be targets too.  Runs when every donor is done.
+WO_HD inline bool ice_accumulate_task(const Fields& F, int32_t t, int32_t round) {
+    int32_t dn[WO_MAX_DEG]; int nd = 0;
+    for (int32_t j = F.off[t]; j < F.off[t + 1]; ++j) {
+        const int32_t n = F.adj[j];
+        if (F.iceTarget[n] != t) continue;
+        if (!(F.doneAt[n] < round)) return false;
+        dn[nd++] = n;
+    }
+    float acc = F.glac[t];
+    // donors in landCells order (ascending rank)
+    int32_t last = -1;
+    for (int k = 0; k < nd; ++k) {
+        int pick = -1; int32_t pr = 0x7fffffff;
+        for (int q = 0; q < nd; ++q) { const int32_t rk = F.rank[dn[q]]; if (rk > last && rk < pr) { pr = rk; pick = q; } }
+        // a donor forwards only if its own iceFlow > 0 (always true: glac > 0 for cells with a target)
+        const float df = F.iceFlow[dn[pick]];
+        if (df > 0) acc = (float)((double)acc + (double)df);
+        last = pr;
+    }
+    int up = 0;
+    for (int k = 0; k < nd; ++k) if (F.iceFlow[dn[k]] > 0) ++up;
+    F.iceFlow[t] = acc;
+    F.iceUp[t] = (uint8_t)up;
+    F.doneAt[t] = round;
+    return true;
+}
+
+// carve task activation: active iff land and iceFlow > 0.1 (js/terrain-post.js:508)
+WO_HD inline void carve_setup_cell(const Fields& F, int32_t r) {
+    const bool active = !F.ocean[r] && ((double)F.iceFlow[r] > 0.1);
+    F.arank[r] = active ? F.rank[r] : WO_NOT_DONE;
+    F.doneAt[r] = WO_NOT_DONE;
+}
+
+// in-place carve of cell r (js/terrain-post.js:506-526).  Ready when no unfinished active cell within
+// two hops has a lower rank.
+WO_HD inline bool carve_task(const Fields& F, int32_t r, int32_t round, double gCarveRate, double gConvergenceBonus,
+                             double glacialStrength) {
+    const int32_t myRank = F.arank[r];
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t n = F.adj[j];
+        if (F.arank[n] < myRank && !(F.doneAt[n] < round)) return false;
+        for (int32_t q = F.off[n]; q < F.off[n + 1]; ++q) {
+            const int32_t mcell = F.adj[q];
+            if (mcell == r) continue;
+            if (F.arank[mcell] < myRank && !(F.doneAt[mcell] < round)) return false;
+        }
+    }
+    const double fl = F.iceFlow[r];
+    const double deepening = gCarveRate * pow(fl, 0.6) * glacialStrength;
+    float er = (float)((double)F.e[r] - deepening);
+    F.e[r] = er;
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        if (F.ocean[nb]) continue;
+        const double d = nd_or_eps(F.dist[j]);
+        const double slope = fabs((double)er - (double)F.e[nb]) / d;
+        double f = 1 - slope;
+        if (!(f > 0)) f = (f != f) ? f : 0;
+        F.e[nb] = (float)((double)F.e[nb] - deepening * 0.4 * f);
+    }
+    if (F.iceUp[r] >= 2) F.e[r] = (float)((double)F.e[r] - gConvergenceBonus * pow(fl, 0.4));
+    F.doneAt[r] = round;
+    return true;
+}
+
+// moraine (js/terrain-post.js:529-537) gathered per target, then fjord (540-551) and clamp (554-556)
+WO_HD inline void moraine_fjord_cell(const Fields& F, int32_t t, double gDepositAmount, double gFjordCarve) {
+    if (F.ocean[t]) return;
+    float e = F.e[t];
+    int32_t last = -1;
+    for (;;) {
+        int32_t pick = -1, pr = 0x7fffffff;
+        for (int32_t j = F.off[t]; j < F.off[t + 1]; ++j) {
+            const int32_t n = F.adj[j];
+            if (F.iceTarget[n] != t) continue;
+            if (!((double)F.iceFlow[n] > 0.1)) continue;
+            if (!((double)F.glac[t] < (double)F.glac[n] * 0.3)) continue;
+            const int32_t rk = F.rank[n];
+            if (rk > last && rk < pr) { pr = rk; pick = n; }
+        }
+        if (pick < 0) break;
+        e = (float)((double)e + gDepositAmount * pow((double)F.iceFlow[pick], 0.3));
+        last = pr;
+    }
+    if ((double)F.glac[t] > 0.2 && (double)F.iceFlow[t] > 0.5 && F.coast[t]) {
+        e = (float)((double)e - gFjordCarve * pow((double)F.iceFlow[t], 0.5));
+        if (e < 0) e = 0;
+    }
+    if (e < 0) e = 0;
+    F.e[t] = e;
+}
+
+}  // namespace wo

@@ -1,0 +1,183 @@
+// gfx950 kernels of the terrain-post path.  Each kernel is a grid-stride wrapper around one body of
+// erode_ops.h (which documents the reference lines it restates); all launches go through wo::launch so the
+// HIP-event profiler sees them.  Wave64, 256-thread workgroups, no MFMA (no dense contraction anywhere on
+// this path): the passes are CSR gathers bounded by HBM/L2 bandwidth or, for the dependency rounds, by
+// launch latency.
+// (Included by planet.hip only: kernels and their host-side launches live in one translation unit.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device.h"
+
+namespace wo {
+
+#define WO_GRID_STRIDE(i, n) for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- fields / Jacobi ---------------
+__global__ __launch_bounds__(WO_BLOCK) void k_coast(Fields F, uint8_t* coast) {
+    WO_GRID_STRIDE(r, F.N) coast[r] = coast_flag(F, r);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_ocean_from_elev(const float* e, uint8_t* ocean, int32_t N) {
+    WO_GRID_STRIDE(r, N) ocean[r] = (e[r] <= 0.0f) ? 1 : 0;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_smooth(Fields F, const float* in, float* out, double strength) {
+    WO_GRID_STRIDE(r, F.N) out[r] = smooth_cell(F, in, r, strength);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_sharpen(Fields F, const float* in, const float* orig, float* out, double strength) {
+    WO_GRID_STRIDE(r, F.N) out[r] = sharpen_cell(F, in, orig, r, strength);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_creep(Fields F, const float* in, float* out, double strength) {
+    WO_GRID_STRIDE(r, F.N) out[r] = creep_cell(F, in, r, strength);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_glacial_blend(Fields F, const float* in, float* out) {
+    WO_GRID_STRIDE(r, F.N) out[r] = glacial_blend_cell(F, in, r);
+}
+
+// ---------------------------------------------------------------- noise -------------------------
+__device__ inline void load_tables(const uint8_t* tables, uint8_t* sP, uint8_t* sM) {
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) { sP[i] = tables[i]; sM[i] = tables[512 + i]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WO_BLOCK) void k_noise_eval(const uint8_t* tables, int32_t kind, int32_t octaves, double p0,
+                                                          double p1, double p2, int64_t n, const double* xyz, double* out) {
+    __shared__ uint8_t sP[512], sM[512];
+    load_tables(tables, sP, sM);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        double v;
+        if (kind == 0) v = noise3d(sP, sM, x, y, z);
+        else if (kind == 1) v = fbm(sP, sM, x, y, z, octaves, p0);
+        else v = ridged_fbm(sP, sM, x, y, z, octaves, p0, p1, p2);
+        out[i] = v;
+    }
+}
+
+// SURVEY 8(d) synthetic terrain: e = 0.9*fbm(1.5p,5) - 0.12 + 0.25*ridged(3p,4)*max(0,fbm(1.5p,5))
+__global__ __launch_bounds__(WO_BLOCK) void k_synthetic(const uint8_t* tables, const float* xyz, float* e, uint8_t* ocean, int32_t N) {
+    __shared__ uint8_t sP[512], sM[512];
+    load_tables(tables, sP, sM);
+    WO_GRID_STRIDE(r, N) {
+        const double x = xyz[3 * r], y = xyz[3 * r + 1], z = xyz[3 * r + 2];
+        const double f = fbm(sP, sM, x * 1.5, y * 1.5, z * 1.5, 5);
+        const double rg = ridged_fbm(sP, sM, x * 3, y * 3, z * 3, 4);
+        const float v = (float)(0.9 * f - 0.12 + 0.25 * rg * (f > 0 ? f : 0));
+        e[r] = v;
+        ocean[r] = (v <= 0.0f) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(WO_BLOCK) void k_warp(Fields F, const uint8_t* tables, const float* in, float* out, double maxAmp,
+                                                    double warpBias, const float* hot) {
+    __shared__ uint8_t sP[512], sM[512];
+    load_tables(tables, sP, sM);
+    WO_GRID_STRIDE(r, F.N) {
+        const int32_t src = warp_source_cell(F, sP, sM, r, maxAmp);
+        out[r] = warp_blend(in[r], in[src], warpBias, hot != nullptr, hot ? hot[r] : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------- land list ---------------------
+__global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N) { WO_GRID_STRIDE(r, N) rank[r] = -1; }
+
+// ---------------------------------------------------------------- hydraulic ---------------------
+__global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_GRID_STRIDE(r, F.N) receiver_cell(F, r); }
+
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_init(Fields F, int32_t* list, int32_t* count) {
+    WO_GRID_STRIDE(r, F.N) {
+        int32_t j = -1; uint32_t a = 0;
+        if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
+        F.accA[r] = a; F.jumpA[r] = j;
+        if (j >= 0) { const int32_t pos = atomicAdd(count, 1); list[pos] = r; }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_snap(Fields F, const int32_t* list, const int32_t* count, uint32_t* snap, int32_t* nj) {
+    const int32_t n = *count;
+    WO_GRID_STRIDE(i, n) { const int32_t d = list[i]; snap[i] = F.accA[d]; nj[i] = F.jumpA[F.jumpA[d]]; }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t* list, const int32_t* count, const uint32_t* snap,
+                                                          const int32_t* nj, int32_t* out, int32_t* outCount, int32_t* zeroCount) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    const int32_t n = *count;
+    WO_GRID_STRIDE(i, n) {
+        const int32_t d = list[i];
+        atomicAdd(&F.accA[F.jumpA[d]], snap[i]);
+        const int32_t j2 = nj[i];
+        F.jumpA[d] = j2;
+        if (j2 >= 0) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = d; }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F) {
+    WO_GRID_STRIDE(c, F.N) {
+        float fl = 0.0f;
+        if (!F.ocean[c]) {
+            uint32_t f = F.accA[c];
+            const int32_t rc = F.rank[c];
+            for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
+                const int32_t n = F.adj[j];
+                if (!F.ocean[n] && F.target[n] == c && F.rank[n] > rc) f += F.accA[n];   // late donors, un-forwarded
+            }
+            fl = (float)f;
+        }
+        F.flow[c] = fl;
+    }
+}
+
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_GRID_STRIDE(r, F.N) solve_setup_cell(F, r); }
+
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
+                                                           int32_t* outCount, int32_t* zeroCount, int32_t round, double K, double m, double dt) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    const int32_t n = *inCount;
+    WO_GRID_STRIDE(i, n) {
+        const int32_t r = in[i];
+        if (!solve_task(F, r, round, K, m, dt)) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = r; }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out) { WO_GRID_STRIDE(r, F.N) out[r] = solve_final_cell(F, r); }
+
+// ---------------------------------------------------------------- thermal -----------------------
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_GRID_STRIDE(r, F.N) thermal_excess_cell(F, r, talus); }
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out, double talus, double kThermal) {
+    WO_GRID_STRIDE(r, F.N) out[r] = thermal_apply_cell(F, r, talus, kThermal);
+}
+
+// ---------------------------------------------------------------- glacial -----------------------
+__global__ __launch_bounds__(WO_BLOCK) void k_glac_index(Fields F, double strength) { WO_GRID_STRIDE(r, F.N) F.glac[r] = glac_index_cell(F, r, strength); }
+__global__ __launch_bounds__(WO_BLOCK) void k_ice_receivers(Fields F) {
+    WO_GRID_STRIDE(r, F.N) { ice_receiver_cell(F, r); if (F.ocean[r]) { F.iceFlow[r] = 0.0f; F.iceUp[r] = 0; } }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_ice_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
+                                                         int32_t* outCount, int32_t* zeroCount, int32_t round) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    const int32_t n = *inCount;
+    WO_GRID_STRIDE(i, n) {
+        const int32_t t = in[i];
+        if (!ice_accumulate_task(F, t, round)) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = t; }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_setup(Fields F, int32_t* list, int32_t* count) {
+    WO_GRID_STRIDE(r, F.N) {
+        carve_setup_cell(F, r);
+        if (F.arank[r] != WO_NOT_DONE) { const int32_t pos = atomicAdd(count, 1); list[pos] = r; }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
+                                                           int32_t* outCount, int32_t* zeroCount, int32_t round, double gCarve,
+                                                           double gConv, double gStrength) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    const int32_t n = *inCount;
+    WO_GRID_STRIDE(i, n) {
+        const int32_t r = in[i];
+        if (!carve_task(F, r, round, gCarve, gConv, gStrength)) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = r; }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDep, double gFjord) {
+    WO_GRID_STRIDE(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
+}
+
+__global__ void k_set_counters(int32_t* c, int32_t v0, int32_t v1, int32_t v2, int32_t v3) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = v0; c[1] = v1; c[2] = v2; c[3] = v3; }
+}
+
+}  // namespace wo

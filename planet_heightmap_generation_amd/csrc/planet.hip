@@ -1,0 +1,695 @@
+// Device context, planet handle, pass orchestration and the device half of the C ABI (include/worogen.h).
+//
+// Orchestration follows the reference's call structure (js/terrain-post.js:369-707 for erodeComposite,
+// js/planet-worker.js:40-102 for the caller) but every per-cell loop is a kernel launch on the planet's
+// stream and every order-defined loop is executed as synchronous dependency rounds (erode_ops.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/worogen.h"
+#include "device.h"
+#include "kernels_impl.h"
+#include "noise.h"
+
+namespace wo {
+
+const char* const kFamilyNames[FAM_COUNT] = {
+    "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
+    "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
+    "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "misc"};
+
+hipEvent_t profile_event(wo_planet* p) {
+    if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
+    hipEvent_t e; WO_HIP(hipEventCreate(&e)); return e;
+}
+void profile_resolve(wo_planet* p) {
+    if (p->pending.empty()) return;
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    for (auto& pe : p->pending) {
+        float ms = 0; WO_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
+        p->famMs[pe.fam] += ms; p->famLaunches[pe.fam] += 1;
+        p->eventPool.push_back(pe.a); p->eventPool.push_back(pe.b);
+    }
+    p->pending.clear();
+}
+
+template <class T> static T* dalloc(size_t n) { void* q = nullptr; WO_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); return (T*)q; }
+template <class T> static void dfree(T*& q) { if (q) { (void)hipFree(q); q = nullptr; } }
+
+static void ensure_scratch(wo_planet* p) {
+    if (p->scratch) return;
+    const size_t N = (size_t)p->N;
+    p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
+    p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
+    p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_selfOut = dalloc<float>(N); p->d_tOut = dalloc<float>(N);
+    p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
+    p->d_predSelf = dalloc<int32_t>(N); p->d_predT = dalloc<int32_t>(N); p->d_predT2 = dalloc<int32_t>(N); p->d_doneAt = dalloc<int32_t>(N);
+    p->d_totalExcess = dalloc<double>(N);
+    p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
+    p->d_iceUp = dalloc<uint8_t>(N);
+    p->d_listA = dalloc<int32_t>(N); p->d_listB = dalloc<int32_t>(N); p->d_counters = dalloc<int32_t>(8);
+    p->sortTempBytes = sort_temp_bytes(p->N);
+    WO_HIP(hipMalloc(&p->d_sortTemp, std::max<size_t>(p->sortTempBytes, 16)));
+    WO_HIP(hipMemsetAsync(p->d_glac, 0, N * sizeof(float), p->ctx->stream));
+    p->scratch = true;
+}
+
+}  // namespace wo
+
+wo::Fields wo_planet::fields() const {
+    wo::Fields F{};
+    F.N = N; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.cellDist = d_cellDist;
+    F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
+    F.predSelf = d_predSelf; F.predT = d_predT; F.predT2 = d_predT2; F.selfOut = d_selfOut; F.tOut = d_tOut; F.doneAt = d_doneAt;
+    F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank;
+    return F;
+}
+
+namespace wo {
+
+static inline void swap_elev(wo_planet* p) { std::swap(p->d_e, p->d_e2); }
+
+static int32_t read_count(wo_planet* p, const int32_t* d_ptr) {
+    WO_HIP(hipMemcpyAsync(p->h_count, d_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream));
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    return p->h_count[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Synchronous dependency rounds.  Round k reads the list of pending tasks (count in counters[k%3]), runs
+// those whose predecessors finished in rounds < k and appends the rest to the other list (count in
+// counters[(k+1)%3]); counters[(k+2)%3] is zeroed for the round after.  Rounds are launched in batches and
+// the pending count is read back once per batch (the grid is sized by the last known count; counts only
+// shrink).  Returns the number of rounds launched.
+// ---------------------------------------------------------------------------------------------------
+template <class LaunchRound>
+static int64_t run_rounds(wo_planet* p, const int32_t* firstList, int32_t firstCount, bool countOnDevice, int batch,
+                          LaunchRound launchRound) {
+    int32_t* c = p->d_counters;
+    hipStream_t s = p->ctx->stream;
+    if (countOnDevice) {
+        // caller left the count in c[3]; move it to c[1], clear c[0], c[2]
+        WO_HIP(hipMemcpyAsync(c + 1, c + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        WO_HIP(hipMemsetAsync(c, 0, sizeof(int32_t), s));
+        WO_HIP(hipMemsetAsync(c + 2, 0, sizeof(int32_t), s));
+        firstCount = read_count(p, c + 1);
+    } else {
+        hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, firstCount, 0, 0);
+    }
+    int32_t count = firstCount;
+    int64_t k = 1;
+    const int32_t* in = firstList;
+    int32_t* out = p->d_listA;
+    while (count > 0) {
+        const int grid = blocks_for(count, 2048);
+        for (int b = 0; b < batch; ++b, ++k) {
+            launchRound((int32_t)k, in, (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), grid);
+            in = out;
+            out = (out == p->d_listA) ? p->d_listB : p->d_listA;
+        }
+        const int32_t next = read_count(p, c + (k % 3));
+        if (k > 4 * (int64_t)p->N + 1024) throw HipError{"dependency rounds do not converge"};
+        count = next;
+    }
+    return k - 1;
+}
+
+struct StageClock {
+    wo_planet* p; std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
+    explicit StageClock(wo_planet* pl) : p(pl) {}
+    void begin(const char* name) { hipEvent_t a = profile_event(p), b = profile_event(p); WO_HIP(hipEventRecord(a, p->ctx->stream)); ev.push_back({name, {a, b}}); }
+    void end() { WO_HIP(hipEventRecord(ev.back().second.second, p->ctx->stream)); }
+    void finish() {
+        WO_HIP(hipStreamSynchronize(p->ctx->stream));
+        std::map<std::string, double> acc; std::vector<std::string> order;
+        for (auto& e : ev) {
+            float ms = 0; WO_HIP(hipEventElapsedTime(&ms, e.second.first, e.second.second));
+            if (!acc.count(e.first)) order.push_back(e.first);
+            acc[e.first] += ms;
+            p->eventPool.push_back(e.second.first); p->eventPool.push_back(e.second.second);
+        }
+        p->stageTiming.clear();
+        for (auto& n : order) p->stageTiming.push_back({n, acc[n]});
+    }
+};
+
+// priorityFloodCarve: host stage (flood_host.cc) — one D2H + H2D round trip of the elevation field
+static void flood_stage(wo_planet* p, double carveStrength) {
+    hipStream_t s = p->ctx->stream;
+    const size_t bytes = (size_t)p->N * sizeof(float);
+    if (!p->h_ocean_valid) {
+        p->h_ocean.resize(p->N);
+        WO_HIP(hipMemcpyAsync(p->h_ocean.data(), p->d_ocean, p->N, hipMemcpyDeviceToHost, s));
+        p->h_ocean_valid = true;
+    }
+    WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    priority_flood_carve_host(p->N, p->h_off.data(), p->h_adj.data(), p->h_pinned, p->h_ocean.data(), carveStrength, p->flood);
+    WO_HIP(hipMemcpyAsync(p->d_e, p->h_pinned, bytes, hipMemcpyHostToDevice, s));
+}
+
+static void coast_flags(wo_planet* p) {
+    launch(p, FAM_COAST, k_coast, blocks_for(p->N), WO_BLOCK, p->fields(), p->d_coast);
+}
+
+// erodeComposite on the resident field (js/terrain-post.js:369-707)
+static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talus,
+                            double kThermal, int32_t gIters, double gStrength) {
+    if (gIters < 0) gIters = 0;
+    if (gStrength != gStrength) gStrength = 0;
+    const int32_t total = std::max(hIters, std::max(tIters, gIters));
+    p->stageTiming.clear(); p->erodeStats.clear();
+    if (total <= 0) return;
+    ensure_scratch(p);
+    hipStream_t s = p->ctx->stream;
+    const int32_t N = p->N;
+    const int gridN = blocks_for(N);
+    StageClock clk(p);
+    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0;
+    double floodHostMs = 0;
+
+    clk.begin("setup");
+    coast_flags(p);
+    // landCells in ascending r (js/terrain-post.js:384-390): host-side compaction of the ocean mask
+    if (!p->h_ocean_valid) {
+        p->h_ocean.resize(N);
+        WO_HIP(hipMemcpyAsync(p->h_ocean.data(), p->d_ocean, N, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipStreamSynchronize(s));
+        p->h_ocean_valid = true;
+    }
+    {
+        int32_t* hl = reinterpret_cast<int32_t*>(p->h_pinned);
+        int32_t L = 0;
+        for (int32_t r = 0; r < N; ++r) if (!p->h_ocean[r]) hl[L++] = r;
+        p->L = L;
+        if (L == 0) { clk.end(); clk.finish(); return; }
+        WO_HIP(hipMemcpyAsync(p->d_landIdx, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(p->d_land[0], p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        WO_HIP(hipStreamSynchronize(s));       // h_pinned is reused by the flood stage
+        p->landCur = 0;
+        launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
+    }
+    const int32_t L = p->L;
+    clk.end();
+
+    auto flood = [&](double cs) {
+        clk.begin("priority_flood(host)");
+        auto t0 = std::chrono::steady_clock::now();
+        flood_stage(p, cs);
+        floodHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        clk.end();
+    };
+    if (hIters > 0) flood(0.5);
+
+    const bool glacial = gIters > 0 && gStrength > 0;
+    if (glacial) launch(p, FAM_GLAC_INDEX, k_glac_index, gridN, WO_BLOCK, p->fields(), gStrength);
+    const double gScale = gIters > 0 ? 1.0 / gIters : 0;
+    const double gCarve = 0.02 * gScale, gConv = 0.01 * gScale, gDep = 0.005 * gScale, gFjord = 0.015 * gScale;
+    const int32_t midIter = (int32_t)std::floor(total * 0.75 + 0.5);
+    bool midDone = false;
+
+    for (int32_t iter = 0; iter < total; ++iter) {
+        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
+        const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
+        if (gNow || hNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
+
+        if (gNow) {
+            clk.begin("glacial");
+            Fields F = p->fields();
+            launch(p, FAM_ICE_RECV, k_ice_receivers, gridN, WO_BLOCK, F);
+            iceRounds += run_rounds(p, p->d_landIdx, L, false, 8,
+                [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
+                    launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
+                });
+            WO_HIP(hipMemsetAsync(p->d_counters + 3, 0, sizeof(int32_t), s));
+            launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
+            // the activation list was written to listB; rounds alternate A/B starting with out = A
+            carveRounds += run_rounds(p, p->d_listB, 0, true, 16,
+                [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
+                    launch(p, FAM_CARVE_ROUND, k_carve_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k, gCarve, gConv, gStrength);
+                });
+            launch(p, FAM_MORAINE, k_moraine_fjord, gridN, WO_BLOCK, F, gDep, gFjord);
+            clk.end();
+        }
+
+        if (hNow) {
+            if (gNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
+            Fields F = p->fields();
+            clk.begin("receivers");
+            launch(p, FAM_RECEIVERS, k_receivers, gridN, WO_BLOCK, F);
+            clk.end();
+            clk.begin("flow");
+            {
+                int32_t* c = p->d_counters;
+                WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
+                launch(p, FAM_FLOW_INIT, k_flow_init, gridN, WO_BLOCK, F, p->d_listB, c + 3);
+                flowRounds += run_rounds(p, p->d_listB, 0, true, 3,
+                    [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
+                        launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
+                        launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
+                               (const int32_t*)p->d_nj, out, outC, zeroC);
+                    });
+                launch(p, FAM_FLOW_FINAL, k_flow_final, gridN, WO_BLOCK, F);
+            }
+            clk.end();
+            clk.begin("solve");
+            launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridN, WO_BLOCK, F);
+            {
+                const int64_t r = run_rounds(p, p->d_landIdx, L, false, 32,
+                    [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
+                        launch(p, FAM_SOLVE_ROUND, k_solve_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k, K, m, dt);
+                    });
+                solveRounds += r; maxSolve = std::max(maxSolve, r);
+            }
+            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2);
+            swap_elev(p);
+            clk.end();
+        }
+
+        if (iter < tIters) {
+            clk.begin("thermal");
+            Fields F = p->fields();
+            launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridN, WO_BLOCK, F, talus);
+            launch(p, FAM_THERMAL_APPLY, k_thermal_apply, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+            swap_elev(p);
+            clk.end();
+        }
+    }
+    if (glacial) {
+        clk.begin("glacial_blend");
+        launch(p, FAM_GLAC_BLEND, k_glacial_blend, gridN, WO_BLOCK, p->fields(), (const float*)p->d_e, p->d_e2);
+        swap_elev(p);
+        clk.end();
+    }
+    clk.finish();
+    p->erodeStats = {{"land_cells", (double)L}, {"iterations", (double)total}, {"sorts", (double)sorts},
+                     {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
+                     {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
+                     {"carve_rounds_total", (double)carveRounds}, {"flood_host_ms", floodHostMs}};
+}
+
+static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
+    if (iterations <= 0) return;
+    coast_flags(p);
+    const int gridN = blocks_for(p->N);
+    hipStream_t s = p->ctx->stream;
+    if (kind == 1) WO_HIP(hipMemcpyAsync(p->d_orig, p->d_e, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int32_t it = 0; it < iterations; ++it) {
+        Fields F = p->fields();
+        if (kind == 0) launch(p, FAM_SMOOTH, k_smooth, gridN, WO_BLOCK, F, (const float*)p->d_e, p->d_e2, strength);
+        else if (kind == 1) launch(p, FAM_SHARPEN, k_sharpen, gridN, WO_BLOCK, F, (const float*)p->d_e, (const float*)p->d_orig, p->d_e2, strength);
+        else launch(p, FAM_CREEP, k_creep, gridN, WO_BLOCK, F, (const float*)p->d_e, p->d_e2, strength);
+        swap_elev(p);
+    }
+}
+
+static void upload_tables(wo_planet* p, double seed) {
+    uint8_t t[1024];
+    noise_tables(seed, t, t + 512);
+    WO_HIP(hipMemcpyAsync(p->d_tables, t, 1024, hipMemcpyHostToDevice, p->ctx->stream));
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));     // t is a stack buffer
+}
+
+static void warp(wo_planet* p, double seed, double strength, bool useHot) {
+    if (!(strength > 0)) return;          // js/terrain-post.js:234
+    upload_tables(p, seed + 9999);
+    const double maxAmp = 0.12 * strength, bias = 0.25 + 0.5 * strength;
+    launch(p, FAM_WARP, k_warp, blocks_for(p->N), WO_BLOCK, p->fields(), (const uint8_t*)p->d_tables, (const float*)p->d_e, p->d_e2,
+           maxAmp, bias, useHot ? (const float*)p->d_hot : (const float*)nullptr);
+    swap_elev(p);
+}
+
+}  // namespace wo
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+using namespace wo;
+
+#define WO_TRY try {
+#define WO_CATCH(fn)                                                                   \
+    } catch (const HipError& e) { set_error(std::string(fn) + ": " + e.msg); return 2; } \
+      catch (const std::exception& e) { set_error(std::string(fn) + ": " + e.what()); return 3; }
+
+static bool check_planet(wo_planet* p, const char* fn) {
+    if (!p) { set_error(std::string(fn) + ": null planet handle"); return false; }
+    hipError_t e = hipSetDevice(p->ctx->device);
+    if (e != hipSuccess) { set_error(std::string(fn) + ": hipSetDevice failed: " + hipGetErrorString(e)); return false; }
+    return true;
+}
+
+extern "C" {
+
+int wo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+wo_ctx* wo_ctx_create(int32_t device) {
+    try {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            set_error("wo_ctx_create: no usable HIP device (libworogen has no CPU fallback)");
+            return nullptr;
+        }
+        if (device < 0 || device >= n) { set_error("wo_ctx_create: device index out of range"); return nullptr; }
+        auto* c = new wo_ctx();
+        c->device = device;
+        WO_HIP(hipSetDevice(device));
+        WO_HIP(hipGetDeviceProperties(&c->prop, device));
+        WO_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        return c;
+    } catch (const HipError& e) { set_error(std::string("wo_ctx_create: ") + e.msg); return nullptr; }
+}
+
+void wo_ctx_destroy(wo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+wo_planet* wo_planet_create(wo_ctx* ctx, int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList,
+                            const float* r_xyz, const float* neighborDist) {
+    if (!ctx || numRegions < 1 || !adjOffset || !adjList || !r_xyz) { set_error("wo_planet_create: bad arguments"); return nullptr; }
+    wo_planet* p = nullptr;
+    try {
+        WO_HIP(hipSetDevice(ctx->device));
+        const int32_t N = numRegions, E = adjOffset[N];
+        int32_t maxDeg = 0;
+        if (adjOffset[0] != 0) { set_error("wo_planet_create: adjOffset[0] != 0"); return nullptr; }
+        for (int32_t r = 0; r < N; ++r) {
+            const int32_t d = adjOffset[r + 1] - adjOffset[r];
+            if (d < 0) { set_error("wo_planet_create: adjOffset is not monotone"); return nullptr; }
+            maxDeg = std::max(maxDeg, d);
+        }
+        if (maxDeg > WO_MAX_DEG) { set_error("wo_planet_create: vertex degree " + std::to_string(maxDeg) + " exceeds the supported maximum " + std::to_string(WO_MAX_DEG)); return nullptr; }
+        for (int32_t i = 0; i < E; ++i) if (adjList[i] < 0 || adjList[i] >= N) { set_error("wo_planet_create: adjList entry out of range"); return nullptr; }
+        p = new wo_planet();
+        p->ctx = ctx; p->N = N; p->E = E; p->maxDeg = maxDeg;
+        p->h_off.assign(adjOffset, adjOffset + N + 1);
+        p->h_adj.assign(adjList, adjList + E);
+        hipStream_t s = ctx->stream;
+        p->d_off = dalloc<int32_t>(N + 1); p->d_adj = dalloc<int32_t>(E); p->d_dist = dalloc<float>(E); p->d_xyz = dalloc<float>(3 * (size_t)N);
+        p->d_e = dalloc<float>(N); p->d_e2 = dalloc<float>(N); p->d_hot = dalloc<float>(N); p->d_orig = dalloc<float>(N);
+        p->d_ocean = dalloc<uint8_t>(N); p->d_coast = dalloc<uint8_t>(N); p->d_tables = dalloc<uint8_t>(1024);
+        WO_HIP(hipHostMalloc((void**)&p->h_pinned, std::max<size_t>((size_t)N * sizeof(float), 64)));
+        WO_HIP(hipHostMalloc((void**)&p->h_count, 64));
+        WO_HIP(hipMemcpyAsync(p->d_off, adjOffset, (size_t)(N + 1) * 4, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(p->d_adj, adjList, (size_t)E * 4, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(p->d_xyz, r_xyz, (size_t)N * 12, hipMemcpyHostToDevice, s));
+        if (neighborDist) {
+            WO_HIP(hipMemcpyAsync(p->d_dist, neighborDist, (size_t)E * 4, hipMemcpyHostToDevice, s));
+        } else {
+            std::vector<float> nd(E);
+            neighbor_dist(N, adjOffset, adjList, r_xyz, nd.data());
+            WO_HIP(hipMemcpyAsync(p->d_dist, nd.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+            WO_HIP(hipStreamSynchronize(s));
+        }
+        WO_HIP(hipMemsetAsync(p->d_e, 0, (size_t)N * 4, s));
+        WO_HIP(hipMemsetAsync(p->d_ocean, 0, (size_t)N, s));
+        WO_HIP(hipEventCreate(&p->evStart)); WO_HIP(hipEventCreate(&p->evStop));
+        WO_HIP(hipStreamSynchronize(s));
+        return p;
+    } catch (const HipError& e) {
+        set_error(std::string("wo_planet_create: ") + e.msg);
+        if (p) wo_planet_destroy(p);
+        return nullptr;
+    }
+}
+
+void wo_planet_destroy(wo_planet* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
+    dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
+    dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_selfOut); dfree(p->d_tOut); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_predSelf); dfree(p->d_predT); dfree(p->d_predT2); dfree(p->d_doneAt); dfree(p->d_totalExcess);
+    dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
+    dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters);
+    if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);
+    if (p->h_pinned) (void)hipHostFree(p->h_pinned);
+    if (p->h_count) (void)hipHostFree(p->h_count);
+    for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto e : p->eventPool) (void)hipEventDestroy(e);
+    if (p->evStart) (void)hipEventDestroy(p->evStart);
+    if (p->evStop) (void)hipEventDestroy(p->evStop);
+    delete p;
+}
+
+int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_isOcean) {
+    if (!check_planet(p, "wo_planet_upload")) return 1;
+    WO_TRY
+    hipStream_t s = p->ctx->stream;
+    if (r_elevation) WO_HIP(hipMemcpyAsync(p->d_e, r_elevation, (size_t)p->N * 4, hipMemcpyHostToDevice, s));
+    if (r_isOcean) {
+        WO_HIP(hipMemcpyAsync(p->d_ocean, r_isOcean, (size_t)p->N, hipMemcpyHostToDevice, s));
+        p->h_ocean.assign(r_isOcean, r_isOcean + p->N);
+        p->h_ocean_valid = true;
+    }
+    WO_HIP(hipStreamSynchronize(s));
+    return 0;
+    WO_CATCH("wo_planet_upload")
+}
+
+int wo_planet_download(wo_planet* p, float* r_elevation) {
+    if (!check_planet(p, "wo_planet_download") || !r_elevation) { if (p) set_error("wo_planet_download: null pointer"); return 1; }
+    WO_TRY
+    WO_HIP(hipMemcpyAsync(r_elevation, p->d_e, (size_t)p->N * 4, hipMemcpyDeviceToHost, p->ctx->stream));
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+    WO_CATCH("wo_planet_download")
+}
+
+int wo_planet_ocean_from_elevation(wo_planet* p) {
+    if (!check_planet(p, "wo_planet_ocean_from_elevation")) return 1;
+    WO_TRY
+    launch(p, FAM_OCEAN, k_ocean_from_elev, blocks_for(p->N), WO_BLOCK, (const float*)p->d_e, p->d_ocean, p->N);
+    p->h_ocean_valid = false;
+    return 0;
+    WO_CATCH("wo_planet_ocean_from_elevation")
+}
+
+int wo_planet_download_ocean(wo_planet* p, uint8_t* r_isOcean) {
+    if (!check_planet(p, "wo_planet_download_ocean") || !r_isOcean) { if (p) set_error("wo_planet_download_ocean: null pointer"); return 1; }
+    WO_TRY
+    WO_HIP(hipMemcpyAsync(r_isOcean, p->d_ocean, (size_t)p->N, hipMemcpyDeviceToHost, p->ctx->stream));
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+    WO_CATCH("wo_planet_download_ocean")
+}
+
+int wo_planet_sync(wo_planet* p) {
+    if (!check_planet(p, "wo_planet_sync")) return 1;
+    WO_TRY
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    return 0;
+    WO_CATCH("wo_planet_sync")
+}
+
+int wo_planet_save_state(wo_planet* p) {
+    if (!check_planet(p, "wo_planet_save_state")) return 1;
+    WO_TRY
+    if (!p->d_savedE) { p->d_savedE = dalloc<float>(p->N); p->d_savedOcean = dalloc<uint8_t>(p->N); }
+    WO_HIP(hipMemcpyAsync(p->d_savedE, p->d_e, (size_t)p->N * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
+    WO_HIP(hipMemcpyAsync(p->d_savedOcean, p->d_ocean, (size_t)p->N, hipMemcpyDeviceToDevice, p->ctx->stream));
+    p->saved = true;
+    return 0;
+    WO_CATCH("wo_planet_save_state")
+}
+
+int wo_planet_restore_state(wo_planet* p) {
+    if (!check_planet(p, "wo_planet_restore_state")) return 1;
+    if (!p->saved) { set_error("wo_planet_restore_state: nothing saved"); return 1; }
+    WO_TRY
+    WO_HIP(hipMemcpyAsync(p->d_e, p->d_savedE, (size_t)p->N * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
+    WO_HIP(hipMemcpyAsync(p->d_ocean, p->d_savedOcean, (size_t)p->N, hipMemcpyDeviceToDevice, p->ctx->stream));
+    p->h_ocean_valid = false;
+    return 0;
+    WO_CATCH("wo_planet_restore_state")
+}
+
+int wo_planet_upload_hotspot(wo_planet* p, const float* r_hotspot) {
+    if (!check_planet(p, "wo_planet_upload_hotspot") || !r_hotspot) { if (p) set_error("wo_planet_upload_hotspot: null pointer"); return 1; }
+    WO_TRY
+    WO_HIP(hipMemcpyAsync(p->d_hot, r_hotspot, (size_t)p->N * 4, hipMemcpyHostToDevice, p->ctx->stream));
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    p->hot_valid = true;
+    return 0;
+    WO_CATCH("wo_planet_upload_hotspot")
+}
+
+int wo_warp_terrain_resident(wo_planet* p, double seed, double strength, int32_t useHotspot) {
+    if (!check_planet(p, "wo_warp_terrain_resident")) return 1;
+    if (useHotspot && !p->hot_valid) { set_error("wo_warp_terrain_resident: no hotspot field uploaded"); return 1; }
+    WO_TRY
+    warp(p, seed, strength, useHotspot != 0);
+    return 0;
+    WO_CATCH("wo_warp_terrain_resident")
+}
+
+int wo_smooth_elevation_resident(wo_planet* p, int32_t iterations, double strength) {
+    if (!check_planet(p, "wo_smooth_elevation_resident")) return 1;
+    WO_TRY jacobi(p, 0, iterations, strength); return 0; WO_CATCH("wo_smooth_elevation_resident")
+}
+int wo_sharpen_ridges_resident(wo_planet* p, int32_t iterations, double strength) {
+    if (!check_planet(p, "wo_sharpen_ridges_resident")) return 1;
+    WO_TRY jacobi(p, 1, iterations, strength); return 0; WO_CATCH("wo_sharpen_ridges_resident")
+}
+int wo_soil_creep_resident(wo_planet* p, int32_t iterations, double strength) {
+    if (!check_planet(p, "wo_soil_creep_resident")) return 1;
+    WO_TRY jacobi(p, 2, iterations, strength); return 0; WO_CATCH("wo_soil_creep_resident")
+}
+
+int wo_erode_composite_resident(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talusSlope,
+                                double kThermal, int32_t gIters, double glacialStrength) {
+    if (!check_planet(p, "wo_erode_composite_resident")) return 1;
+    WO_TRY
+    erode_composite(p, hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength);
+    return 0;
+    WO_CATCH("wo_erode_composite_resident")
+}
+
+int wo_planet_synthetic_terrain(wo_planet* p, double seed) {
+    if (!check_planet(p, "wo_planet_synthetic_terrain")) return 1;
+    WO_TRY
+    upload_tables(p, seed);
+    launch(p, FAM_SYNTH, k_synthetic, blocks_for(p->N), WO_BLOCK, (const uint8_t*)p->d_tables, (const float*)p->d_xyz, p->d_e, p->d_ocean, p->N);
+    p->h_ocean_valid = false;
+    return 0;
+    WO_CATCH("wo_planet_synthetic_terrain")
+}
+
+// ---- JS call surface: host arrays in, mutated in place ----
+static int with_host_field(wo_planet* p, const char* fn, float* e, const uint8_t* oc, bool needOcean, void (*body)(wo_planet*, void*), void* arg) {
+    if (!check_planet(p, fn)) return 1;
+    if (!e || (needOcean && !oc)) { set_error(std::string(fn) + ": null pointer"); return 1; }
+    try {
+        int rc = wo_planet_upload(p, e, oc);
+        if (rc) return rc;
+        body(p, arg);
+        return wo_planet_download(p, e);
+    } catch (const HipError& ex) { set_error(std::string(fn) + ": " + ex.msg); return 2; }
+      catch (const std::exception& ex) { set_error(std::string(fn) + ": " + ex.what()); return 3; }
+}
+
+struct JacArgs { int kind; int32_t it; double s; };
+struct WarpArgs { double seed, strength; bool hot; };
+struct ErodeArgs { int32_t h; double K, m, dt; int32_t t; double talus, kT; int32_t g; double gs; };
+
+int wo_warp_terrain(wo_planet* p, float* r_elevation, double seed, double strength, const float* r_hotspot) {
+    if (p && r_hotspot) { int rc = wo_planet_upload_hotspot(p, r_hotspot); if (rc) return rc; }
+    WarpArgs a{seed, strength, r_hotspot != nullptr};
+    return with_host_field(p, "wo_warp_terrain", r_elevation, nullptr, false,
+                           [](wo_planet* q, void* v) { auto* w = (WarpArgs*)v; warp(q, w->seed, w->strength, w->hot); }, &a);
+}
+int wo_smooth_elevation(wo_planet* p, float* e, const uint8_t* oc, int32_t it, double s) {
+    JacArgs a{0, it, s};
+    return with_host_field(p, "wo_smooth_elevation", e, oc, true, [](wo_planet* q, void* v) { auto* j = (JacArgs*)v; jacobi(q, j->kind, j->it, j->s); }, &a);
+}
+int wo_sharpen_ridges(wo_planet* p, float* e, const uint8_t* oc, int32_t it, double s) {
+    JacArgs a{1, it, s};
+    return with_host_field(p, "wo_sharpen_ridges", e, oc, true, [](wo_planet* q, void* v) { auto* j = (JacArgs*)v; jacobi(q, j->kind, j->it, j->s); }, &a);
+}
+int wo_soil_creep(wo_planet* p, float* e, const uint8_t* oc, int32_t it, double s) {
+    JacArgs a{2, it, s};
+    return with_host_field(p, "wo_soil_creep", e, oc, true, [](wo_planet* q, void* v) { auto* j = (JacArgs*)v; jacobi(q, j->kind, j->it, j->s); }, &a);
+}
+int wo_erode_composite(wo_planet* p, float* e, const uint8_t* oc, int32_t hIters, double K, double m, double dt, int32_t tIters,
+                       double talusSlope, double kThermal, int32_t gIters, double glacialStrength) {
+    ErodeArgs a{hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength};
+    return with_host_field(p, "wo_erode_composite", e, oc, true,
+                           [](wo_planet* q, void* v) { auto* x = (ErodeArgs*)v; erode_composite(q, x->h, x->K, x->m, x->dt, x->t, x->talus, x->kT, x->g, x->gs); }, &a);
+}
+
+int wo_noise_eval(wo_ctx* ctx, double seed, int32_t kind, int32_t octaves, double p0, double p1, double p2, int64_t n,
+                  const double* xyz, double* out) {
+    if (!ctx || !xyz || !out || n < 0 || kind < 0 || kind > 2) { set_error("wo_noise_eval: bad arguments"); return 1; }
+    if (n == 0) return 0;
+    double *d_in = nullptr, *d_out = nullptr; uint8_t* d_t = nullptr;
+    try {
+        WO_HIP(hipSetDevice(ctx->device));
+        uint8_t t[1024];
+        noise_tables(seed, t, t + 512);
+        d_in = dalloc<double>(3 * (size_t)n); d_out = dalloc<double>((size_t)n); d_t = dalloc<uint8_t>(1024);
+        hipStream_t s = ctx->stream;
+        WO_HIP(hipMemcpyAsync(d_t, t, 1024, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(d_in, xyz, 3 * (size_t)n * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_noise_eval, dim3(blocks_for(n, 4096)), dim3(WO_BLOCK), 0, s, (const uint8_t*)d_t, kind, octaves, p0, p1, p2, n,
+                           (const double*)d_in, d_out);
+        WO_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipStreamSynchronize(s));
+        dfree(d_in); dfree(d_out); dfree(d_t);
+        return 0;
+    } catch (const HipError& e) { dfree(d_in); dfree(d_out); dfree(d_t); set_error(std::string("wo_noise_eval: ") + e.msg); return 2; }
+}
+
+// ---- measurement ----
+int wo_timer_start(wo_planet* p) {
+    if (!check_planet(p, "wo_timer_start")) return 1;
+    WO_TRY WO_HIP(hipEventRecord(p->evStart, p->ctx->stream)); return 0; WO_CATCH("wo_timer_start")
+}
+int wo_timer_stop_ms(wo_planet* p, double* ms) {
+    if (!check_planet(p, "wo_timer_stop_ms") || !ms) return 1;
+    WO_TRY
+    WO_HIP(hipEventRecord(p->evStop, p->ctx->stream));
+    WO_HIP(hipEventSynchronize(p->evStop));
+    float f = 0; WO_HIP(hipEventElapsedTime(&f, p->evStart, p->evStop));
+    *ms = f;
+    return 0;
+    WO_CATCH("wo_timer_stop_ms")
+}
+int wo_profile_enable(wo_planet* p, int32_t on) {
+    if (!check_planet(p, "wo_profile_enable")) return 1;
+    WO_TRY if (!on) profile_resolve(p); p->profiling = on != 0; return 0; WO_CATCH("wo_profile_enable")
+}
+int wo_profile_reset(wo_planet* p) {
+    if (!check_planet(p, "wo_profile_reset")) return 1;
+    WO_TRY
+    profile_resolve(p);
+    for (int i = 0; i < FAM_COUNT; ++i) { p->famMs[i] = 0; p->famLaunches[i] = 0; }
+    return 0;
+    WO_CATCH("wo_profile_reset")
+}
+int wo_profile_report(wo_planet* p, int32_t cap, const char** names, double* total_ms, int64_t* launches, int32_t* count) {
+    if (!check_planet(p, "wo_profile_report") || !count) return 1;
+    WO_TRY
+    profile_resolve(p);
+    int32_t n = 0;
+    for (int i = 0; i < FAM_COUNT && n < cap; ++i) {
+        if (p->famLaunches[i] == 0) continue;
+        if (names) names[n] = kFamilyNames[i];
+        if (total_ms) total_ms[n] = p->famMs[i];
+        if (launches) launches[n] = p->famLaunches[i];
+        ++n;
+    }
+    *count = n;
+    return 0;
+    WO_CATCH("wo_profile_report")
+}
+int wo_last_stage_timing(wo_planet* p, int32_t cap, const char** stages, double* ms, int32_t* count) {
+    if (!p || !count) return 1;
+    int32_t n = 0;
+    for (auto& st : p->stageTiming) { if (n >= cap) break; if (stages) stages[n] = st.first.c_str(); if (ms) ms[n] = st.second; ++n; }
+    *count = n;
+    return 0;
+}
+int wo_last_erode_stats(wo_planet* p, int32_t cap, const char** names, double* values, int32_t* count) {
+    if (!p || !count) return 1;
+    int32_t n = 0;
+    for (auto& st : p->erodeStats) { if (n >= cap) break; if (names) names[n] = st.first.c_str(); if (values) values[n] = st.second; ++n; }
+    *count = n;
+    return 0;
+}
+
+}  // extern "C"

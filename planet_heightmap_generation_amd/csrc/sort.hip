@@ -1,0 +1,48 @@
+// Stable descending sort of landCells by float32 elevation (reference: the in-place
+// landCells.sort((a,b) => r_elevation[b] - r_elevation[a]) at js/terrain-post.js:471,563 — V8's sort is
+// stable, so ties keep the previous iteration's order).  A stable LSD radix sort of (key, cell) pairs taken
+// in the previous order reproduces that exactly; keys map -0 and +0 to the same value (erode_ops.h).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "device.h"
+
+namespace wo {
+
+__global__ __launch_bounds__(WO_BLOCK) void k_sort_keys(const float* __restrict__ e, const int32_t* __restrict__ land,
+                                                         uint32_t* __restrict__ keys, int32_t L) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x)
+        keys[i] = desc_key(e[land[i]]);
+}
+
+__global__ __launch_bounds__(WO_BLOCK) void k_rank_scatter(const int32_t* __restrict__ land, int32_t* __restrict__ rank, int32_t L) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x)
+        rank[land[i]] = i;
+}
+
+size_t sort_temp_bytes(int32_t n) {
+    size_t bytes = 0;
+    hipcub::DoubleBuffer<uint32_t> k(nullptr, nullptr);
+    hipcub::DoubleBuffer<int32_t> v(nullptr, nullptr);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, v, n, 0, 32, nullptr);
+    return bytes;
+}
+
+void sort_land_by_elevation(wo_planet* p) {
+    const int32_t L = p->L;
+    const int cur = p->landCur;
+    launch(p, FAM_SORT_KEYS, k_sort_keys, blocks_for(L, 4096), WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_land[cur],
+           p->d_keys[0], L);
+    hipcub::DoubleBuffer<uint32_t> k(p->d_keys[0], p->d_keys[1]);
+    hipcub::DoubleBuffer<int32_t> v(p->d_land[cur], p->d_land[cur ^ 1]);
+    hipStream_t s = p->ctx->stream;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+    size_t bytes = p->sortTempBytes;
+    WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, k, v, L, 0, 32, s));
+    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_SORT_RADIX, a, b}); }
+    p->landCur = (v.Current() == p->d_land[cur]) ? cur : (cur ^ 1);
+    launch(p, FAM_RANK, k_rank_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, L);
+}
+
+}  // namespace wo

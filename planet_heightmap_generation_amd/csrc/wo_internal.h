@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace wo {
 
@@ -11,6 +12,17 @@ int sphere_delaunay(int V, const float* xyz, int* triangles, int* halfedges, std
 int mesh_csr(int V, int numSides, const int* triangles, const int* halfedges,
              int* adjOffset, int* adjList, int* adjTri, std::string& err);
 void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float* xyz, float* out);
+
+// flood_host.cc
+struct FloodScratch {
+    std::vector<int32_t> label, stack, drainTo, path, order, order2;
+    std::vector<uint8_t> open, visited;
+    std::vector<float> surface, key;
+    std::vector<uint32_t> bits, bits2;
+    void ensure(int32_t N);
+};
+void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, float* e,
+                               const uint8_t* ocean, double carveStrength, FloodScratch& S);
 
 // error slot used by every extern "C" entry point (thread-local)
 void set_error(const std::string& msg);

@@ -1,0 +1,206 @@
+// TEST-ONLY emulator: drives the kernel bodies of planet_heightmap_generation_amd/csrc/erode_ops.h one
+// "thread" at a time on the CPU, with the same round structure the HIP host code uses (a task may only
+// consume results of earlier rounds).  It exists because the build container has no GPU: it lets the
+// parallel re-formulations be checked bit-for-bit against the oracle before they are run on gfx950.
+// It is never linked into libworogen.so and is not reachable from the product API.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "../../planet_heightmap_generation_amd/csrc/erode_ops.h"
+#include "../../planet_heightmap_generation_amd/csrc/wo_internal.h"
+
+using namespace wo;
+
+namespace {
+
+struct Emu {
+    Fields F{};
+    std::vector<uint8_t> coast, iceUp;
+    std::vector<float> e2, cellDist, flow, selfOut, tOut, glac, iceFlow;
+    std::vector<int32_t> land, landIdx, rank, target, jumpA, predSelf, predT, predT2, doneAt, iceTarget, arank;
+    std::vector<uint32_t> accA;
+    std::vector<double> totalExcess;
+    int64_t solveRounds = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, maxSolveRounds = 0;
+};
+
+void stable_sort_desc(Emu& E) {
+    const int32_t L = E.F.L;
+    std::vector<uint32_t> k0(L), k1(L);
+    std::vector<int32_t> v1(L);
+    for (int32_t i = 0; i < L; ++i) k0[i] = desc_key(E.F.e[E.land[i]]);
+    for (int pass = 0; pass < 4; ++pass) {
+        uint32_t cnt[257] = {0};
+        const int sh = pass * 8;
+        for (int32_t i = 0; i < L; ++i) cnt[((k0[i] >> sh) & 255) + 1]++;
+        for (int i = 0; i < 256; ++i) cnt[i + 1] += cnt[i];
+        for (int32_t i = 0; i < L; ++i) { uint32_t d = cnt[(k0[i] >> sh) & 255]++; k1[d] = k0[i]; v1[d] = E.land[i]; }
+        k0.swap(k1); E.land.swap(v1);
+    }
+    E.F.land = E.land.data();
+    for (int32_t i = 0; i < L; ++i) E.rank[E.land[i]] = i;
+}
+
+// generic synchronous rounds over a task list
+template <class Task>
+int64_t run_rounds(std::vector<int32_t> list, Task task) {
+    int64_t round = 0;
+    std::vector<int32_t> next;
+    while (!list.empty()) {
+        ++round;
+        next.clear();
+        for (int32_t r : list) if (!task(r, (int32_t)round)) next.push_back(r);
+        if (next.size() == list.size()) return -round;   // no progress: dependency cycle (bug)
+        list.swap(next);
+    }
+    return round;
+}
+
+}  // namespace
+
+extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t* adj, float* e, const float* xyz,
+                                   const uint8_t* ocean, int32_t hIters, double K, double m, double dt,
+                                   int32_t tIters, double talus, double kThermal, int32_t gIters, double gStrength,
+                                   const float* dist, double* stats /* 8 */) {
+    if (gIters < 0) gIters = 0;
+    int32_t total = hIters > tIters ? hIters : tIters;
+    if (gIters > total) total = gIters;
+    if (total <= 0) return 0;
+    Emu E;
+    Fields& F = E.F;
+    F.N = N; F.off = off; F.adj = adj; F.dist = dist; F.xyz = xyz; F.ocean = ocean; F.e = e;
+    E.coast.resize(N); E.e2.resize(N); E.rank.assign(N, -1); E.target.resize(N); E.cellDist.resize(N); E.flow.resize(N);
+    E.accA.resize(N); E.jumpA.resize(N); E.predSelf.resize(N); E.predT.resize(N); E.predT2.resize(N);
+    E.selfOut.resize(N); E.tOut.resize(N); E.doneAt.resize(N); E.totalExcess.resize(N);
+    E.glac.assign(N, 0.f); E.iceTarget.resize(N); E.iceFlow.resize(N); E.iceUp.resize(N); E.arank.resize(N);
+    F.e2 = E.e2.data(); F.rank = E.rank.data(); F.target = E.target.data(); F.cellDist = E.cellDist.data();
+    F.flow = E.flow.data(); F.accA = E.accA.data(); F.jumpA = E.jumpA.data(); F.predSelf = E.predSelf.data();
+    F.predT = E.predT.data(); F.predT2 = E.predT2.data(); F.selfOut = E.selfOut.data(); F.tOut = E.tOut.data();
+    F.doneAt = E.doneAt.data(); F.totalExcess = E.totalExcess.data(); F.glac = E.glac.data();
+    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data();
+    F.coast = E.coast.data();
+    for (int32_t r = 0; r < N; ++r) E.coast[r] = coast_flag(F, r);
+    for (int32_t r = 0; r < N; ++r) if (!ocean[r]) E.land.push_back(r);
+    E.landIdx = E.land;
+    F.L = (int32_t)E.land.size(); F.land = E.land.data();
+    if (F.L == 0) return 0;
+    for (int32_t i = 0; i < F.L; ++i) E.rank[E.land[i]] = i;
+    FloodScratch fs;
+    if (hIters > 0) priority_flood_carve_host(N, off, adj, e, ocean, 0.5, fs);
+    const bool glacial = gIters > 0 && gStrength > 0;
+    if (glacial) for (int32_t r = 0; r < N; ++r) E.glac[r] = glac_index_cell(F, r, gStrength);
+    const double gScale = gIters > 0 ? 1.0 / gIters : 0;
+    const double gCarve = 0.02 * gScale, gConv = 0.01 * gScale, gDep = 0.005 * gScale, gFjord = 0.015 * gScale;
+    const int32_t midIter = (int32_t)std::floor(total * 0.75 + 0.5);
+    bool midDone = false;
+    int rc = 0;
+    for (int32_t iter = 0; iter < total; ++iter) {
+        if (!midDone && iter >= midIter) { midDone = true; priority_flood_carve_host(N, off, adj, e, ocean, 0.85, fs); }
+        const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
+        if (gNow || hNow) stable_sort_desc(E);
+        if (gNow) {
+            for (int32_t r = 0; r < N; ++r) ice_receiver_cell(F, r);
+            for (int32_t r = 0; r < N; ++r) if (ocean[r]) { F.iceFlow[r] = 0; F.iceUp[r] = 0; }
+            int64_t n1 = run_rounds(E.landIdx, [&](int32_t t, int32_t k) { return ice_accumulate_task(F, t, k); });
+            if (n1 < 0) rc = 10;
+            E.iceRounds += n1;
+            std::vector<int32_t> act;
+            for (int32_t r = 0; r < N; ++r) { carve_setup_cell(F, r); }
+            for (int32_t r : E.landIdx) if (F.arank[r] != WO_NOT_DONE) act.push_back(r);
+            int64_t n2 = run_rounds(act, [&](int32_t r, int32_t k) { return carve_task(F, r, k, gCarve, gConv, gStrength); });
+            if (n2 < 0) rc = 11;
+            E.carveRounds += n2;
+            for (int32_t r = 0; r < N; ++r) moraine_fjord_cell(F, r, gDep, gFjord);
+        }
+        if (hNow) {
+            if (gNow) stable_sort_desc(E);
+            for (int32_t r = 0; r < N; ++r) receiver_cell(F, r);
+            // flow: pointer doubling over the forward forest
+            std::vector<int32_t> act, nj;
+            std::vector<uint32_t> snap;
+            for (int32_t r = 0; r < N; ++r) { F.accA[r] = ocean[r] ? 0u : 1u; F.jumpA[r] = ocean[r] ? -1 : flow_forward_target(F, r); }
+            for (int32_t r : E.landIdx) if (F.jumpA[r] >= 0) act.push_back(r);
+            while (!act.empty()) {
+                ++E.flowRounds;
+                snap.resize(act.size()); nj.resize(act.size());
+                for (size_t i = 0; i < act.size(); ++i) { const int32_t d = act[i]; snap[i] = F.accA[d]; nj[i] = F.jumpA[F.jumpA[d]]; }
+                std::vector<int32_t> nxt;
+                for (size_t i = 0; i < act.size(); ++i) {
+                    const int32_t d = act[i];
+                    F.accA[F.jumpA[d]] += snap[i];
+                    F.jumpA[d] = nj[i];
+                    if (nj[i] >= 0) nxt.push_back(d);
+                }
+                act.swap(nxt);
+            }
+            for (int32_t c = 0; c < N; ++c) {
+                if (ocean[c]) { F.flow[c] = 0; continue; }
+                uint32_t f = F.accA[c];
+                for (int32_t j = off[c]; j < off[c + 1]; ++j) {
+                    const int32_t n = adj[j];
+                    if (!ocean[n] && F.target[n] == c && F.rank[n] > F.rank[c]) f += F.accA[n];
+                }
+                F.flow[c] = (float)f;
+            }
+            for (int32_t r = 0; r < N; ++r) solve_setup_cell(F, r);
+            int64_t n3 = run_rounds(E.landIdx, [&](int32_t r, int32_t k) { return solve_task(F, r, k, K, m, dt); });
+            if (n3 < 0) rc = 12;
+            E.solveRounds += n3; if (n3 > E.maxSolveRounds) E.maxSolveRounds = n3;
+            for (int32_t r = 0; r < N; ++r) F.e2[r] = solve_final_cell(F, r);
+            std::memcpy(e, F.e2, sizeof(float) * (size_t)N);
+        }
+        if (iter < tIters) {
+            for (int32_t r = 0; r < N; ++r) thermal_excess_cell(F, r, talus);
+            for (int32_t r = 0; r < N; ++r) F.e2[r] = thermal_apply_cell(F, r, talus, kThermal);
+            std::memcpy(e, F.e2, sizeof(float) * (size_t)N);
+        }
+    }
+    if (glacial) {
+        for (int32_t r = 0; r < N; ++r) F.e2[r] = glacial_blend_cell(F, e, r);
+        std::memcpy(e, F.e2, sizeof(float) * (size_t)N);
+    }
+    if (stats) {
+        stats[0] = (double)F.L; stats[1] = (double)E.solveRounds; stats[2] = (double)E.maxSolveRounds;
+        stats[3] = (double)E.flowRounds; stats[4] = (double)E.iceRounds; stats[5] = (double)E.carveRounds;
+    }
+    return rc;
+}
+
+extern "C" void emu_jacobi(int32_t kind, int32_t N, const int32_t* off, const int32_t* adj, float* e,
+                           const uint8_t* ocean, int32_t iterations, double strength) {
+    Fields F{};
+    F.N = N; F.off = off; F.adj = adj; F.ocean = ocean; F.e = e;
+    std::vector<uint8_t> coast(N);
+    F.coast = coast.data();
+    for (int32_t r = 0; r < N; ++r) coast[r] = coast_flag(F, r);
+    std::vector<float> tmp(N), original(e, e + N);
+    for (int32_t it = 0; it < iterations; ++it) {
+        for (int32_t r = 0; r < N; ++r)
+            tmp[r] = kind == 0 ? smooth_cell(F, e, r, strength) : kind == 1 ? sharpen_cell(F, e, original.data(), r, strength)
+                                                                           : creep_cell(F, e, r, strength);
+        std::memcpy(e, tmp.data(), sizeof(float) * (size_t)N);
+    }
+}
+
+extern "C" void emu_warp(int32_t N, const int32_t* off, const int32_t* adj, float* e, const float* xyz, double seed,
+                         double strength, const float* hot) {
+    if (strength <= 0) return;
+    Fields F{};
+    F.N = N; F.off = off; F.adj = adj; F.xyz = xyz; F.e = e;
+    uint8_t P[512], M[512];
+    noise_tables(seed + 9999, P, M);
+    std::vector<float> out(N);
+    const double maxAmp = 0.12 * strength, bias = 0.25 + 0.5 * strength;
+    for (int32_t r = 0; r < N; ++r) {
+        const int32_t src = warp_source_cell(F, P, M, r, maxAmp);
+        out[r] = warp_blend(e[r], e[src], bias, hot != nullptr, hot ? hot[r] : 0.f);
+    }
+    std::memcpy(e, out.data(), sizeof(float) * (size_t)N);
+}
+
+extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, float* e, const uint8_t* ocean, double cs) {
+    FloodScratch fs;
+    priority_flood_carve_host(N, off, adj, e, ocean, cs, fs);
+}
