@@ -125,5 +125,6 @@ inline void launch(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, in
 // sort.hip: stable descending sort of the land list by current elevation + rank scatter
 void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
+void rank_from_land(wo_planet* p);
 
 }  // namespace wo

@@ -195,6 +195,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         WO_HIP(hipStreamSynchronize(s));       // h_pinned is reused by the flood stage
         p->landCur = 0;
         launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
+        rank_from_land(p);      // thermal-only runs never sort: landCells stays in ascending-r order
     }
     const int32_t L = p->L;
     clk.end();

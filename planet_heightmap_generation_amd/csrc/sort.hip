@@ -20,6 +20,11 @@ __global__ __launch_bounds__(WO_BLOCK) void k_rank_scatter(const int32_t* __rest
         rank[land[i]] = i;
 }
 
+// rank[] for the current (e.g. initial ascending-r) order without sorting
+void rank_from_land(wo_planet* p) {
+    launch(p, FAM_RANK, k_rank_scatter, blocks_for(p->L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, p->L);
+}
+
 size_t sort_temp_bytes(int32_t n) {
     size_t bytes = 0;
     hipcub::DoubleBuffer<uint32_t> k(nullptr, nullptr);
