@@ -25,6 +25,8 @@ struct HipError { std::string msg; };
     } while (0)
 
 constexpr int WO_BLOCK = 256;
+constexpr int WO_LEVEL_BITS = 12;                       // predicted solve levels are clamped to 4095
+constexpr int WO_MAX_LEVEL = (1 << WO_LEVEL_BITS) - 1;
 inline int blocks_for(int64_t n, int maxBlocks = 1 << 20) {
     int64_t b = (n + WO_BLOCK - 1) / WO_BLOCK;
     if (b < 1) b = 1;
@@ -38,7 +40,7 @@ enum Family : int {
     FAM_SORT_KEYS, FAM_SORT_RADIX, FAM_RANK, FAM_RECEIVERS, FAM_FLOW_INIT, FAM_FLOW_SNAP, FAM_FLOW_APPLY, FAM_FLOW_FINAL,
     FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
     FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
-    FAM_MISC, FAM_COUNT
+    FAM_LEVEL_SORT, FAM_MISC, FAM_COUNT
 };
 extern const char* const kFamilyNames[FAM_COUNT];
 
@@ -82,6 +84,7 @@ struct wo_planet {
     float *d_glac = nullptr, *d_iceFlow = nullptr;
     int32_t *d_iceTarget = nullptr, *d_arank = nullptr;
     uint8_t* d_iceUp = nullptr;
+    int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
     int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
     void* d_sortTemp = nullptr; size_t sortTempBytes = 0;
     int landCur = 0;                    // which of d_land[] holds the current order
@@ -126,5 +129,6 @@ inline void launch(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, in
 void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
 void rank_from_land(wo_planet* p);
+void sort_by_level(wo_planet* p);
 
 }  // namespace wo

@@ -12,6 +12,9 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "wo_internal.h"
 
@@ -30,40 +33,42 @@ inline double cell_noise(int32_t r) {
     return ((double)h / 4294967295.0) * 0.01;
 }
 
-// Binary min-heap over cell ids keyed by an external float array, with the reference's exact sift rules
-// (js/terrain-post.js:18-46): sift-up stops on >=, sift-down prefers the left child unless the right is
-// strictly smaller.
+// Binary min-heap of (key, cell) pairs with the reference's exact sift rules (js/terrain-post.js:18-46):
+// sift-up stops on >=, sift-down prefers the left child unless the right is strictly smaller.  The reference
+// keys the heap through an external Float32Array; every cell is pushed exactly once and its key never changes
+// afterwards, so carrying the key next to the cell id compares the same values while keeping the sifts inside
+// one small contiguous array (the external-array form costs a cache miss per comparison at 10^7 cells).
+using HeapItem = FloodHeapItem;
 struct KeyHeap {
-    std::vector<int32_t>& d;
-    const float* key;
+    std::vector<HeapItem>& d;
     size_t n = 0;
-    KeyHeap(std::vector<int32_t>& storage, const float* k) : d(storage), key(k) {}
-    void push(int32_t c) {
+    explicit KeyHeap(std::vector<HeapItem>& storage) : d(storage) {}
+    void push(int32_t c, float kc) {
         size_t i = n++;
-        d[i] = c;
-        const float kc = key[c];
+        if (d.size() < n) d.resize(d.size() * 2 + 1024);
         while (i > 0) {
             const size_t parent = (i - 1) >> 1;
-            if (kc >= key[d[parent]]) break;
-            d[i] = d[parent]; d[parent] = c;
+            if (kc >= d[parent].key) break;
+            d[i] = d[parent];
             i = parent;
         }
+        d[i] = HeapItem{kc, c};
     }
     int32_t pop() {
-        const int32_t top = d[0];
-        const int32_t last = d[--n];
+        const int32_t top = d[0].cell;
+        const HeapItem last = d[--n];
         if (n > 0) {
             size_t i = 0;
-            d[0] = last;
             for (;;) {
-                size_t s = i;
                 const size_t l = 2 * i + 1, r = l + 1;
-                if (l < n && key[d[l]] < key[d[s]]) s = l;
-                if (r < n && key[d[r]] < key[d[s]]) s = r;
+                size_t s = i; float ks = last.key;
+                if (l < n && d[l].key < ks) { s = l; ks = d[l].key; }
+                if (r < n && d[r].key < ks) { s = r; }
                 if (s == i) break;
-                const int32_t t = d[i]; d[i] = d[s]; d[s] = t;
+                d[i] = d[s];
                 i = s;
             }
+            d[i] = last;
         }
         return top;
     }
@@ -78,55 +83,76 @@ inline uint32_t asc_bits(float f) {
 }  // namespace
 
 void FloodScratch::ensure(int32_t N) {
-    if ((int32_t)label.size() >= N) return;
-    label.resize(N); stack.resize(N); open.resize(N); surface.resize(N); drainTo.resize(N);
-    visited.resize(N); key.resize(N); path.resize(N); order.resize(N); order2.resize(N);
+    if ((int32_t)surface.size() >= N) return;
+    surface.resize(N); drainTo.resize(N); visited.resize(N); path.resize(N); order.resize(N); order2.resize(N);
     bits.resize(N); bits2.resize(N);
+    staticValid = false;
 }
 
-void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, float* e,
-                               const uint8_t* ocean, double carveStrength, FloodScratch& S) {
-    const double EPS = 1e-7;
-    S.ensure(N);
-    int32_t* label = S.label.data();
-    // --- largest ocean component = open ocean (:66-94)
-    std::fill(label, label + N, -1);
+// Everything that depends only on (mesh, r_isOcean): the open-ocean mask (largest ocean component, first
+// wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose first open-ocean neighbour in
+// adjacency order exists, ascending r, :118-128).  Both flood calls of an erodeComposite share it.
+static void build_static(int32_t N, const int32_t* off, const int32_t* adj, const uint8_t* ocean, FloodScratch& S) {
+    std::vector<int32_t> label(N, -1), stack(N);
     std::vector<int32_t> sizes;
     for (int32_t r = 0; r < N; ++r) {
         if (!ocean[r] || label[r] >= 0) continue;
         const int32_t lab = (int32_t)sizes.size();
         int32_t sp = 0, size = 0;
-        S.stack[sp++] = r; label[r] = lab;
+        stack[sp++] = r; label[r] = lab;
         while (sp > 0) {
-            const int32_t cur = S.stack[--sp];
+            const int32_t cur = stack[--sp];
             ++size;
             for (int32_t i = off[cur]; i < off[cur + 1]; ++i) {
                 const int32_t nb = adj[i];
-                if (ocean[nb] && label[nb] < 0) { label[nb] = lab; S.stack[sp++] = nb; }
+                if (ocean[nb] && label[nb] < 0) { label[nb] = lab; stack[sp++] = nb; }
             }
         }
         sizes.push_back(size);
     }
     int32_t mainLab = 0;
     for (size_t i = 1; i < sizes.size(); ++i) if (sizes[i] > sizes[mainLab]) mainLab = (int32_t)i;
-    for (int32_t r = 0; r < N; ++r) S.open[r] = (ocean[r] && label[r] == mainLab) ? 1 : 0;
+    S.seedCell.clear(); S.seedTarget.clear();
+    for (int32_t r = 0; r < N; ++r) {
+        if (ocean[r]) continue;
+        for (int32_t i = off[r]; i < off[r + 1]; ++i) {
+            const int32_t nb = adj[i];
+            if (ocean[nb] && label[nb] == mainLab) { S.seedCell.push_back(r); S.seedTarget.push_back(nb); break; }
+        }
+    }
+    S.staticValid = true;
+}
 
-    // --- keys, seeds (:107-128)
+void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, float* e,
+                               const uint8_t* ocean, double carveStrength, FloodScratch& S) {
+    const double EPS = 1e-7;
+    const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flood] %-10s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+        tp = now;
+    };
+    S.ensure(N);
+    if (!S.staticValid) build_static(N, off, adj, ocean, S);
+    lap("static");
+
+    // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed
     float* surface = S.surface.data();
     int32_t* drainTo = S.drainTo.data();
     uint8_t* visited = S.visited.data();
-    float* key = S.key.data();
-    for (int32_t r = 0; r < N; ++r) {
-        surface[r] = e[r]; drainTo[r] = -1; visited[r] = 0;
-        key[r] = (float)((double)e[r] + cell_noise(r));
+    std::memcpy(surface, e, sizeof(float) * (size_t)N);
+    std::memset(drainTo, 0xff, sizeof(int32_t) * (size_t)N);
+    std::memcpy(visited, ocean, (size_t)N);                 // ocean cells are pre-visited (:119)
+    if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
+    KeyHeap heap(S.heapStore);
+    for (size_t i = 0; i < S.seedCell.size(); ++i) {        // :118-128, ascending r
+        const int32_t r = S.seedCell[i];
+        visited[r] = 1; drainTo[r] = S.seedTarget[i];
+        heap.push(r, (float)((double)e[r] + cell_noise(r)));
     }
-    KeyHeap heap(S.stack, key);
-    for (int32_t r = 0; r < N; ++r) {
-        if (ocean[r]) { visited[r] = 1; continue; }
-        for (int32_t i = off[r]; i < off[r + 1]; ++i) {
-            if (S.open[adj[i]]) { visited[r] = 1; drainTo[r] = adj[i]; heap.push(r); break; }
-        }
-    }
+    lap("init+seeds");
     // --- pass 1 (:131-147)
     while (heap.n > 0) {
         const int32_t c = heap.pop();
@@ -136,13 +162,17 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             if (visited[nb]) continue;
             visited[nb] = 1;
             drainTo[nb] = c;
+            float k;
             if ((double)e[nb] < lim) {
                 surface[nb] = (float)lim;
-                key[nb] = (float)((double)surface[nb] + cell_noise(nb));
+                k = (float)((double)surface[nb] + cell_noise(nb));
+            } else {
+                k = (float)((double)e[nb] + cell_noise(nb));
             }
-            heap.push(nb);
+            heap.push(nb, k);
         }
     }
+    lap("pass1");
     // --- pass 2 (:152-196): ascending r, sequential
     int32_t* path = S.path.data();
     for (int32_t r = 0; r < N; ++r) {
@@ -173,6 +203,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         }
         e[r] = (float)((double)e[r] + deficit * (1 - carveStrength));
     }
+    lap("pass2");
     // --- pass 3 (:200-214): land cells by ascending surface (stable), enforce descent along drainTo
     int32_t nLand = 0;
     int32_t* order = S.order.data();
@@ -199,6 +230,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         const double te = ocean[t] ? 0.0 : (double)e[t];
         if ((double)e[c] <= te) e[c] = (float)(te + EPS);
     }
+    lap("pass3");
 }
 
 }  // namespace wo

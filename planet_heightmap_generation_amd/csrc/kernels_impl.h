@@ -13,6 +13,32 @@ namespace wo {
 
 #define WO_GRID_STRIDE(i, n) for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += gridDim.x * blockDim.x)
 
+// Block-uniform strided loop: every thread of the workgroup runs the same number of trips (needed around
+// block_append's barriers); `valid` tells whether index i is in range.
+#define WO_BLOCK_STRIDE(i, valid, n)                                                              \
+    for (int32_t base_ = blockIdx.x * blockDim.x, i = base_ + threadIdx.x, valid = (i < (n));   \
+         base_ < (n); base_ += gridDim.x * blockDim.x, i = base_ + threadIdx.x, valid = (i < (n)))
+
+// Append `value` of every thread with `flag` to out[] with ONE global atomic per workgroup (wave ballot +
+// LDS scan of the per-wave counts) instead of one per wave on a single hot counter.
+__device__ inline void block_append(bool flag, int32_t value, int32_t* out, int32_t* outCount) {
+    __shared__ int32_t s_wave[WO_BLOCK / 64];
+    __shared__ int32_t s_base;
+    const unsigned long long mask = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < WO_BLOCK / 64; ++w) { const int32_t c = s_wave[w]; s_wave[w] = tot; tot += c; }
+        s_base = tot ? atomicAdd(outCount, tot) : 0;
+    }
+    __syncthreads();
+    if (flag) out[s_base + s_wave[wave] + prefix] = value;
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------- fields / Jacobi ---------------
 __global__ __launch_bounds__(WO_BLOCK) void k_coast(Fields F, uint8_t* coast) {
     WO_GRID_STRIDE(r, F.N) coast[r] = coast_flag(F, r);
@@ -83,28 +109,41 @@ __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N
 // ---------------------------------------------------------------- hydraulic ---------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_GRID_STRIDE(r, F.N) receiver_cell(F, r); }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_init(Fields F, int32_t* list, int32_t* count) {
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_init(Fields F) {
     WO_GRID_STRIDE(r, F.N) {
         int32_t j = -1; uint32_t a = 0;
         if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
         F.accA[r] = a; F.jumpA[r] = j;
-        if (j >= 0) { const int32_t pos = atomicAdd(count, 1); list[pos] = r; }
     }
 }
+// pointer-doubling round, part 1: snapshot the value each active cell will send and its next ancestor
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_snap(Fields F, const int32_t* list, const int32_t* count, uint32_t* snap, int32_t* nj) {
     const int32_t n = *count;
-    WO_GRID_STRIDE(i, n) { const int32_t d = list[i]; snap[i] = F.accA[d]; nj[i] = F.jumpA[F.jumpA[d]]; }
+    WO_GRID_STRIDE(i, n) {
+        const int32_t d = list[i];
+        const int32_t j = F.jumpA[d];
+        snap[i] = F.accA[d];
+        nj[i] = (j >= 0) ? F.jumpA[j] : -1;
+    }
 }
+// part 2: A[jump[d]] += snapshot (integer atomics: exact, order-free), jump[d] <- jump[jump[d]]
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t* list, const int32_t* count, const uint32_t* snap,
                                                           const int32_t* nj, int32_t* out, int32_t* outCount, int32_t* zeroCount) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
     const int32_t n = *count;
-    WO_GRID_STRIDE(i, n) {
-        const int32_t d = list[i];
-        atomicAdd(&F.accA[F.jumpA[d]], snap[i]);
-        const int32_t j2 = nj[i];
-        F.jumpA[d] = j2;
-        if (j2 >= 0) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = d; }
+    WO_BLOCK_STRIDE(i, valid, n) {
+        bool again = false; int32_t d = -1;
+        if (valid) {
+            d = list[i];
+            const int32_t j = F.jumpA[d];
+            if (j >= 0) {
+                atomicAdd(&F.accA[j], snap[i]);
+                const int32_t j2 = nj[i];
+                F.jumpA[d] = j2;
+                again = j2 >= 0;
+            }
+        }
+        block_append(again, d, out, outCount);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F) {
@@ -125,16 +164,28 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F) {
 
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_GRID_STRIDE(r, F.N) solve_setup_cell(F, r); }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
-                                                           int32_t* outCount, int32_t* zeroCount, int32_t round, double K, double m, double dt) {
+// One synchronous round of the solve dataflow.  Tasks come from two places: the leftovers of earlier rounds
+// and the bucket of tasks whose level in the previous erosion iteration was exactly this round (levels barely
+// move between iterations, so almost every task is examined once, when it is ready).
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_t* left, const int32_t* leftCount,
+                                                           const int32_t* bucket, int32_t bucketCount, int32_t* out, int32_t* outCount,
+                                                           int32_t* zeroCount, int32_t round, double K, double m, double dt) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    const int32_t n = *inCount;
-    WO_GRID_STRIDE(i, n) {
-        const int32_t r = in[i];
-        if (!solve_task(F, r, round, K, m, dt)) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = r; }
+    const int32_t nl = *leftCount;
+    const int32_t n = nl + bucketCount;
+    WO_BLOCK_STRIDE(i, valid, n) {
+        bool pending = false; int32_t r = -1;
+        if (valid) {
+            r = (i < nl) ? left[i] : bucket[i - nl];
+            pending = !solve_task(F, r, round, K, m, dt);
+        }
+        block_append(pending, r, out, outCount);
     }
 }
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out) { WO_GRID_STRIDE(r, F.N) out[r] = solve_final_cell(F, r); }
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level) {
+    WO_GRID_STRIDE(r, F.N) { out[r] = solve_final_cell(F, r); level[r] = F.doneAt[r]; }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 
 // ---------------------------------------------------------------- thermal -----------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_GRID_STRIDE(r, F.N) thermal_excess_cell(F, r, talus); }
@@ -151,15 +202,17 @@ __global__ __launch_bounds__(WO_BLOCK) void k_ice_round(Fields F, const int32_t*
                                                          int32_t* outCount, int32_t* zeroCount, int32_t round) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
     const int32_t n = *inCount;
-    WO_GRID_STRIDE(i, n) {
-        const int32_t t = in[i];
-        if (!ice_accumulate_task(F, t, round)) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = t; }
+    WO_BLOCK_STRIDE(i, valid, n) {
+        bool pending = false; int32_t t = -1;
+        if (valid) { t = in[i]; pending = !ice_accumulate_task(F, t, round); }
+        block_append(pending, t, out, outCount);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_setup(Fields F, int32_t* list, int32_t* count) {
-    WO_GRID_STRIDE(r, F.N) {
-        carve_setup_cell(F, r);
-        if (F.arank[r] != WO_NOT_DONE) { const int32_t pos = atomicAdd(count, 1); list[pos] = r; }
+    WO_BLOCK_STRIDE(r, valid, F.N) {
+        bool act = false;
+        if (valid) { carve_setup_cell(F, r); act = F.arank[r] != WO_NOT_DONE; }
+        block_append(act, r, list, count);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
@@ -167,9 +220,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_
                                                            double gConv, double gStrength) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
     const int32_t n = *inCount;
-    WO_GRID_STRIDE(i, n) {
-        const int32_t r = in[i];
-        if (!carve_task(F, r, round, gCarve, gConv, gStrength)) { const int32_t pos = atomicAdd(outCount, 1); out[pos] = r; }
+    WO_BLOCK_STRIDE(i, valid, n) {
+        bool pending = false; int32_t r = -1;
+        if (valid) { r = in[i]; pending = !carve_task(F, r, round, gCarve, gConv, gStrength); }
+        block_append(pending, r, out, outCount);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDep, double gFjord) {

@@ -21,7 +21,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -54,6 +54,8 @@ static void ensure_scratch(wo_planet* p) {
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
     p->d_iceUp = dalloc<uint8_t>(N);
     p->d_listA = dalloc<int32_t>(N); p->d_listB = dalloc<int32_t>(N); p->d_counters = dalloc<int32_t>(8);
+    p->d_level = dalloc<int32_t>(N); p->d_byLevel = dalloc<int32_t>(N); p->d_levelStart = dalloc<int32_t>(WO_MAX_LEVEL + 2);
+    WO_HIP(hipHostMalloc((void**)&p->h_levelStart, (WO_MAX_LEVEL + 2) * sizeof(int32_t)));
     p->sortTempBytes = sort_temp_bytes(p->N);
     WO_HIP(hipMalloc(&p->d_sortTemp, std::max<size_t>(p->sortTempBytes, 16)));
     WO_HIP(hipMemsetAsync(p->d_glac, 0, N * sizeof(float), p->ctx->stream));
@@ -75,6 +77,7 @@ wo::Fields wo_planet::fields() const {
 namespace wo {
 
 static inline void swap_elev(wo_planet* p) { std::swap(p->d_e, p->d_e2); }
+static inline void ocean_changed(wo_planet* p, bool hostCopyValid) { p->h_ocean_valid = hostCopyValid; p->flood.staticValid = false; }
 
 static int32_t read_count(wo_planet* p, const int32_t* d_ptr) {
     WO_HIP(hipMemcpyAsync(p->h_count, d_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream));
@@ -117,6 +120,47 @@ static int64_t run_rounds(wo_planet* p, const int32_t* firstList, int32_t firstC
         const int32_t next = read_count(p, c + (k % 3));
         if (k > 4 * (int64_t)p->N + 1024) throw HipError{"dependency rounds do not converge"};
         count = next;
+    }
+    return k - 1;
+}
+
+// Solve rounds with level prediction: round k examines the leftovers of earlier rounds plus the bucket of
+// tasks that completed in round k during the previous erosion iteration (sort_by_level).  Any schedule
+// that respects the dependencies produces the same bits (the dataflow is single-assignment), so a wrong
+// prediction only costs re-examinations.
+constexpr int WO_LOOKAHEAD = 3;
+static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double m, double dt, int64_t* examined) {
+    sort_by_level(p);
+    const int32_t* ls = p->h_levelStart;
+    int32_t maxPred = 1;
+    for (int32_t l = 1; l <= WO_MAX_LEVEL; ++l) if (ls[l + 1] > ls[l]) maxPred = l;
+    int32_t* c = p->d_counters;
+    hipStream_t s = p->ctx->stream;
+    hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
+    const int batch = 32;
+    int64_t k = 1;
+    int32_t leftKnown = 0;
+    const int32_t* in = p->d_listB;
+    int32_t* out = p->d_listA;
+    for (;;) {
+        for (int b = 0; b < batch; ++b, ++k) {
+            // tasks enter WO_LOOKAHEAD rounds ahead of their predicted level: a few cheap re-examinations buy
+            // back the rounds that cascaded mispredictions would add (emulator: 1393 -> 1047 rounds, optimum 1023)
+            const int64_t loL = (k == 1) ? 1 : std::min<int64_t>(k + WO_LOOKAHEAD, WO_MAX_LEVEL + 1);
+            const int64_t hiL = std::min<int64_t>(k + WO_LOOKAHEAD, WO_MAX_LEVEL);
+            const int32_t bc = (hiL >= loL) ? ls[hiL + 1] - ls[loL] : 0;
+            const int32_t* bucket = p->d_byLevel + ((hiL >= loL) ? ls[loL] : 0);
+            const int grid = blocks_for((int64_t)bc + 2 * (int64_t)leftKnown + 1024, 2048);
+            launch(p, FAM_SOLVE_ROUND, k_solve_round, grid, WO_BLOCK, F, in, (const int32_t*)(c + (k % 3)), bucket, bc, out,
+                   c + ((k + 1) % 3), c + ((k + 2) % 3), (int32_t)k, K, m, dt);
+            if (examined) *examined += bc;
+            in = out;
+            out = (out == p->d_listA) ? p->d_listB : p->d_listA;
+        }
+        leftKnown = read_count(p, c + (k % 3));
+        if (examined) *examined += (int64_t)leftKnown * batch;       // rough: leftovers are re-examined every round
+        if (k + WO_LOOKAHEAD > maxPred && leftKnown == 0) break;
+        if (k > 4 * (int64_t)p->N + 1024) throw HipError{"solve rounds do not converge"};
     }
     return k - 1;
 }
@@ -172,7 +216,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t N = p->N;
     const int gridN = blocks_for(N);
     StageClock clk(p);
-    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0;
+    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0;
     double floodHostMs = 0;
 
     clk.begin("setup");
@@ -196,6 +240,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         p->landCur = 0;
         launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
         rank_from_land(p);      // thermal-only runs never sort: landCells stays in ascending-r order
+        launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_level, 1, N);   // no level history yet: everything in round 1
     }
     const int32_t L = p->L;
     clk.end();
@@ -247,29 +292,22 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             launch(p, FAM_RECEIVERS, k_receivers, gridN, WO_BLOCK, F);
             clk.end();
             clk.begin("flow");
-            {
-                int32_t* c = p->d_counters;
-                WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
-                launch(p, FAM_FLOW_INIT, k_flow_init, gridN, WO_BLOCK, F, p->d_listB, c + 3);
-                flowRounds += run_rounds(p, p->d_listB, 0, true, 3,
-                    [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
-                        launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
-                        launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
-                               (const int32_t*)p->d_nj, out, outC, zeroC);
-                    });
-                launch(p, FAM_FLOW_FINAL, k_flow_final, gridN, WO_BLOCK, F);
-            }
+            launch(p, FAM_FLOW_INIT, k_flow_init, gridN, WO_BLOCK, F);
+            flowRounds += run_rounds(p, p->d_landIdx, L, false, 4,
+                [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
+                    launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
+                    launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
+                           (const int32_t*)p->d_nj, out, outC, zeroC);
+                });
+            launch(p, FAM_FLOW_FINAL, k_flow_final, gridN, WO_BLOCK, F);
             clk.end();
             clk.begin("solve");
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridN, WO_BLOCK, F);
             {
-                const int64_t r = run_rounds(p, p->d_landIdx, L, false, 32,
-                    [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
-                        launch(p, FAM_SOLVE_ROUND, k_solve_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k, K, m, dt);
-                    });
+                const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
             }
-            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2);
+            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2, p->d_level);
             swap_elev(p);
             clk.end();
         }
@@ -292,6 +330,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     clk.finish();
     p->erodeStats = {{"land_cells", (double)L}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
+                     {"solve_tasks_examined_est", (double)solveExamined},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
                      {"carve_rounds_total", (double)carveRounds}, {"flood_host_ms", floodHostMs}};
 }
@@ -437,7 +476,8 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_selfOut); dfree(p->d_tOut); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_predSelf); dfree(p->d_predT); dfree(p->d_predT2); dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
-    dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters);
+    dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
+    if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);
     if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);
     if (p->h_pinned) (void)hipHostFree(p->h_pinned);
     if (p->h_count) (void)hipHostFree(p->h_count);
@@ -456,7 +496,7 @@ int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_is
     if (r_isOcean) {
         WO_HIP(hipMemcpyAsync(p->d_ocean, r_isOcean, (size_t)p->N, hipMemcpyHostToDevice, s));
         p->h_ocean.assign(r_isOcean, r_isOcean + p->N);
-        p->h_ocean_valid = true;
+        ocean_changed(p, true);
     }
     WO_HIP(hipStreamSynchronize(s));
     return 0;
@@ -476,7 +516,7 @@ int wo_planet_ocean_from_elevation(wo_planet* p) {
     if (!check_planet(p, "wo_planet_ocean_from_elevation")) return 1;
     WO_TRY
     launch(p, FAM_OCEAN, k_ocean_from_elev, blocks_for(p->N), WO_BLOCK, (const float*)p->d_e, p->d_ocean, p->N);
-    p->h_ocean_valid = false;
+    ocean_changed(p, false);
     return 0;
     WO_CATCH("wo_planet_ocean_from_elevation")
 }
@@ -515,7 +555,7 @@ int wo_planet_restore_state(wo_planet* p) {
     WO_TRY
     WO_HIP(hipMemcpyAsync(p->d_e, p->d_savedE, (size_t)p->N * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
     WO_HIP(hipMemcpyAsync(p->d_ocean, p->d_savedOcean, (size_t)p->N, hipMemcpyDeviceToDevice, p->ctx->stream));
-    p->h_ocean_valid = false;
+    ocean_changed(p, false);
     return 0;
     WO_CATCH("wo_planet_restore_state")
 }
@@ -566,7 +606,7 @@ int wo_planet_synthetic_terrain(wo_planet* p, double seed) {
     WO_TRY
     upload_tables(p, seed);
     launch(p, FAM_SYNTH, k_synthetic, blocks_for(p->N), WO_BLOCK, (const uint8_t*)p->d_tables, (const float*)p->d_xyz, p->d_e, p->d_ocean, p->N);
-    p->h_ocean_valid = false;
+    ocean_changed(p, false);
     return 0;
     WO_CATCH("wo_planet_synthetic_terrain")
 }

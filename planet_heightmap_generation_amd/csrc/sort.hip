@@ -25,12 +25,51 @@ void rank_from_land(wo_planet* p) {
     launch(p, FAM_RANK, k_rank_scatter, blocks_for(p->L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, p->L);
 }
 
+// ---- solve scheduling: land cells grouped by the round in which they completed last iteration ----
+__global__ __launch_bounds__(WO_BLOCK) void k_level_keys(const int32_t* __restrict__ level, const int32_t* __restrict__ landIdx,
+                                                          uint32_t* __restrict__ keys, int32_t L, int32_t maxLevel) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
+        int32_t l = level[landIdx[i]];
+        if (l < 1) l = 1;
+        if (l > maxLevel) l = maxLevel;
+        keys[i] = (uint32_t)l;
+    }
+}
+// start[l] = first position in the sorted key array whose key is >= l  (l = 0 .. maxLevel + 1)
+__global__ void k_level_bounds(const uint32_t* __restrict__ keys, int32_t L, int32_t* __restrict__ start, int32_t maxLevel) {
+    for (int32_t l = blockIdx.x * blockDim.x + threadIdx.x; l <= maxLevel + 1; l += gridDim.x * blockDim.x) {
+        int32_t lo = 0, hi = L;
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (keys[mid] < (uint32_t)l) lo = mid + 1; else hi = mid; }
+        start[l] = lo;
+    }
+}
+
+void sort_by_level(wo_planet* p) {
+    const int32_t L = p->L;
+    hipStream_t s = p->ctx->stream;
+    launch(p, FAM_LEVEL_SORT, k_level_keys, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_level, (const int32_t*)p->d_landIdx,
+           p->d_keys[0], L, (int32_t)WO_MAX_LEVEL);
+    size_t bytes = p->sortTempBytes;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+    WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, (const uint32_t*)p->d_keys[0], p->d_keys[1],
+                                             (const int32_t*)p->d_landIdx, p->d_byLevel, L, 0, WO_LEVEL_BITS, s));
+    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_LEVEL_SORT, a, b}); }
+    launch(p, FAM_LEVEL_SORT, k_level_bounds, blocks_for(WO_MAX_LEVEL + 2, 64), WO_BLOCK, (const uint32_t*)p->d_keys[1], L,
+           p->d_levelStart, (int32_t)WO_MAX_LEVEL);
+    WO_HIP(hipMemcpyAsync(p->h_levelStart, p->d_levelStart, (WO_MAX_LEVEL + 2) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+}
+
 size_t sort_temp_bytes(int32_t n) {
     size_t bytes = 0;
     hipcub::DoubleBuffer<uint32_t> k(nullptr, nullptr);
     hipcub::DoubleBuffer<int32_t> v(nullptr, nullptr);
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, v, n, 0, 32, nullptr);
-    return bytes;
+    size_t bytes2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
+                                             (int32_t*)nullptr, n, 0, WO_LEVEL_BITS, nullptr);
+    return bytes > bytes2 ? bytes : bytes2;
 }
 
 void sort_land_by_elevation(wo_planet* p) {

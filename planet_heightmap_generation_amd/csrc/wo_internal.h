@@ -14,11 +14,14 @@ int mesh_csr(int V, int numSides, const int* triangles, const int* halfedges,
 void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float* xyz, float* out);
 
 // flood_host.cc
+struct FloodHeapItem { float key; int32_t cell; };
 struct FloodScratch {
-    std::vector<int32_t> label, stack, drainTo, path, order, order2;
-    std::vector<uint8_t> open, visited;
-    std::vector<float> surface, key;
+    std::vector<int32_t> drainTo, path, order, order2, seedCell, seedTarget;
+    std::vector<uint8_t> visited;
+    std::vector<float> surface;
     std::vector<uint32_t> bits, bits2;
+    std::vector<FloodHeapItem> heapStore;
+    bool staticValid = false;       // seed list valid for the current (mesh, r_isOcean)
     void ensure(int32_t N);
 };
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, float* e,

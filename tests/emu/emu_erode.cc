@@ -58,6 +58,33 @@ int64_t run_rounds(std::vector<int32_t> list, Task task) {
     return round;
 }
 
+// solve rounds with level prediction, mirroring run_solve_rounds() in planet.hip: round k examines the
+// leftovers plus the tasks whose level in the previous iteration was k
+static int LOOKAHEAD = 2;
+int64_t run_solve_rounds_pred(Emu& E, std::vector<int32_t>& level, double K, double m, double dt) {
+    const Fields& F = E.F;
+    int32_t maxPred = 1;
+    for (int32_t r : E.landIdx) { if (level[r] < 1) level[r] = 1; if (level[r] > maxPred) maxPred = level[r]; }
+    std::vector<std::vector<int32_t>> bucket(maxPred + 2);
+    for (int32_t r : E.landIdx) bucket[level[r]].push_back(r);
+    std::vector<int32_t> left, next;
+    int64_t round = 0;
+    for (;;) {
+        ++round;
+        next.clear();
+        for (int32_t r : left) if (!solve_task(F, r, (int32_t)round, K, m, dt)) next.push_back(r);
+        // tasks enter LOOKAHEAD rounds before their predicted level (cheap re-examination, fewer cascaded delays)
+        const int64_t lo = (round == 1) ? 1 : round + LOOKAHEAD, hi = round + LOOKAHEAD;
+        for (int64_t l = lo; l <= hi && l <= maxPred; ++l)
+            for (int32_t r : bucket[l]) if (!solve_task(F, r, (int32_t)round, K, m, dt)) next.push_back(r);
+        left.swap(next);
+        if (round + LOOKAHEAD >= maxPred && left.empty()) break;
+        if (round > 8 * (int64_t)F.N) return -round;
+    }
+    for (int32_t r : E.landIdx) level[r] = F.doneAt[r];
+    return round;
+}
+
 }  // namespace
 
 extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t* adj, float* e, const float* xyz,
@@ -87,6 +114,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     F.L = (int32_t)E.land.size(); F.land = E.land.data();
     if (F.L == 0) return 0;
     for (int32_t i = 0; i < F.L; ++i) E.rank[E.land[i]] = i;
+    std::vector<int32_t> level(N, 1);
     FloodScratch fs;
     if (hIters > 0) priority_flood_carve_host(N, off, adj, e, ocean, 0.5, fs);
     const bool glacial = gIters > 0 && gStrength > 0;
@@ -145,7 +173,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
                 F.flow[c] = (float)f;
             }
             for (int32_t r = 0; r < N; ++r) solve_setup_cell(F, r);
-            int64_t n3 = run_rounds(E.landIdx, [&](int32_t r, int32_t k) { return solve_task(F, r, k, K, m, dt); });
+            int64_t n3 = run_solve_rounds_pred(E, level, K, m, dt);
             if (n3 < 0) rc = 12;
             E.solveRounds += n3; if (n3 > E.maxSolveRounds) E.maxSolveRounds = n3;
             for (int32_t r = 0; r < N; ++r) F.e2[r] = solve_final_cell(F, r);
@@ -204,3 +232,5 @@ extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, flo
     FloodScratch fs;
     priority_flood_carve_host(N, off, adj, e, ocean, cs, fs);
 }
+
+extern "C" void emu_set_lookahead(int v) { LOOKAHEAD = v; }
