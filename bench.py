@@ -56,6 +56,44 @@ PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kT
 WARP, CREEP = 0.75, (3, 0.1125)
 
 
+# ---- multi-rank plumbing (one process per GPU; no collective on the data path) ---------------------------
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def dist_init(world: int, local_rank: int, backend: str = "nccl"):
+    """Returns the torch.distributed module (initialised) or None for a single process."""
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def dist_max(dist, value: float, device: str) -> float:
+    """MAX over ranks of a host scalar (the timed region's wall time)."""
+    if dist is None:
+        return value
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def seed_for_rank(rank: int) -> int:
+    return 1 + rank          # BASELINE config 5: one planet per GPU, seeds 1..
+
+
+def whole_job_value(cells: int, iters: int, steps: int, world: int, wall_s: float) -> float:
+    """Mcells·iter/s aggregated over all ranks (every rank processes `steps` planets of `cells` cells)."""
+    return cells * iters * steps * world / wall_s / 1e6
+
+
 def build_inputs(cells: int, seed: int):
     from planet_heightmap_generation_amd import sphere_mesh as S
     t0 = time.time()
@@ -104,25 +142,18 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = dist_env()
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
+    dist = dist_init(world, local_rank, "nccl")
     torch.cuda.set_device(local_rank)
 
     from planet_heightmap_generation_amd import terrain_post as TP
     params = dict(PARAMS)
     if args.iters != 200:
         params.update(hIters=args.iters, tIters=args.iters, gIters=min(10, max(1, args.iters // 20)))
-    seed = 1 + rank
+    seed = seed_for_rank(rank)
     mesh, xyz, nd, t_mesh = build_inputs(args.cells, seed)
     pl = TP.Planet(mesh, xyz, nd, device=local_rank)
     pl.synthetic_terrain(seed)
@@ -146,10 +177,7 @@ def main():
     ev_ms = pl.timer_stop_ms()
     barrier()
     wall = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    wall = dist_max(dist, wall, "cuda")
     stats = pl.last_erode_stats()
     stages = pl.last_stage_timing()
     L = int(stats.get("land_cells", 0))
@@ -181,7 +209,7 @@ def main():
         cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters)
 
     if rank == 0:
-        value = N * iters * args.steps * world / wall / 1e6
+        value = whole_job_value(N, iters, args.steps, world, wall)
         out = {
             "metric": "Mcells·iter/s, terrain-post erosion stack", "value": value, "unit": "Mcells·iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,

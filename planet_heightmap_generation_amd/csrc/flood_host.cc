@@ -45,30 +45,39 @@ struct KeyHeap {
     explicit KeyHeap(std::vector<HeapItem>& storage) : d(storage) {}
     void push(int32_t c, float kc) {
         size_t i = n++;
-        if (d.size() < n) d.resize(d.size() * 2 + 1024);
+        if (d.size() < n + 2) d.resize(d.size() * 2 + 1024);
+        HeapItem* h = d.data();
         while (i > 0) {
             const size_t parent = (i - 1) >> 1;
-            if (kc >= d[parent].key) break;
-            d[i] = d[parent];
+            if (kc >= h[parent].key) break;
+            h[i] = h[parent];
             i = parent;
         }
-        d[i] = HeapItem{kc, c};
+        h[i] = HeapItem{kc, c};
     }
+    // Same comparisons as js/terrain-post.js:36-42 (left vs current, then right vs the smaller of the two),
+    // evaluated with selects instead of branches; slots n and n+1 hold +inf sentinels so absent children lose.
     int32_t pop() {
-        const int32_t top = d[0].cell;
-        const HeapItem last = d[--n];
+        HeapItem* h = d.data();
+        const int32_t top = h[0].cell;
+        const HeapItem last = h[--n];
+        h[n].key = INFINITY; h[n + 1].key = INFINITY;
         if (n > 0) {
             size_t i = 0;
+            const float kc = last.key;
             for (;;) {
-                const size_t l = 2 * i + 1, r = l + 1;
-                size_t s = i; float ks = last.key;
-                if (l < n && d[l].key < ks) { s = l; ks = d[l].key; }
-                if (r < n && d[r].key < ks) { s = r; }
+                const size_t l = 2 * i + 1;
+                if (l >= n) break;
+                const float kl = h[l].key, kr = h[l + 1].key;
+                const bool a = kl < kc;
+                const float mk = a ? kl : kc;
+                size_t s = a ? l : i;
+                s = (kr < mk) ? l + 1 : s;
                 if (s == i) break;
-                d[i] = d[s];
+                h[i] = h[s];
                 i = s;
             }
-            d[i] = last;
+            h[i] = last;
         }
         return top;
     }
@@ -138,18 +147,21 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     if (!S.staticValid) build_static(N, off, adj, ocean, S);
     lap("static");
 
-    // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed
+    // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed.  The flood's
+    // per-neighbour state (elevation, visited flag, drain target) is packed in one 8-byte record so that
+    // visiting a neighbour costs one cache line, not three: drain == UNVISITED / OCEAN / NO_TARGET(-1) / cell id.
     float* surface = S.surface.data();
     int32_t* drainTo = S.drainTo.data();
-    uint8_t* visited = S.visited.data();
+    constexpr int32_t UNVISITED = -2, OCEAN = -3;
+    if ((int32_t)S.state.size() < N) S.state.resize(N);
+    FloodCell* st = S.state.data();
+    for (int32_t r = 0; r < N; ++r) { st[r].e = e[r]; st[r].drain = ocean[r] ? OCEAN : UNVISITED; }
     std::memcpy(surface, e, sizeof(float) * (size_t)N);
-    std::memset(drainTo, 0xff, sizeof(int32_t) * (size_t)N);
-    std::memcpy(visited, ocean, (size_t)N);                 // ocean cells are pre-visited (:119)
     if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
     KeyHeap heap(S.heapStore);
     for (size_t i = 0; i < S.seedCell.size(); ++i) {        // :118-128, ascending r
         const int32_t r = S.seedCell[i];
-        visited[r] = 1; drainTo[r] = S.seedTarget[i];
+        st[r].drain = S.seedTarget[i];
         heap.push(r, (float)((double)e[r] + cell_noise(r)));
     }
     lap("init+seeds");
@@ -157,24 +169,28 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     while (heap.n > 0) {
         const int32_t c = heap.pop();
         const double lim = (double)surface[c] + EPS;
-        for (int32_t i = off[c]; i < off[c + 1]; ++i) {
+        const int32_t iEnd = off[c + 1];
+        for (int32_t i = off[c]; i < iEnd; ++i) {
             const int32_t nb = adj[i];
-            if (visited[nb]) continue;
-            visited[nb] = 1;
-            drainTo[nb] = c;
+            FloodCell& sn = st[nb];
+            if (sn.drain != UNVISITED) continue;
+            sn.drain = c;
             float k;
-            if ((double)e[nb] < lim) {
+            if ((double)sn.e < lim) {
                 surface[nb] = (float)lim;
                 k = (float)((double)surface[nb] + cell_noise(nb));
             } else {
-                k = (float)((double)e[nb] + cell_noise(nb));
+                k = (float)((double)sn.e + cell_noise(nb));
             }
             heap.push(nb, k);
         }
     }
+    // unreachable land (enclosed by inland seas) keeps drainTo = -1 (:108)
+    for (int32_t r = 0; r < N; ++r) { const int32_t d = st[r].drain; drainTo[r] = d >= 0 ? d : -1; }
     lap("pass1");
     // --- pass 2 (:152-196): ascending r, sequential
     int32_t* path = S.path.data();
+    int64_t nDef = 0, totLen = 0;
     for (int32_t r = 0; r < N; ++r) {
         if (ocean[r]) continue;
         const double deficit = (double)surface[r] - (double)e[r];
@@ -185,6 +201,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             path[len++] = cur;
             if ((double)e[cur] > peakElev) { peakElev = e[cur]; peakIdx = len - 1; }
         }
+        if (timing) { ++nDef; totLen += len; }
         if (peakIdx < 0) continue;
         const double carveAmount = deficit * carveStrength;
         const double rc = std::ceil((double)len * 0.3);
@@ -203,6 +220,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         }
         e[r] = (float)((double)e[r] + deficit * (1 - carveStrength));
     }
+    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells, total path length %lld\n", (long long)nDef, (long long)totLen);
     lap("pass2");
     // --- pass 3 (:200-214): land cells by ascending surface (stable), enforce descent along drainTo
     int32_t nLand = 0;

@@ -77,7 +77,21 @@ wo::Fields wo_planet::fields() const {
 namespace wo {
 
 static inline void swap_elev(wo_planet* p) { std::swap(p->d_e, p->d_e2); }
-static inline void ocean_changed(wo_planet* p, bool hostCopyValid) { p->h_ocean_valid = hostCopyValid; p->flood.staticValid = false; }
+// The device ocean mask changed (or may have): the host copy is refreshed lazily.  The flood's cached
+// open-ocean / seed data is only rebuilt when the mask really differs (a "reapply" with the same mask keeps it).
+static inline void ocean_changed(wo_planet* p) { p->h_ocean_valid = false; }
+static void refresh_host_ocean(wo_planet* p) {
+    if (p->h_ocean_valid) return;
+    hipStream_t s = p->ctx->stream;
+    std::vector<uint8_t> tmp(p->N);
+    WO_HIP(hipMemcpyAsync(tmp.data(), p->d_ocean, p->N, hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    if (tmp.size() != p->h_ocean.size() || std::memcmp(tmp.data(), p->h_ocean.data(), tmp.size()) != 0) {
+        p->h_ocean.swap(tmp);
+        p->flood.staticValid = false;
+    }
+    p->h_ocean_valid = true;
+}
 
 static int32_t read_count(wo_planet* p, const int32_t* d_ptr) {
     WO_HIP(hipMemcpyAsync(p->h_count, d_ptr, sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream));
@@ -188,11 +202,7 @@ struct StageClock {
 static void flood_stage(wo_planet* p, double carveStrength) {
     hipStream_t s = p->ctx->stream;
     const size_t bytes = (size_t)p->N * sizeof(float);
-    if (!p->h_ocean_valid) {
-        p->h_ocean.resize(p->N);
-        WO_HIP(hipMemcpyAsync(p->h_ocean.data(), p->d_ocean, p->N, hipMemcpyDeviceToHost, s));
-        p->h_ocean_valid = true;
-    }
+    refresh_host_ocean(p);
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     WO_HIP(hipStreamSynchronize(s));
     priority_flood_carve_host(p->N, p->h_off.data(), p->h_adj.data(), p->h_pinned, p->h_ocean.data(), carveStrength, p->flood);
@@ -222,12 +232,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     clk.begin("setup");
     coast_flags(p);
     // landCells in ascending r (js/terrain-post.js:384-390): host-side compaction of the ocean mask
-    if (!p->h_ocean_valid) {
-        p->h_ocean.resize(N);
-        WO_HIP(hipMemcpyAsync(p->h_ocean.data(), p->d_ocean, N, hipMemcpyDeviceToHost, s));
-        WO_HIP(hipStreamSynchronize(s));
-        p->h_ocean_valid = true;
-    }
+    refresh_host_ocean(p);
     {
         int32_t* hl = reinterpret_cast<int32_t*>(p->h_pinned);
         int32_t L = 0;
@@ -495,8 +500,11 @@ int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_is
     if (r_elevation) WO_HIP(hipMemcpyAsync(p->d_e, r_elevation, (size_t)p->N * 4, hipMemcpyHostToDevice, s));
     if (r_isOcean) {
         WO_HIP(hipMemcpyAsync(p->d_ocean, r_isOcean, (size_t)p->N, hipMemcpyHostToDevice, s));
-        p->h_ocean.assign(r_isOcean, r_isOcean + p->N);
-        ocean_changed(p, true);
+        if (p->h_ocean.size() != (size_t)p->N || std::memcmp(p->h_ocean.data(), r_isOcean, (size_t)p->N) != 0) {
+            p->h_ocean.assign(r_isOcean, r_isOcean + p->N);
+            p->flood.staticValid = false;
+        }
+        p->h_ocean_valid = true;
     }
     WO_HIP(hipStreamSynchronize(s));
     return 0;
@@ -516,7 +524,7 @@ int wo_planet_ocean_from_elevation(wo_planet* p) {
     if (!check_planet(p, "wo_planet_ocean_from_elevation")) return 1;
     WO_TRY
     launch(p, FAM_OCEAN, k_ocean_from_elev, blocks_for(p->N), WO_BLOCK, (const float*)p->d_e, p->d_ocean, p->N);
-    ocean_changed(p, false);
+    ocean_changed(p);
     return 0;
     WO_CATCH("wo_planet_ocean_from_elevation")
 }
@@ -555,7 +563,7 @@ int wo_planet_restore_state(wo_planet* p) {
     WO_TRY
     WO_HIP(hipMemcpyAsync(p->d_e, p->d_savedE, (size_t)p->N * 4, hipMemcpyDeviceToDevice, p->ctx->stream));
     WO_HIP(hipMemcpyAsync(p->d_ocean, p->d_savedOcean, (size_t)p->N, hipMemcpyDeviceToDevice, p->ctx->stream));
-    ocean_changed(p, false);
+    ocean_changed(p);
     return 0;
     WO_CATCH("wo_planet_restore_state")
 }
@@ -606,7 +614,7 @@ int wo_planet_synthetic_terrain(wo_planet* p, double seed) {
     WO_TRY
     upload_tables(p, seed);
     launch(p, FAM_SYNTH, k_synthetic, blocks_for(p->N), WO_BLOCK, (const uint8_t*)p->d_tables, (const float*)p->d_xyz, p->d_e, p->d_ocean, p->N);
-    ocean_changed(p, false);
+    ocean_changed(p);
     return 0;
     WO_CATCH("wo_planet_synthetic_terrain")
 }

@@ -15,12 +15,14 @@ void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float*
 
 // flood_host.cc
 struct FloodHeapItem { float key; int32_t cell; };
+struct FloodCell { float e; int32_t drain; };
 struct FloodScratch {
     std::vector<int32_t> drainTo, path, order, order2, seedCell, seedTarget;
     std::vector<uint8_t> visited;
     std::vector<float> surface;
     std::vector<uint32_t> bits, bits2;
     std::vector<FloodHeapItem> heapStore;
+    std::vector<FloodCell> state;
     bool staticValid = false;       // seed list valid for the current (mesh, r_isOcean)
     void ensure(int32_t N);
 };

@@ -1,0 +1,34 @@
+"""bench.py's N>1 path on CPU: two ranks over gloo (the GPU run uses the same code over RCCL).  The path shards
+by planet (ensemble, no data-path collective): ranks must get distinct seeds, the job time must be the MAX over
+ranks and the value must aggregate all ranks' cells."""
+import json
+import socket
+import subprocess
+import sys
+
+from conftest import REPO
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo(tmp_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(REPO / "tests" / "dist_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.loads((tmp_path / f"rank{i}.json").read_text()) for i in range(2)]
+    assert [x["seed"] for x in res] == [1, 2]
+    assert all(abs(x["wall"] - 3.0) < 1e-12 for x in res)               # max over ranks
+    assert all(abs(x["value"] - 1000 * 200 * 3 * 2 / 3.0 / 1e6) < 1e-12 for x in res)
+
+
+def test_bench_line_schema_helpers():
+    import bench
+    assert bench.whole_job_value(10_000_001, 200, 2, 1, 10.0) == 10_000_001 * 200 * 2 / 10.0 / 1e6
+    assert set(bench.ALGO_BYTES) >= {"solve_round", "thermal_apply", "receivers", "sort_radix(hipcub)"}
