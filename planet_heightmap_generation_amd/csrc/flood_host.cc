@@ -16,6 +16,12 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <algorithm>
+#include <atomic>
+#include <numeric>
+#include <thread>
+
+#include "host_util.h"
 #include "wo_internal.h"
 
 namespace wo {
@@ -155,13 +161,18 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     constexpr int32_t UNVISITED = -2, OCEAN = -3;
     if ((int32_t)S.state.size() < N) S.state.resize(N);
     FloodCell* st = S.state.data();
-    for (int32_t r = 0; r < N; ++r) { st[r].e = e[r]; st[r].drain = ocean[r] ? OCEAN : UNVISITED; }
+    if ((int32_t)S.root.size() < N) S.root.resize(N);
+    int32_t* root = S.root.data();          // drainage tree id (= ordinal of the seed the cell finally drains through), -1 for none
+    parallel_ranges(N, [&](int64_t b, int64_t en, int) {
+        for (int64_t r = b; r < en; ++r) { st[r].e = e[r]; st[r].drain = ocean[r] ? OCEAN : UNVISITED; root[r] = -1; }
+    });
     std::memcpy(surface, e, sizeof(float) * (size_t)N);
     if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
     KeyHeap heap(S.heapStore);
     for (size_t i = 0; i < S.seedCell.size(); ++i) {        // :118-128, ascending r
         const int32_t r = S.seedCell[i];
         st[r].drain = S.seedTarget[i];
+        root[r] = (int32_t)i;
         heap.push(r, (float)((double)e[r] + cell_noise(r)));
     }
     lap("init+seeds");
@@ -170,11 +181,13 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         const int32_t c = heap.pop();
         const double lim = (double)surface[c] + EPS;
         const int32_t iEnd = off[c + 1];
+        const int32_t rootC = root[c];
         for (int32_t i = off[c]; i < iEnd; ++i) {
             const int32_t nb = adj[i];
             FloodCell& sn = st[nb];
             if (sn.drain != UNVISITED) continue;
             sn.drain = c;
+            root[nb] = rootC;
             float k;
             if ((double)sn.e < lim) {
                 surface[nb] = (float)lim;
@@ -186,49 +199,116 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         }
     }
     // unreachable land (enclosed by inland seas) keeps drainTo = -1 (:108)
-    for (int32_t r = 0; r < N; ++r) { const int32_t d = st[r].drain; drainTo[r] = d >= 0 ? d : -1; }
+    parallel_ranges(N, [&](int64_t b, int64_t en, int) {
+        for (int64_t r = b; r < en; ++r) { const int32_t d = st[r].drain; drainTo[r] = d >= 0 ? d : -1; }
+    });
     lap("pass1");
-    // --- pass 2 (:152-196): ascending r, sequential
-    int32_t* path = S.path.data();
-    int64_t nDef = 0, totLen = 0;
-    for (int32_t r = 0; r < N; ++r) {
-        if (ocean[r]) continue;
-        const double deficit = (double)surface[r] - (double)e[r];
-        if (deficit <= EPS) continue;
-        int32_t len = 0, peakIdx = -1;
-        double peakElev = -INFINITY;
-        for (int32_t cur = r; cur >= 0 && !ocean[cur]; cur = drainTo[cur]) {
-            path[len++] = cur;
-            if ((double)e[cur] > peakElev) { peakElev = e[cur]; peakIdx = len - 1; }
-        }
-        if (timing) { ++nDef; totLen += len; }
-        if (peakIdx < 0) continue;
-        const double carveAmount = deficit * carveStrength;
-        const double rc = std::ceil((double)len * 0.3);
-        const int32_t radius = rc > 3.0 ? (int32_t)rc : 3;
-        const int32_t k0 = peakIdx - radius > 0 ? peakIdx - radius : 0;
-        const int32_t k1 = peakIdx + radius < len - 1 ? peakIdx + radius : len - 1;
-        double kernelSum = 0;
-        for (int32_t k = k0; k <= k1; ++k) kernelSum += 1 - std::fabs((double)(k - peakIdx)) / (radius + 1);
-        if (kernelSum > 0) {
-            for (int32_t k = k0; k <= k1; ++k) {
-                const double w = (1 - std::fabs((double)(k - peakIdx)) / (radius + 1)) / kernelSum;
-                float v = (float)((double)e[path[k]] - carveAmount * w);
-                if (v < 0) v = 0;
-                e[path[k]] = v;
-            }
-        }
-        e[r] = (float)((double)e[r] + deficit * (1 - carveStrength));
+    // --- pass 2 (:152-196) and pass 3 (:200-214).  Both are sequential in the reference, but every cell a turn
+    // reads or writes (the drain path of r, the carve window on it, r itself; in pass 3 the cell and its
+    // drain target) lies inside r's drainage tree, and trees share no land cell.  So the trees are processed
+    // concurrently on the host's cores while each tree keeps the reference's order (ascending r in pass 2,
+    // ascending (surface, r) in pass 3): identical results, no relaxation.
+    const int32_t nTrees = (int32_t)S.seedCell.size();
+    std::vector<int32_t> cnt2(nTrees + 1, 0);
+    // all cells of each tree, ascending r inside.  (Not just the cells with an initial deficit: a carve lowers
+    // other cells of the path below their flood surface, and the reference tests `deficit > EPS` against the
+    // current height when it reaches them, :154-155.)
+    int32_t* list2 = S.order.data();
+    {
+        for (int32_t r = 0; r < N; ++r) if (root[r] >= 0) cnt2[root[r] + 1]++;
+        for (int32_t t = 0; t < nTrees; ++t) cnt2[t + 1] += cnt2[t];
+        std::vector<int32_t> fill(cnt2.begin(), cnt2.end() - 1);
+        for (int32_t r = 0; r < N; ++r) if (root[r] >= 0) list2[fill[root[r]]++] = r;
     }
-    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells, total path length %lld\n", (long long)nDef, (long long)totLen);
+    // Trees are numbered by their seed's cell id, i.e. along the Fibonacci spiral: consecutive tree ids are
+    // spatial neighbours.  Workers take contiguous chunks of tree ids so that each core works inside its own
+    // band of the elevation array (random hand-out makes cores fight over shared cache lines and erases the gain).
+    auto for_trees = [&](const std::vector<int32_t>& cnt, auto body) {
+        // measured on the 2-socket EPYC GPU box: 4-8 workers give ~3x on these pointer-chasing passes; 16+ cores
+        // contend in the memory system (cross-CCD/NUMA coherence on the written field) and per-tree time rises 7x
+        const int nt = std::max(1, std::min<int>(std::min(host_threads(), 6), nTrees));
+        const int64_t total = cnt[nTrees];
+        const int64_t perChunk = std::max<int64_t>(2048, total / (nt * 16));
+        std::vector<int32_t> chunkStart;            // chunk boundaries with ~equal cell counts
+        chunkStart.push_back(0);
+        for (int32_t t = 0, last = 0; t < nTrees; ++t)
+            if (cnt[t + 1] - cnt[last] >= perChunk) { chunkStart.push_back(t + 1); last = t + 1; }
+        if (chunkStart.back() != nTrees) chunkStart.push_back(nTrees);
+        const size_t nChunks = chunkStart.size() - 1;
+        std::atomic<size_t> next{0};
+        std::atomic<int64_t> busyUs{0}, maxTreeUs{0};
+        auto worker = [&]() {
+            int64_t myBusy = 0, myMax = 0;
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= nChunks) break;
+                for (int32_t t = chunkStart[c]; t < chunkStart[c + 1]; ++t) if (cnt[t + 1] > cnt[t]) {
+                    if (timing) {
+                        auto t0 = std::chrono::steady_clock::now();
+                        body(t);
+                        const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                        myBusy += us; if (us > myMax) myMax = us;
+                    } else body(t);
+                }
+            }
+            if (timing) { busyUs += myBusy; int64_t prev = maxTreeUs.load(); while (myMax > prev && !maxTreeUs.compare_exchange_weak(prev, myMax)) {} }
+        };
+        if (nt == 1) { worker(); return; }
+        std::vector<std::thread> th;
+        for (int i = 0; i < nt; ++i) th.emplace_back(worker);
+        for (auto& t : th) t.join();
+        if (timing) std::fprintf(stderr, "[flood]   %d threads, %zu chunks: summed busy %.1f ms, slowest single tree %.1f ms\n", nt, nChunks, busyUs.load() / 1e3, maxTreeUs.load() / 1e3);
+    };
+    std::atomic<int64_t> nDef{0}, totLen{0}, maxTreeLen{0};
+    lap("group2");
+    for_trees(cnt2, [&](int32_t tree) {
+        std::vector<int32_t> path;
+        int64_t myLen = 0;
+        for (int32_t q = cnt2[tree]; q < cnt2[tree + 1]; ++q) {
+            const int32_t r = list2[q];
+            // the deficit is taken against the CURRENT (already carved) height, as in the reference (:154)
+            const double deficit = (double)surface[r] - (double)e[r];
+            if (deficit <= EPS) continue;
+            if (timing) ++nDef;
+            path.clear();
+            int32_t peakIdx = -1;
+            double peakElev = -INFINITY;
+            for (int32_t cur = r; cur >= 0 && !ocean[cur]; cur = drainTo[cur]) {
+                path.push_back(cur);
+                if ((double)e[cur] > peakElev) { peakElev = e[cur]; peakIdx = (int32_t)path.size() - 1; }
+            }
+            const int32_t len = (int32_t)path.size();
+            myLen += len;
+            if (peakIdx < 0) continue;
+            const double carveAmount = deficit * carveStrength;
+            const double rc = std::ceil((double)len * 0.3);
+            const int32_t radius = rc > 3.0 ? (int32_t)rc : 3;
+            const int32_t k0 = peakIdx - radius > 0 ? peakIdx - radius : 0;
+            const int32_t k1 = peakIdx + radius < len - 1 ? peakIdx + radius : len - 1;
+            double kernelSum = 0;
+            for (int32_t k = k0; k <= k1; ++k) kernelSum += 1 - std::fabs((double)(k - peakIdx)) / (radius + 1);
+            if (kernelSum > 0) {
+                for (int32_t k = k0; k <= k1; ++k) {
+                    const double w = (1 - std::fabs((double)(k - peakIdx)) / (radius + 1)) / kernelSum;
+                    float v = (float)((double)e[path[k]] - carveAmount * w);
+                    if (v < 0) v = 0;
+                    e[path[k]] = v;
+                }
+            }
+            e[r] = (float)((double)e[r] + deficit * (1 - carveStrength));
+        }
+        if (timing) { totLen += myLen; int64_t prev = maxTreeLen.load(); while (myLen > prev && !maxTreeLen.compare_exchange_weak(prev, myLen)) {} }
+    });
+    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
+    if (timing) std::fprintf(stderr, "[flood] pass2: largest tree walks %lld path steps\n", (long long)maxTreeLen.load());
     lap("pass2");
-    // --- pass 3 (:200-214): land cells by ascending surface (stable), enforce descent along drainTo
+    // --- pass 3: land cells by ascending surface (stable => ties ascending r), then grouped by tree
     int32_t nLand = 0;
     int32_t* order = S.order.data();
     int32_t* order2 = S.order2.data();
     uint32_t* b0 = S.bits.data();
     uint32_t* b1 = S.bits2.data();
-    for (int32_t r = 0; r < N; ++r) if (!ocean[r]) { order[nLand] = r; b0[nLand] = asc_bits(surface[r]); ++nLand; }
+    for (int32_t r = 0; r < N; ++r) if (root[r] >= 0) { order[nLand] = r; b0[nLand] = asc_bits(surface[r]); ++nLand; }
     for (int pass = 0; pass < 3; ++pass) {          // 11 + 11 + 10 bit LSD radix, stable
         const int sh = pass * 11;
         const uint32_t mask = pass == 2 ? 1023u : 2047u;
@@ -242,12 +322,21 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         }
         std::swap(b0, b1); std::swap(order, order2);
     }
-    for (int32_t i = 0; i < nLand; ++i) {
-        const int32_t c = order[i], t = drainTo[c];
-        if (t < 0) continue;
-        const double te = ocean[t] ? 0.0 : (double)e[t];
-        if ((double)e[c] <= te) e[c] = (float)(te + EPS);
+    std::vector<int32_t> cnt3(nTrees + 1, 0);
+    for (int32_t i = 0; i < nLand; ++i) cnt3[root[order[i]] + 1]++;
+    for (int32_t t = 0; t < nTrees; ++t) cnt3[t + 1] += cnt3[t];
+    {
+        std::vector<int32_t> fill(cnt3.begin(), cnt3.end() - 1);
+        for (int32_t i = 0; i < nLand; ++i) { const int32_t c = order[i]; order2[fill[root[c]]++] = c; }   // stable
     }
+    for_trees(cnt3, [&](int32_t tree) {
+        for (int32_t q = cnt3[tree]; q < cnt3[tree + 1]; ++q) {
+            const int32_t c = order2[q], t = drainTo[c];
+            if (t < 0) continue;
+            const double te = ocean[t] ? 0.0 : (double)e[t];
+            if ((double)e[c] <= te) e[c] = (float)(te + EPS);
+        }
+    });
     lap("pass3");
 }
 

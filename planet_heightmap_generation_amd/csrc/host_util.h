@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <thread>
 #include <vector>
@@ -10,6 +11,7 @@
 namespace wo {
 
 inline int host_threads() {
+    if (const char* ev = std::getenv("WO_HOST_THREADS")) { int v = std::atoi(ev); if (v >= 1) return v > 256 ? 256 : v; }
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
     if (n > 64) n = 64;

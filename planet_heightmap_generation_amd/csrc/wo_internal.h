@@ -17,7 +17,7 @@ void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float*
 struct FloodHeapItem { float key; int32_t cell; };
 struct FloodCell { float e; int32_t drain; };
 struct FloodScratch {
-    std::vector<int32_t> drainTo, path, order, order2, seedCell, seedTarget;
+    std::vector<int32_t> drainTo, path, order, order2, seedCell, seedTarget, root;
     std::vector<uint8_t> visited;
     std::vector<float> surface;
     std::vector<uint32_t> bits, bits2;
