@@ -76,10 +76,11 @@ struct wo_planet {
     bool scratch = false;
     int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
     uint32_t* d_keys[2] = {nullptr, nullptr};
-    float *d_cellDist = nullptr, *d_flow = nullptr, *d_selfOut = nullptr, *d_tOut = nullptr;
+    float *d_cellDist = nullptr, *d_flow = nullptr;
+    wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr;
     uint32_t *d_acc = nullptr, *d_snap = nullptr;
     int32_t *d_jump = nullptr, *d_nj = nullptr;
-    int32_t *d_predSelf = nullptr, *d_predT = nullptr, *d_predT2 = nullptr, *d_doneAt = nullptr;
+    int32_t* d_doneAt = nullptr;
     double* d_totalExcess = nullptr;
     float *d_glac = nullptr, *d_iceFlow = nullptr;
     int32_t *d_iceTarget = nullptr, *d_arank = nullptr;

@@ -37,6 +37,22 @@ namespace wo {
 constexpr int WO_MAX_DEG = 24;          // planets with a larger vertex degree are rejected at creation
 constexpr int32_t WO_NOT_DONE = 0x7fffffff;
 
+// ---- solve dataflow records (one 48-byte record in, one 16-byte record out per task) ----
+// Everything a turn of the implicit solve needs that does not depend on other turns is gathered once, in
+// index order, by solve_setup; a round then costs: list entry -> task record -> <=3 predecessor granules.
+struct alignas(16) SolveTask {
+    int32_t predSelf, predT, predT2;   // granule index 2*cell + (0: that cell's own turn, 1: its deposit on its receiver), -1: none
+    int32_t target;                    // drainTarget[r]
+    float e0r, e0t, e0t2;              // heights before the pass (used where there is no predecessor event)
+    float flow;                        // flow[r]
+    float cellDist, cellDistT;         // cellDist[r], cellDist[target]
+    int32_t t2;                        // drainTarget[target] or -1
+    uint32_t flags;                    // bit0: target is ocean, bit1: t2 is ocean
+};
+// {value, round tag}: tag 0 = not produced yet.  Written once per pass, consumed only by later rounds.
+struct alignas(8) Granule { float v; int32_t tag; };
+struct alignas(16) SolveOut { Granule self, dep; };
+
 struct Fields {
     int32_t N;                 // numRegions
     const int32_t* off;        // adjOffset [N+1]
@@ -57,9 +73,9 @@ struct Fields {
     uint32_t* accA; uint32_t* accB;     // pointer-doubling accumulators [N]
     int32_t* jumpA; int32_t* jumpB;     // pointer-doubling ancestors [N]
     // solve dataflow
-    int32_t* predSelf; int32_t* predT; int32_t* predT2;   // predecessor task (cell id) or -1 [N]
-    float* selfOut; float* tOut;        // event outputs [N]
-    int32_t* doneAt;                    // round in which the task finished, WO_NOT_DONE before [N]
+    SolveTask* task;                    // per-land-cell task record built by solve_setup [N]
+    SolveOut* out;                      // per-cell event outputs {own turn, deposit on receiver} [N]
+    int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]
     // thermal
     double* totalExcess;                // [N]
     // glacial
@@ -250,63 +266,70 @@ WO_HD inline int32_t latest_event_before(const Fields& F, int32_t x, int32_t r) 
     return best;
 }
 
+// granule index of the event task p leaves on location x (p == x: own turn, else deposit)
+WO_HD inline int32_t granule_index(int32_t x, int32_t p) { return p < 0 ? -1 : 2 * p + (p == x ? 0 : 1); }
+
 WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
-    F.doneAt[r] = WO_NOT_DONE;
-    if (F.ocean[r]) { F.predSelf[r] = F.predT[r] = F.predT2[r] = -1; return; }
+    if (F.ocean[r]) return;
+    SolveTask T;
     const int32_t t = F.target[r];
-    F.predSelf[r] = latest_event_before(F, r, r);
-    int32_t pt = -1, pt2 = -1;
-    if (t >= 0 && !F.ocean[t]) {
-        pt = latest_event_before(F, t, r);
-        const int32_t t2 = F.target[t];
-        if (t2 >= 0 && !F.ocean[t2]) pt2 = latest_event_before(F, t2, r);
+    T.target = t;
+    T.predSelf = granule_index(r, latest_event_before(F, r, r));
+    T.predT = -1; T.predT2 = -1; T.t2 = -1; T.flags = 0;
+    T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
+    T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
+    if (t >= 0) {
+        T.e0t = F.e[t];
+        if (F.ocean[t]) T.flags |= 1u;
+        else {
+            T.predT = granule_index(t, latest_event_before(F, t, r));
+            const int32_t t2 = F.target[t];
+            T.cellDistT = F.cellDist[t];
+            if (t2 >= 0 && T.cellDistT > 0) {
+                T.t2 = t2;
+                T.e0t2 = F.e[t2];
+                if (F.ocean[t2]) T.flags |= 2u;
+                else T.predT2 = granule_index(t2, latest_event_before(F, t2, r));
+            }
+        }
     }
-    F.predT[r] = pt; F.predT2[r] = pt2;
+    F.task[r] = T;
+    SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
+    F.out[r] = z;
 }
 
-// value of location x as left by event task p (p == x: own turn, else p deposited onto x); p < 0: initial
-WO_HD inline double event_value(const Fields& F, int32_t x, int32_t p) {
-    if (p < 0) return (double)F.e[x];
-    return (p == x) ? (double)F.selfOut[p] : (double)F.tOut[p];
-}
-
-// Returns true when the task ran (all predecessors finished in rounds < round).
+// Returns true when the task ran (all predecessors were produced in rounds < round).
 WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K, double m, double dt) {
-    const int32_t ps = F.predSelf[r], pt = F.predT[r], pt2 = F.predT2[r];
-    if (ps >= 0 && !(F.doneAt[ps] < round)) return false;
-    if (pt >= 0 && !(F.doneAt[pt] < round)) return false;
-    if (pt2 >= 0 && !(F.doneAt[pt2] < round)) return false;
-    const int32_t t = F.target[r];
-    const double er = event_value(F, r, ps);
-    if (t < 0) {       // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
-        F.selfOut[r] = (float)er; F.tOut[r] = 0; F.doneAt[r] = round; return true;
+    const SolveTask T = F.task[r];
+    const Granule* G = reinterpret_cast<const Granule*>(F.out);
+    double er = T.e0r, et = T.e0t, et2 = T.e0t2;
+    if (T.predSelf >= 0) { const Granule g = G[T.predSelf]; if (g.tag == 0 || !(g.tag < round)) return false; er = g.v; }
+    if (T.predT >= 0)    { const Granule g = G[T.predT];    if (g.tag == 0 || !(g.tag < round)) return false; et = g.v; }
+    if (T.predT2 >= 0)   { const Granule g = G[T.predT2];   if (g.tag == 0 || !(g.tag < round)) return false; et2 = g.v; }
+    SolveOut o;
+    o.self.tag = round; o.dep.tag = round;
+    if (T.target < 0) {          // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
+        o.self.v = (float)er; o.dep.v = 0; F.out[r] = o; return true;
     }
-    const double et = event_value(F, t, pt);
-    const double fl = F.flow[r];
+    const double fl = T.flow;
     const double pw = (m == 0.5) ? sqrt(fl) : pow(fl, m);
-    const double factor = K * pw * dt / (double)F.cellDist[r];
+    const double factor = K * pw * dt / (double)T.cellDist;
     const double hr = et > 0 ? et : 0;
     double hn = (er + factor * hr) / (1 + factor);
     if (hn < hr) hn = hr;
     if (hn < 0) hn = 0;
     const double eroded = er - hn;
     float tval = (float)et;
-    if (eroded > 0 && !F.ocean[t]) {
-        const int32_t t2 = F.target[t];
+    if (eroded > 0 && !(T.flags & 1u)) {
         double slope = 0;
-        if (t2 >= 0 && F.cellDist[t] > 0) {
-            // t2 may be an ocean cell (never written here) or land (latest event before this turn)
-            const double et2 = F.ocean[t2] ? (double)F.e[t2] : event_value(F, t2, pt2);
-            slope = fabs(et - et2) / (double)F.cellDist[t];
-        }
+        if (T.t2 >= 0) slope = fabs(et - et2) / (double)T.cellDistT;
         const double depositFrac = 0.5 / (1 + slope * 50);
         const double deposit = eroded * depositFrac;
         tval = (float)(et + deposit);
         if ((double)tval > hn) tval = (float)hn;
     }
-    F.tOut[r] = tval;
-    F.selfOut[r] = (float)hn;
-    F.doneAt[r] = round;
+    o.self.v = (float)hn; o.dep.v = tval;
+    F.out[r] = o;
     return true;
 }
 
@@ -322,7 +345,7 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
         if (k < bestRank) { best = n; bestRank = k; }
     }
     if (best < 0) return F.e[x];
-    return (best == x) ? F.selfOut[x] : F.tOut[best];
+    return (best == x) ? F.out[x].self.v : F.out[best].dep.v;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level) {
-    WO_GRID_STRIDE(r, F.N) { out[r] = solve_final_cell(F, r); level[r] = F.doneAt[r]; }
+    WO_GRID_STRIDE(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[r].self.tag; }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 

@@ -47,9 +47,9 @@ static void ensure_scratch(wo_planet* p) {
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
-    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_selfOut = dalloc<float>(N); p->d_tOut = dalloc<float>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
-    p->d_predSelf = dalloc<int32_t>(N); p->d_predT = dalloc<int32_t>(N); p->d_predT2 = dalloc<int32_t>(N); p->d_doneAt = dalloc<int32_t>(N);
+    p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
     p->d_iceUp = dalloc<uint8_t>(N);
@@ -69,7 +69,7 @@ wo::Fields wo_planet::fields() const {
     F.N = N; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
-    F.predSelf = d_predSelf; F.predT = d_predT; F.predT2 = d_predT2; F.selfOut = d_selfOut; F.tOut = d_tOut; F.doneAt = d_doneAt;
+    F.task = d_task; F.out = d_out; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank;
     return F;
 }
@@ -478,8 +478,8 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_selfOut); dfree(p->d_tOut); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
-    dfree(p->d_predSelf); dfree(p->d_predT); dfree(p->d_predT2); dfree(p->d_doneAt); dfree(p->d_totalExcess);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
     if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);

@@ -19,8 +19,9 @@ namespace {
 struct Emu {
     Fields F{};
     std::vector<uint8_t> coast, iceUp;
-    std::vector<float> e2, cellDist, flow, selfOut, tOut, glac, iceFlow;
-    std::vector<int32_t> land, landIdx, rank, target, jumpA, predSelf, predT, predT2, doneAt, iceTarget, arank;
+    std::vector<float> e2, cellDist, flow, glac, iceFlow;
+    std::vector<SolveTask> task; std::vector<SolveOut> out;
+    std::vector<int32_t> land, landIdx, rank, target, jumpA, doneAt, iceTarget, arank;
     std::vector<uint32_t> accA;
     std::vector<double> totalExcess;
     int64_t solveRounds = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, maxSolveRounds = 0;
@@ -81,7 +82,7 @@ int64_t run_solve_rounds_pred(Emu& E, std::vector<int32_t>& level, double K, dou
         if (round + LOOKAHEAD >= maxPred && left.empty()) break;
         if (round > 8 * (int64_t)F.N) return -round;
     }
-    for (int32_t r : E.landIdx) level[r] = F.doneAt[r];
+    for (int32_t r : E.landIdx) level[r] = F.out[r].self.tag;
     return round;
 }
 
@@ -99,12 +100,10 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     Fields& F = E.F;
     F.N = N; F.off = off; F.adj = adj; F.dist = dist; F.xyz = xyz; F.ocean = ocean; F.e = e;
     E.coast.resize(N); E.e2.resize(N); E.rank.assign(N, -1); E.target.resize(N); E.cellDist.resize(N); E.flow.resize(N);
-    E.accA.resize(N); E.jumpA.resize(N); E.predSelf.resize(N); E.predT.resize(N); E.predT2.resize(N);
-    E.selfOut.resize(N); E.tOut.resize(N); E.doneAt.resize(N); E.totalExcess.resize(N);
+    E.accA.resize(N); E.jumpA.resize(N); E.task.resize(N); E.out.resize(N); E.doneAt.resize(N); E.totalExcess.resize(N);
     E.glac.assign(N, 0.f); E.iceTarget.resize(N); E.iceFlow.resize(N); E.iceUp.resize(N); E.arank.resize(N);
     F.e2 = E.e2.data(); F.rank = E.rank.data(); F.target = E.target.data(); F.cellDist = E.cellDist.data();
-    F.flow = E.flow.data(); F.accA = E.accA.data(); F.jumpA = E.jumpA.data(); F.predSelf = E.predSelf.data();
-    F.predT = E.predT.data(); F.predT2 = E.predT2.data(); F.selfOut = E.selfOut.data(); F.tOut = E.tOut.data();
+    F.flow = E.flow.data(); F.accA = E.accA.data(); F.jumpA = E.jumpA.data(); F.task = E.task.data(); F.out = E.out.data();
     F.doneAt = E.doneAt.data(); F.totalExcess = E.totalExcess.data(); F.glac = E.glac.data();
     F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data();
     F.coast = E.coast.data();
