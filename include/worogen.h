@@ -95,6 +95,33 @@ int wo_sharpen_ridges(wo_planet* p, float* r_elevation, const uint8_t* r_isOcean
 /* applySoilCreep(mesh, r_elevation, r_isOcean, iterations, strength)  js/terrain-post.js:758 */
 int wo_soil_creep(wo_planet* p, float* r_elevation, const uint8_t* r_isOcean, int32_t iterations, double strength);
 
+/* ------------------------------------------------ assignElevation (js/elevation.js:216-1391) -- */
+/* Plate tables are dense by plate id (the reference keys plateVec / plateDensity / plateIsOcean by plate id;
+ * ids are coarse-mesh region indices for plates, 0..n-1 for super plates). */
+typedef struct wo_plate_table {
+    int32_t        numIds;   /* table length = max plate id + 1                              */
+    const uint8_t* hasVec;   /* [numIds] plateVec[id] is defined                              */
+    const double*  pole;     /* [3*numIds] plateVec[id].pole                                  */
+    const double*  omega;    /* [numIds]   plateVec[id].omega                                 */
+    const uint8_t* isOcean;  /* [numIds]   plateIsOcean.has(id)                               */
+    const double*  density;  /* [numIds]   plateDensity[id]                                   */
+} wo_plate_table;
+/* assignElevation(mesh, r_xyz, plateIsOcean, r_plate, plateVec, plateSeeds, noise, noiseMag, seed, spread,
+ *                 plateDensity, superPlateData)  ->  { r_elevation, mountain_r, coastline_r, ocean_r, r_stress,
+ *                 debugLayers }                                                 js/elevation.js:216,1386-1390
+ * plateSeeds is the Set in iteration order; r_superPlate / superPlates are NULL when superPlateData is null;
+ * noisePerm512 / noisePm12_512 are the `noise` instance's tables; debugLayers (NULL or 12*numRegions floats,
+ * layer-major) in the order base, tectonic, noise, interior, coastal, ocean, hotspot, tecActivity, margins,
+ * backArc, foldRidge, orogenicPower; the three Sets come back in insertion order (arrays of numRegions ints,
+ * sizes in setCounts[3]).  The resident r_elevation of the planet is set to the result as well. */
+int wo_assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plate_table* plates,
+                        const int32_t* plateSeeds, int32_t numPlateSeeds,
+                        const int32_t* r_superPlate, const wo_plate_table* superPlates,
+                        const uint8_t* noisePerm512, const uint8_t* noisePm12_512,
+                        double noiseMag, double seed, double spread,
+                        float* r_elevation, float* r_stress, float* debugLayers,
+                        int32_t* mountain_r, int32_t* coastline_r, int32_t* ocean_r, int32_t* setCounts);
+
 /* ------------------------------------------------ device-resident variants -------------------- */
 /* The "reapply" pattern (js/planet-worker.js:341-440): fields stay in HBM, only scalars arrive.
  * wo_planet_upload sets the resident r_elevation (and r_isOcean when not NULL); the *_resident

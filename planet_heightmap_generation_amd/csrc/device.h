@@ -40,7 +40,7 @@ enum Family : int {
     FAM_SORT_KEYS, FAM_SORT_RADIX, FAM_RANK, FAM_RECEIVERS, FAM_FLOW_INIT, FAM_FLOW_SNAP, FAM_FLOW_APPLY, FAM_FLOW_FINAL,
     FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
     FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
-    FAM_LEVEL_SORT, FAM_MISC, FAM_COUNT
+    FAM_LEVEL_SORT, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_MISC, FAM_COUNT
 };
 extern const char* const kFamilyNames[FAM_COUNT];
 
@@ -57,6 +57,7 @@ struct wo_planet {
     int32_t N = 0, E = 0, maxDeg = 0;
     // host copies kept for the host-resident flood stage
     std::vector<int32_t> h_off, h_adj;
+    std::vector<float> h_xyz;
     std::vector<uint8_t> h_ocean;
     bool h_ocean_valid = false;
     float* h_pinned = nullptr;          // N floats, pinned

@@ -12,6 +12,8 @@
 
 #include "../../include/worogen.h"
 #include "device.h"
+#include "elevation_host.h"
+#include "elevation_kernels.h"
 #include "kernels_impl.h"
 #include "noise.h"
 
@@ -21,7 +23,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "elev_collisions", "elev_uplift_fused", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -442,6 +444,7 @@ wo_planet* wo_planet_create(wo_ctx* ctx, int32_t numRegions, const int32_t* adjO
         p->ctx = ctx; p->N = N; p->E = E; p->maxDeg = maxDeg;
         p->h_off.assign(adjOffset, adjOffset + N + 1);
         p->h_adj.assign(adjList, adjList + E);
+        p->h_xyz.assign(r_xyz, r_xyz + 3 * (size_t)N);
         hipStream_t s = ctx->stream;
         p->d_off = dalloc<int32_t>(N + 1); p->d_adj = dalloc<int32_t>(E); p->d_dist = dalloc<float>(E); p->d_xyz = dalloc<float>(3 * (size_t)N);
         p->d_e = dalloc<float>(N); p->d_e2 = dalloc<float>(N); p->d_hot = dalloc<float>(N); p->d_orig = dalloc<float>(N);
@@ -742,3 +745,144 @@ int wo_last_erode_stats(wo_planet* p, int32_t cap, const char** names, double* v
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// assignElevation (js/elevation.js:216-1391): collisions on the device, order-defined graph work on the
+// host (elevation_host.cc), the fused per-cell uplift pass on the device.
+// ---------------------------------------------------------------------------------------------------
+namespace wo {
+
+struct DevPlateTable {
+    PlateTable t{}; uint8_t* hasVec = nullptr; double* pole = nullptr; double* omega = nullptr; uint8_t* isOcean = nullptr; double* density = nullptr;
+    void upload(const wo_plate_table& h, hipStream_t s) {
+        const size_t n = (size_t)h.numIds;
+        hasVec = dalloc<uint8_t>(n); pole = dalloc<double>(3 * n); omega = dalloc<double>(n); isOcean = dalloc<uint8_t>(n); density = dalloc<double>(n);
+        WO_HIP(hipMemcpyAsync(hasVec, h.hasVec, n, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(pole, h.pole, 3 * n * 8, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(omega, h.omega, n * 8, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(isOcean, h.isOcean, n, hipMemcpyHostToDevice, s));
+        WO_HIP(hipMemcpyAsync(density, h.density, n * 8, hipMemcpyHostToDevice, s));
+        t.numIds = h.numIds; t.hasVec = hasVec; t.pole = pole; t.omega = omega; t.isOcean = isOcean; t.density = density;
+    }
+    void release() { dfree(hasVec); dfree(pole); dfree(omega); dfree(isOcean); dfree(density); }
+};
+
+struct DevCollision {
+    CollisionOut o{};
+    void alloc(size_t N) { o.stress = dalloc<float>(N); o.subduct = dalloc<float>(N); o.btype = dalloc<int8_t>(N); o.bothOcean = dalloc<uint8_t>(N); o.hasOcean = dalloc<uint8_t>(N); o.setCode = dalloc<uint8_t>(N); }
+    void download(CollisionHost& h, size_t N, hipStream_t s) {
+        h.resize((int32_t)N);
+        WO_HIP(hipMemcpyAsync(h.stress.data(), o.stress, N * 4, hipMemcpyDeviceToHost, s)); WO_HIP(hipMemcpyAsync(h.subduct.data(), o.subduct, N * 4, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipMemcpyAsync(h.btype.data(), o.btype, N, hipMemcpyDeviceToHost, s)); WO_HIP(hipMemcpyAsync(h.bothOcean.data(), o.bothOcean, N, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipMemcpyAsync(h.hasOcean.data(), o.hasOcean, N, hipMemcpyDeviceToHost, s)); WO_HIP(hipMemcpyAsync(h.setCode.data(), o.setCode, N, hipMemcpyDeviceToHost, s));
+    }
+    void release() { dfree(o.stress); dfree(o.subduct); dfree(o.btype); dfree(o.bothOcean); dfree(o.hasOcean); dfree(o.setCode); }
+};
+
+static PlateTable host_table(const wo_plate_table& h) { PlateTable t; t.numIds = h.numIds; t.hasVec = h.hasVec; t.pole = h.pole; t.omega = h.omega; t.isOcean = h.isOcean; t.density = h.density; return t; }
+
+template <class T> static T* upload_vec(const std::vector<T>& v, hipStream_t s) {
+    T* d = dalloc<T>(v.size());
+    WO_HIP(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return d;
+}
+
+static void assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plate_table* plates, const int32_t* plateSeeds, int32_t numPlateSeeds,
+                             const int32_t* r_superPlate, const wo_plate_table* superPlates, const uint8_t* perm, const uint8_t* pm12,
+                             double noiseMag, double seed, double spread, float* r_elevation, float* r_stress, float* debugLayers,
+                             int32_t* mountain_r, int32_t* coastline_r, int32_t* ocean_r, int32_t* setCounts) {
+    hipStream_t s = p->ctx->stream;
+    const int32_t N = p->N;
+    const int gridN = blocks_for(N);
+    const bool hasSuper = r_superPlate != nullptr && superPlates != nullptr;
+    for (int32_t r = 0; r < N; ++r) if (r_plate[r] < 0 || r_plate[r] >= plates->numIds) throw HipError{"r_plate entry outside the plate table"};
+    if (hasSuper) for (int32_t r = 0; r < N; ++r) if (r_superPlate[r] < 0 || r_superPlate[r] >= superPlates->numIds) throw HipError{"r_superPlate entry outside the super-plate table"};
+    std::vector<std::pair<std::string, double>> timing;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* stage) { WO_HIP(hipStreamSynchronize(s)); auto now = std::chrono::steady_clock::now(); timing.push_back({stage, std::chrono::duration<double, std::milli>(now - t0).count()}); t0 = now; };
+
+    // noise instances: the caller's `noise` plus the nine the reference seeds itself (js/elevation.js:539,636,980-982,1056,1127-1129)
+    std::vector<uint8_t> tabs(EL_TAB_COUNT * 1024), hs3(1024);
+    std::memcpy(tabs.data(), perm, 512); std::memcpy(tabs.data() + 512, pm12, 512);
+    const double offs[EL_TAB_COUNT] = {0, 419, 557, 77, 133, 211, 307, 501, 502};
+    for (int k = 1; k < EL_TAB_COUNT; ++k) noise_tables(seed + offs[k], tabs.data() + k * 1024, tabs.data() + k * 1024 + 512);
+    noise_tables(seed + 503, hs3.data(), hs3.data() + 512);
+    uint8_t* d_tabs = upload_vec(tabs, s);
+    int32_t* d_plate = dalloc<int32_t>(N);
+    WO_HIP(hipMemcpyAsync(d_plate, r_plate, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    DevPlateTable dT, dTS; dT.upload(*plates, s);
+    DevCollision cS, cP; cS.alloc(N);
+    CollisionHost hS, hP;
+    launch(p, FAM_ELEV_COLLISION, k_collision, gridN, WO_BLOCK, N, (const int32_t*)p->d_off, (const int32_t*)p->d_adj, (const float*)p->d_xyz,
+           (const int32_t*)d_plate, dT.t, (const uint8_t*)d_tabs, cS.o);
+    cS.download(hS, N, s);
+    int32_t* d_super = nullptr;
+    if (hasSuper) {
+        d_super = dalloc<int32_t>(N);
+        WO_HIP(hipMemcpyAsync(d_super, r_superPlate, (size_t)N * 4, hipMemcpyHostToDevice, s));
+        dTS.upload(*superPlates, s); cP.alloc(N);
+        launch(p, FAM_ELEV_COLLISION, k_collision, gridN, WO_BLOCK, N, (const int32_t*)p->d_off, (const int32_t*)p->d_adj, (const float*)p->d_xyz,
+               (const int32_t*)d_super, dTS.t, (const uint8_t*)d_tabs, cP.o);
+        cP.download(hP, N, s);
+    }
+    lap(hasSuper ? "Collisions (dual)" : "Collisions");
+
+    // host stage
+    if (p->h_xyz.empty()) throw HipError{"planet has no host copy of r_xyz"};
+    ElevMesh M{N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data()};
+    ElevInputs I{};
+    I.plate = r_plate; I.plates = host_table(*plates); I.plateSeeds = plateSeeds; I.numPlateSeeds = numPlateSeeds;
+    I.superPlate = hasSuper ? r_superPlate : nullptr; if (hasSuper) I.superPlates = host_table(*superPlates);
+    I.seed = seed; I.spread = spread; I.noiseMag = noiseMag; I.hsNoise3 = NoiseTab{hs3.data(), hs3.data() + 512};
+    ElevHostState H; ElevParams Q{}; std::vector<Dome> domes;
+    elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
+    lap("Stress, sets, distance fields, BFS fields (host)");
+
+    // per-cell pass
+    ElevFields F{};
+    F.xyz = p->d_xyz; F.plate = d_plate;
+    std::vector<void*> tmp;
+    auto up = [&](auto& v) { auto* d = upload_vec(v, s); tmp.push_back((void*)d); return d; };
+    F.isOcean = up(H.isOcean); F.stress = up(H.stress); F.subduct = up(H.subduct); F.btype = up(H.btype);
+    F.distMountain = up(H.distMountain); F.distOcean = up(H.distOcean); F.distCoastline = up(H.distCoastline); F.distCoast = up(H.distCoast);
+    F.distCoastLand = up(H.distCoastLand); F.dBdry = up(H.dBdry); F.coastStressMax = up(H.coastStressMax); F.coastSubductMax = up(H.coastSubductMax);
+    F.coastConvergent = up(H.coastConvergent); F.riftDist = up(H.riftDist); F.ridgeDist = up(H.ridgeDist); F.fractureDist = up(H.fractureDist);
+    F.backArcDist = up(H.backArcDist); F.backArcStress = up(H.backArcStress); F.arcDist = up(H.arcDist); F.arcStress = up(H.arcStress);
+    F.elev = p->d_e;
+    float* d_dl = nullptr;
+    if (debugLayers) { d_dl = dalloc<float>((size_t)DL_COUNT * N); WO_HIP(hipMemsetAsync(d_dl, 0, (size_t)DL_COUNT * N * 4, s)); }
+    F.dl = d_dl;
+    if (domes.empty()) domes.push_back(Dome{});
+    Dome* d_domes = upload_vec(domes, s);
+    launch(p, FAM_ELEV_MAIN, k_elevation, gridN, WO_BLOCK, F, Q, dT.t, (const uint8_t*)d_tabs, (const Dome*)d_domes);
+    if (r_elevation) WO_HIP(hipMemcpyAsync(r_elevation, p->d_e, (size_t)N * 4, hipMemcpyDeviceToHost, s));
+    if (debugLayers) WO_HIP(hipMemcpyAsync(debugLayers, d_dl, (size_t)DL_COUNT * N * 4, hipMemcpyDeviceToHost, s));
+    lap("Elevation loop + coastal + arcs + hotspots + compression (device)");
+    if (r_stress) std::memcpy(r_stress, H.stress.data(), (size_t)N * 4);
+    if (mountain_r) std::memcpy(mountain_r, H.mountain.data(), H.mountain.size() * 4);
+    if (coastline_r) std::memcpy(coastline_r, H.coastline.data(), H.coastline.size() * 4);
+    if (ocean_r) std::memcpy(ocean_r, H.ocean.data(), H.ocean.size() * 4);
+    if (setCounts) { setCounts[0] = (int32_t)H.mountain.size(); setCounts[1] = (int32_t)H.coastline.size(); setCounts[2] = (int32_t)H.ocean.size(); }
+    for (void* d : tmp) (void)hipFree(d);
+    (void)hipFree(d_tabs); (void)hipFree(d_plate); (void)hipFree(d_domes);
+    if (d_super) (void)hipFree(d_super);
+    if (d_dl) (void)hipFree(d_dl);
+    dT.release(); dTS.release(); cS.release(); cP.release();
+    p->stageTiming = timing;
+}
+
+}  // namespace wo
+
+extern "C" int wo_assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plate_table* plates, const int32_t* plateSeeds,
+                                   int32_t numPlateSeeds, const int32_t* r_superPlate, const wo_plate_table* superPlates,
+                                   const uint8_t* noisePerm512, const uint8_t* noisePm12_512, double noiseMag, double seed, double spread,
+                                   float* r_elevation, float* r_stress, float* debugLayers, int32_t* mountain_r, int32_t* coastline_r,
+                                   int32_t* ocean_r, int32_t* setCounts) {
+    if (!check_planet(p, "wo_assign_elevation")) return 1;
+    if (!r_plate || !plates || !plateSeeds || !noisePerm512 || !noisePm12_512) { set_error("wo_assign_elevation: null pointer"); return 1; }
+    WO_TRY
+    assign_elevation(p, r_plate, plates, plateSeeds, numPlateSeeds, r_superPlate, superPlates, noisePerm512, noisePm12_512, noiseMag, seed, spread,
+                     r_elevation, r_stress, debugLayers, mountain_r, coastline_r, ocean_r, setCounts);
+    return 0;
+    WO_CATCH("wo_assign_elevation")
+}

@@ -1,0 +1,62 @@
+"""assignElevation (js/elevation.js) — the product's native host stage (csrc/elevation_host.cc) plus the
+per-cell kernel bodies (csrc/elevation_ops.h) driven on the CPU by the test-only emulator, against golden
+vectors produced by running the reference JavaScript (oracle/ref_harness/make_golden_elevation.py).  Bit-exact:
+elevation, stress, the three Sets in insertion order and all 12 debug layers."""
+import ctypes as C
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO, load_golden
+from elev_common import dense_table, load_case
+
+EMU_DIR = REPO / "tests" / "emu"
+CASES = ("elev_N5000_s3_nosuper", "elev_config1_N10000_s1", "elev_N10000_s2")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["make", "-s", "-C", str(EMU_DIR)], check=True)
+    L = C.CDLL(str(EMU_DIR / "_build" / "libemu.so"))
+    p, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+    L.emu_assign_elevation.argtypes = [i32, p, p, p, p, i32, p, p, p, p, p, p, i32, p, i32, p, p, p, p, p, p, p, f64, f64, f64, p, p, p, p, p, p, p]
+    L.emu_pair_intensity.restype = f64
+    L.emu_pair_intensity.argtypes = [i32, i32]
+    return L
+
+
+def P(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def test_pair_intensity_known_answers(emu):
+    # SURVEY Appendix C (captured from the reference under Node)
+    assert emu.emu_pair_intensity(17, 4242) == 0.5255
+    assert emu.emu_pair_intensity(19999, 3) == 1.3159999999999998
+    assert emu.emu_pair_intensity(0, 1) == 1.0529
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_assign_elevation_bit_exact(emu, oracle, name):
+    g = load_golden(name)
+    meta, *_ = load_case(g)
+    N, seed = meta["numRegions"], meta["seed"]
+    n, has, pole, om, oc, de = dense_table(g["plateSeeds"], g["plateVec"], g["plateDensity"], g["plateIsOcean"])
+    if meta["hasSuper"]:
+        ns = meta["numSuperPlates"]
+        sn, shas, spole, som, soc, sde = dense_table(np.arange(ns), g["superPlateVec"], g["superPlateDensity"], g["superPlateIsOcean"])
+        rs = g["r_superPlate"]
+    else:
+        sn, shas, spole, som, soc, sde, rs = 0, None, None, None, None, None, None
+    perm, pm12 = oracle.noise_tables(seed)
+    e = np.zeros(N, np.float32); st = np.zeros(N, np.float32); dl = np.zeros(12 * N, np.float32)
+    mo = np.zeros(N, np.int32); co = np.zeros(N, np.int32); oc_ = np.zeros(N, np.int32); cnt = np.zeros(3, np.int32)
+    rc = emu.emu_assign_elevation(N, P(g["adjOffset"]), P(g["adjList"]), P(g["xyz"]), P(g["r_plate"]), n, P(has), P(pole), P(om), P(oc), P(de),
+                                  P(g["plateSeeds"]), g["plateSeeds"].size, P(rs), sn, P(shas), P(spole), P(som), P(soc), P(sde), P(perm), P(pm12),
+                                  meta["nMag"], float(seed), float(meta["spread"]), P(e), P(st), P(dl), P(mo), P(co), P(oc_), P(cnt))
+    assert rc == 0
+    assert np.array_equal(e, g["ref_elevation"]) and np.array_equal(st, g["ref_stress"])
+    assert np.array_equal(mo[:cnt[0]], g["ref_mountain"]) and np.array_equal(co[:cnt[1]], g["ref_coastline"]) and np.array_equal(oc_[:cnt[2]], g["ref_ocean"])
+    for i, layer in enumerate(meta["layers"]):
+        assert np.array_equal(dl[i * N:(i + 1) * N], g["ref_dl_" + layer]), layer
