@@ -263,6 +263,59 @@ napi_value NoiseEval(napi_env env, napi_callback_info info) {                  /
     return out;
 }
 
+// assignElevation(planet, r_plate, plates, plateSeeds, r_superPlate|null, superPlates|null, perm, pm12, noiseMag, seed, spread, wantDebug)
+// plates = { numIds, hasVec:Uint8Array, pole:Float64Array, omega:Float64Array, isOcean:Uint8Array, density:Float64Array }
+bool read_table(Args& a, napi_value obj, wo_plate_table* t) {
+    napi_env env = a.env;
+    auto get = [&](const char* k) { napi_value v; napi_get_named_property(env, obj, k, &v); return v; };
+    double n = 0; napi_get_value_double(env, get("numIds"), &n);
+    t->numIds = (int32_t)n;
+    auto arr = [&](const char* k, napi_typedarray_type want, size_t need) -> void* {
+        napi_value v = get(k); bool is = false; napi_is_typedarray(env, v, &is);
+        if (!is) { napi_throw_type_error(env, nullptr, "plate table: expected typed arrays"); a.ok = false; return nullptr; }
+        napi_typedarray_type ty; size_t len; void* data; napi_value ab; size_t off;
+        napi_get_typedarray_info(env, v, &ty, &len, &data, &ab, &off);
+        if (ty != want || len != need) { napi_throw_range_error(env, nullptr, "plate table: wrong array type or length"); a.ok = false; return nullptr; }
+        return data;
+    };
+    const size_t m = (size_t)t->numIds;
+    t->hasVec = (const uint8_t*)arr("hasVec", napi_uint8_array, m); if (!a.ok) return false;
+    t->pole = (const double*)arr("pole", napi_float64_array, 3 * m); if (!a.ok) return false;
+    t->omega = (const double*)arr("omega", napi_float64_array, m); if (!a.ok) return false;
+    t->isOcean = (const uint8_t*)arr("isOcean", napi_uint8_array, m); if (!a.ok) return false;
+    t->density = (const double*)arr("density", napi_float64_array, m); if (!a.ok) return false;
+    return true;
+}
+
+napi_value AssignElevation(napi_env env, napi_callback_info info) {
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    size_t n, ns, nsup = 0, np_, nm;
+    int32_t* r_plate = (int32_t*)a.ta(1, napi_int32_array, &n); if (!a.ok) return nullptr;
+    wo_plate_table T{}, TS{};
+    if (!read_table(a, a.argv[2], &T)) return nullptr;
+    int32_t* seeds = (int32_t*)a.ta(3, napi_int32_array, &ns); if (!a.ok) return nullptr;
+    int32_t* r_super = a.has(4) ? (int32_t*)a.ta(4, napi_int32_array, &nsup) : nullptr; if (!a.ok) return nullptr;
+    const bool hasSuper = r_super != nullptr && a.has(5);
+    if (hasSuper && !read_table(a, a.argv[5], &TS)) return nullptr;
+    if (hasSuper && nsup != n) { napi_throw_range_error(env, nullptr, "r_superPlate length mismatch"); return nullptr; }
+    uint8_t* perm = (uint8_t*)a.ta(6, napi_uint8_array, &np_); uint8_t* pm12 = (uint8_t*)a.ta(7, napi_uint8_array, &nm); if (!a.ok) return nullptr;
+    if (np_ != 512 || nm != 512) { napi_throw_range_error(env, nullptr, "noise tables must have 512 entries"); return nullptr; }
+    bool wantDebug = true; if (a.argc > 11) napi_get_value_bool(env, a.argv[11], &wantDebug);
+    void *e, *st, *dl = nullptr;
+    napi_value ea = make_ta(env, napi_float32_array, n, 4, &e), sa = make_ta(env, napi_float32_array, n, 4, &st), da = nullptr;
+    if (wantDebug) da = make_ta(env, napi_float32_array, 12 * n, 4, &dl);
+    std::vector<int32_t> mo(n), co(n), oc(n); int32_t cnt[3] = {0, 0, 0};
+    if (wo_assign_elevation(p, r_plate, &T, seeds, (int32_t)ns, hasSuper ? r_super : nullptr, hasSuper ? &TS : nullptr, perm, pm12,
+                            a.num(8), a.num(9), a.num(10), (float*)e, (float*)st, (float*)dl, mo.data(), co.data(), oc.data(), cnt))
+        return throw_wo(env, "assignElevation");
+    napi_value o; napi_create_object(env, &o);
+    set_prop(env, o, "r_elevation", ea); set_prop(env, o, "r_stress", sa);
+    if (da) set_prop(env, o, "debugLayers", da);
+    const char* names[3] = {"mountain", "coastline", "ocean"}; std::vector<int32_t>* v[3] = {&mo, &co, &oc};
+    for (int k = 0; k < 3; ++k) { void* d; napi_value t = make_ta(env, napi_int32_array, (size_t)cnt[k], 4, &d); std::memcpy(d, v[k]->data(), (size_t)cnt[k] * 4); set_prop(env, o, names[k], t); }
+    return o;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"fibSpherePoints", FibSpherePoints}, {"sphereDelaunay", SphereDelaunay}, {"meshCsr", MeshCsr}, {"neighborDist", NeighborDist},
@@ -276,7 +329,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"warpTerrainResident", WarpTerrainResident}, {"smoothElevationResident", SmoothElevationResident},
         {"erodeCompositeResident", ErodeCompositeResident}, {"sharpenRidgesResident", SharpenRidgesResident},
         {"applySoilCreepResident", ApplySoilCreepResident}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
-        {"lastStageTiming", LastStageTiming},
+        {"lastStageTiming", LastStageTiming}, {"assignElevation", AssignElevation},
     };
     for (auto& f : fns) {
         napi_value v;

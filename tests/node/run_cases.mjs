@@ -82,6 +82,25 @@ async function main() {
             result.postTiming = r.postTiming.map((t) => t.stage);
             break;
         }
+        case 'assign_elevation': {
+            const EL = await imp('elevation.js');
+            const ids = Array.from(readArr(j.plateSeeds, Int32Array));
+            const pv = readArr(j.plateVec, Float64Array), pd = readArr(j.plateDensity, Float64Array), po = readArr(j.plateIsOcean, Uint8Array);
+            const plateVec = {}, plateDensity = {}; const plateIsOcean = new Set();
+            ids.forEach((id, i) => { plateVec[id] = { pole: [pv[4 * i], pv[4 * i + 1], pv[4 * i + 2]], omega: pv[4 * i + 3] }; plateDensity[id] = pd[i]; if (po[i]) plateIsOcean.add(id); });
+            let sup = null;
+            if (j.r_superPlate) {
+                const sv = readArr(j.superPlateVec, Float64Array), sd = readArr(j.superPlateDensity, Float64Array), so = readArr(j.superPlateIsOcean, Uint8Array);
+                sup = { r_superPlate: readArr(j.r_superPlate, Int32Array), superPlateVec: {}, superPlateDensity: {}, superPlateIsOcean: new Set() };
+                for (let s2 = 0; s2 < sd.length; s2++) { sup.superPlateVec[s2] = { pole: [sv[4 * s2], sv[4 * s2 + 1], sv[4 * s2 + 2]], omega: sv[4 * s2 + 3] }; sup.superPlateDensity[s2] = sd[s2]; if (so[s2]) sup.superPlateIsOcean.add(s2); }
+            }
+            const r = EL.assignElevation(mesh, xyz, plateIsOcean, readArr(j.r_plate, Int32Array), plateVec, new Set(ids), new SN.SimplexNoise(j.seed), j.nMag, j.seed, j.spread, plateDensity, sup);
+            writeArr(j.out + '.elev', r.r_elevation); writeArr(j.out + '.stress', r.r_stress); writeArr(j.out + '.hotspot', r.debugLayers.hotspot);
+            writeArr(j.out + '.mountain', Int32Array.from(r.mountain_r)); writeArr(j.out + '.coastline', Int32Array.from(r.coastline_r)); writeArr(j.out + '.ocean', Int32Array.from(r.ocean_r));
+            result.elevTiming = r._timing.map((t) => t.stage);
+            result.elevKeys = Object.keys(r).sort(); result.layerKeys = Object.keys(r.debugLayers).sort();
+            break;
+        }
         case 'error_paths': {
             const errs = [];
             const e = readArr(j.elevation, Float32Array), oc = readArr(j.isOcean, Uint8Array);

@@ -91,3 +91,27 @@ def test_js_drop_in_matches_goldens(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "pipe.bin", np.float32), e)
     assert np.array_equal(np.fromfile(tmp_path / "pipe.bin.delta", np.float32), delta)
     pl.close()
+
+
+@pytest.mark.gpu
+def test_js_assign_elevation(tmp_path):
+    import json as _json
+    g = load_golden("elev_config1_N10000_s1")
+    meta = _json.loads(bytes(g["meta_json"]).decode())
+    for k in ("triangles", "halfedges", "xyz", "neighborDist", "r_plate", "plateSeeds", "plateVec", "plateDensity", "plateIsOcean", "r_superPlate",
+              "superPlateVec", "superPlateDensity", "superPlateIsOcean"):
+        np.ascontiguousarray(g[k]).tofile(tmp_path / f"{k}.bin")
+    jobs = [{"op": "load_mesh", "tri": "triangles.bin", "he": "halfedges.bin", "xyz": "xyz.bin", "nd": "neighborDist.bin", "numRegions": meta["numRegions"]},
+            {"op": "assign_elevation", "r_plate": "r_plate.bin", "plateSeeds": "plateSeeds.bin", "plateVec": "plateVec.bin", "plateDensity": "plateDensity.bin",
+             "plateIsOcean": "plateIsOcean.bin", "r_superPlate": "r_superPlate.bin", "superPlateVec": "superPlateVec.bin",
+             "superPlateDensity": "superPlateDensity.bin", "superPlateIsOcean": "superPlateIsOcean.bin", "seed": meta["seed"], "nMag": meta["nMag"],
+             "spread": meta["spread"], "out": "ae"}]
+    res = run_node(tmp_path, jobs)
+    e = np.fromfile(tmp_path / "ae.elev", np.float32)
+    d = e.astype(np.float64) - g["ref_elevation"].astype(np.float64)
+    assert float(np.sqrt((d * d).mean())) < 1e-5
+    assert np.array_equal(np.fromfile(tmp_path / "ae.mountain", np.int32), g["ref_mountain"])
+    assert np.array_equal(np.fromfile(tmp_path / "ae.coastline", np.int32), g["ref_coastline"])
+    assert np.array_equal(np.fromfile(tmp_path / "ae.ocean", np.int32), g["ref_ocean"])
+    assert res["elevKeys"] == sorted(["r_elevation", "mountain_r", "coastline_r", "ocean_r", "r_stress", "debugLayers", "_timing"])
+    assert "superPlates" in res["layerKeys"] and len(res["layerKeys"]) == 13
