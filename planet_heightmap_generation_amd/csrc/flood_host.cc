@@ -177,8 +177,25 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     }
     lap("init+seeds");
     // --- pass 1 (:131-147)
+    const FloodHeapItem* hp = S.heapStore.data();
     while (heap.n > 0) {
         const int32_t c = heap.pop();
+        hp = S.heapStore.data();
+        // The cells that pop next sit in the first heap levels: start pulling their rows in now (the flood visits
+        // cells in key order, i.e. scattered over the globe, so every pop would otherwise start with cold misses).
+        {
+            const size_t lim2 = heap.n < 7 ? heap.n : 7;
+            for (size_t q = 0; q < lim2; ++q) {
+                const int32_t cc = hp[q].cell;
+                __builtin_prefetch(&off[cc]); __builtin_prefetch(&st[cc]); __builtin_prefetch(&surface[cc]); __builtin_prefetch(&root[cc]);
+            }
+            if (heap.n > 0) {          // the very next pop: its row was requested while it sat deeper; now request its neighbours' state
+                const int32_t c0 = hp[0].cell;
+                const int32_t o0 = off[c0], o1 = off[c0 + 1];
+                for (int32_t j = o0; j < o1; ++j) __builtin_prefetch(&st[adj[j]]);
+            }
+            for (size_t q = 1; q < lim2 && q < 3; ++q) __builtin_prefetch(&adj[off[hp[q].cell]]);
+        }
         const double lim = (double)surface[c] + EPS;
         const int32_t iEnd = off[c + 1];
         const int32_t rootC = root[c];

@@ -182,6 +182,66 @@ __global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_
         block_append(pending, r, out, outCount);
     }
 }
+// The tail of the solve DAG: once only river main stems are left (a few hundred tasks per round for hundreds of
+// rounds) a kernel launch per round is all latency.  One 1024-thread workgroup then runs the remaining rounds
+// itself: same tasks, same "consume only earlier rounds" rule, but a round boundary is a __syncthreads()
+// (workgroup-scope visibility of the granules written through to L2) instead of a kernel boundary.
+// Pending lists live in LDS.  stats[0] = last round run, stats[1] = 1 if the LDS lists overflowed (the host then
+// rebuilds the pending list from the round tags and goes back to one launch per round).
+constexpr int WO_TAIL_THREADS = 1024;
+constexpr int WO_TAIL_CAP = 14336;          // 2 lists x 56 KiB of the CU's 160 KiB LDS
+__global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const int32_t* leftIn, const int32_t* leftCountPtr,
+                                                                 const int32_t* byLevel, const int32_t* levelStart, int32_t firstRound,
+                                                                 int32_t maxPred, int32_t lookahead, int32_t maxLevel, int32_t maxRounds,
+                                                                 int32_t* stats, double K, double m, double dt) {
+    __shared__ int32_t s_list[2][WO_TAIL_CAP];
+    __shared__ int32_t s_cnt[2];
+    __shared__ int32_t s_overflow;
+    const int tid = threadIdx.x;
+    const int32_t n0 = *leftCountPtr;
+    if (n0 > WO_TAIL_CAP) { if (tid == 0) { stats[0] = firstRound - 1; stats[1] = 1; } return; }
+    for (int32_t i = tid; i < n0; i += WO_TAIL_THREADS) s_list[0][i] = leftIn[i];
+    if (tid == 0) { s_cnt[0] = n0; s_cnt[1] = 0; s_overflow = 0; }
+    __syncthreads();
+    int cur = 0;
+    int32_t k = firstRound;
+    for (;; ++k) {
+        const int32_t nl = s_cnt[cur];
+        const int32_t loL = (k == 1) ? 1 : min(k + lookahead, maxLevel + 1);
+        const int32_t hiL = min(k + lookahead, maxLevel);
+        const int32_t b0 = (hiL >= loL) ? levelStart[loL] : 0;
+        const int32_t bc = (hiL >= loL) ? levelStart[hiL + 1] - b0 : 0;
+        const int32_t n = nl + bc;
+        for (int32_t i = tid; i < n; i += WO_TAIL_THREADS) {
+            const int32_t r = (i < nl) ? s_list[cur][i] : byLevel[b0 + (i - nl)];
+            if (!solve_task(F, r, k, K, m, dt)) {
+                const int32_t pos = atomicAdd(&s_cnt[cur ^ 1], 1);
+                if (pos < WO_TAIL_CAP) s_list[cur ^ 1][pos] = r; else s_overflow = 1;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int32_t nextCount = s_cnt[cur ^ 1];
+        const bool over = s_overflow != 0;
+        __syncthreads();
+        if (tid == 0) s_cnt[cur] = 0;
+        cur ^= 1;
+        if (over) { if (tid == 0) { stats[0] = k; stats[1] = 1; } return; }
+        if ((k + lookahead >= maxPred && nextCount == 0) || k >= maxRounds) break;
+        __syncthreads();
+    }
+    if (tid == 0) { stats[0] = k; stats[1] = (s_cnt[cur] != 0) ? 2 : 0; }
+}
+
+// pending = land tasks whose round tag is still 0 (recovery after a tail overflow)
+__global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const int32_t* landIdx, int32_t L, int32_t* out, int32_t* outCount) {
+    WO_BLOCK_STRIDE(i, valid, L) {
+        bool pend = false; int32_t r = -1;
+        if (valid) { r = landIdx[i]; pend = F.out[r].self.tag == 0; }
+        block_append(pend, r, out, outCount);
+    }
+}
+
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level) {
     WO_GRID_STRIDE(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[r].self.tag; }
 }

@@ -23,7 +23,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "elev_collisions", "elev_uplift_fused", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "elev_collisions", "elev_uplift_fused", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -145,19 +145,24 @@ static int64_t run_rounds(wo_planet* p, const int32_t* firstList, int32_t firstC
 // that respects the dependencies produces the same bits (the dataflow is single-assignment), so a wrong
 // prediction only costs re-examinations.
 constexpr int WO_LOOKAHEAD = 3;
-static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double m, double dt, int64_t* examined) {
+static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double m, double dt, int64_t* examined, int64_t* tailRounds) {
     sort_by_level(p);
     const int32_t* ls = p->h_levelStart;
     int32_t maxPred = 1;
     for (int32_t l = 1; l <= WO_MAX_LEVEL; ++l) if (ls[l + 1] > ls[l]) maxPred = l;
+    // largest predicted bucket at or above each level: decides when the single-workgroup tail can take over
+    static thread_local std::vector<int32_t> sufMax;
+    sufMax.assign(WO_MAX_LEVEL + 3, 0);
+    for (int32_t l = WO_MAX_LEVEL; l >= 1; --l) sufMax[l] = std::max(sufMax[l + 1], ls[l + 1] - ls[l]);
     int32_t* c = p->d_counters;
     hipStream_t s = p->ctx->stream;
     hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
-    const int batch = 32;
+    const int batch = 16;
     int64_t k = 1;
     int32_t leftKnown = 0;
     const int32_t* in = p->d_listB;
     int32_t* out = p->d_listA;
+    const bool tailEnabled = std::getenv("WO_NO_SOLVE_TAIL") == nullptr;
     for (;;) {
         for (int b = 0; b < batch; ++b, ++k) {
             // tasks enter WO_LOOKAHEAD rounds ahead of their predicted level: a few cheap re-examinations buy
@@ -177,6 +182,39 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
         if (examined) *examined += (int64_t)leftKnown * batch;       // rough: leftovers are re-examined every round
         if (k + WO_LOOKAHEAD > maxPred && leftKnown == 0) break;
         if (k > 4 * (int64_t)p->N + 1024) throw HipError{"solve rounds do not converge"};
+        // hand the tail to one workgroup when what is left is thin: few leftovers and only small buckets ahead
+        const int64_t nextLevel = std::min<int64_t>(k + WO_LOOKAHEAD, WO_MAX_LEVEL + 1);
+        if (tailEnabled && leftKnown <= WO_TAIL_CAP / 4 && sufMax[nextLevel] <= WO_TAIL_CAP / 8) {
+            int32_t* stats = c + 4;
+            WO_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), s));
+            launch(p, FAM_SOLVE_TAIL, k_solve_tail, 1, WO_TAIL_THREADS, F, in, (const int32_t*)(c + (k % 3)), (const int32_t*)p->d_byLevel,
+                   (const int32_t*)p->d_levelStart, (int32_t)k, maxPred, (int32_t)WO_LOOKAHEAD, (int32_t)WO_MAX_LEVEL,
+                   (int32_t)std::min<int64_t>(k + 65536, 2000000000), stats, K, m, dt);
+            WO_HIP(hipMemcpyAsync(p->h_count, stats, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            WO_HIP(hipStreamSynchronize(s));
+            const int32_t lastRound = p->h_count[0], flag = p->h_count[1];
+            if (tailRounds) *tailRounds += std::max<int64_t>(0, lastRound - (k - 1));
+            if (flag == 0) { k = (int64_t)lastRound + 1; break; }
+            // overflow (or round cap): rebuild the pending list from the round tags and continue one launch per round;
+            // every still-pending task is re-listed, so the predicted buckets are not used again in this pass
+            k = (int64_t)lastRound + 1;
+            WO_HIP(hipMemsetAsync(c, 0, 3 * sizeof(int32_t), s));
+            launch(p, FAM_MISC, k_collect_pending, blocks_for(p->L, 2048), WO_BLOCK, F, (const int32_t*)p->d_landIdx, p->L, p->d_listA, c + (k % 3));
+            in = p->d_listA; out = p->d_listB;
+            leftKnown = read_count(p, c + (k % 3));
+            for (;;) {
+                if (leftKnown == 0) break;
+                for (int b = 0; b < batch; ++b, ++k) {
+                    launch(p, FAM_SOLVE_ROUND, k_solve_round, blocks_for(2 * (int64_t)leftKnown + 1024, 2048), WO_BLOCK, F, in,
+                           (const int32_t*)(c + (k % 3)), (const int32_t*)p->d_byLevel, 0, out, c + ((k + 1) % 3), c + ((k + 2) % 3), (int32_t)k, K, m, dt);
+                    in = out;
+                    out = (out == p->d_listA) ? p->d_listB : p->d_listA;
+                }
+                leftKnown = read_count(p, c + (k % 3));
+                if (k > 4 * (int64_t)p->N + 1024) throw HipError{"solve rounds do not converge"};
+            }
+            break;
+        }
     }
     return k - 1;
 }
@@ -228,7 +266,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t N = p->N;
     const int gridN = blocks_for(N);
     StageClock clk(p);
-    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0;
+    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0;
     double floodHostMs = 0;
 
     clk.begin("setup");
@@ -311,7 +349,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.begin("solve");
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridN, WO_BLOCK, F);
             {
-                const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined);
+                const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
             }
             launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2, p->d_level);
@@ -337,7 +375,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     clk.finish();
     p->erodeStats = {{"land_cells", (double)L}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
-                     {"solve_tasks_examined_est", (double)solveExamined},
+                     {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
                      {"carve_rounds_total", (double)carveRounds}, {"flood_host_ms", floodHostMs}};
 }
