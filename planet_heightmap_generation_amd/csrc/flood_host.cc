@@ -4,22 +4,30 @@
 // order that is defined by a binary heap over float keys (ties included), pass 2 carves along drain paths
 // sequentially in ascending cell order reading already-carved heights, and SURVEY §6.4 measured that
 // relaxing either changes the result by ~1e-2 RMS.  A serial walk on one GPU lane would take seconds per
-// call, so the two calls per erodeComposite run here on one host core between device phases (the field
-// makes one D2H + H2D round trip per call).  DESIGN.md lists an order-equivalent device flood as the next step.
+// call, so the two calls per erodeComposite run here between device phases (the field makes one D2H + H2D
+// round trip per call).  DESIGN.md lists an order-equivalent device flood as the next step.
+// This is product code (it is the designed path, not a fallback, and it does not touch oracle/).
 //
-// This is product code (it is the designed path, it is not a fallback and it does not touch oracle/).
-#include <cmath>
-#include <cstdint>
-#include <cstring>
-#include <vector>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-
+// Layout (all results identical to the reference; only *where* data sits changes):
+//  * land cells are renumbered compactly in Morton order of their positions, with their own CSR (ocean
+//    neighbours dropped: the reference skips them as "visited" without side effects).  The flood pops cells in
+//    key order, i.e. scattered over the globe; with 10^7 cells every pop used to touch ~6 cold cache lines in
+//    40-240 MB arrays.  In the compact Morton layout a cell, its row and its neighbours' state share a few lines
+//    in arrays 4x smaller.  Orders the reference defines by cell id (seed order, pass-2 order, pass-3 tie
+//    order, the noise hash) still use the original ids.
+//  * pass 1 is serial (heap order); the rows of the next few heap entries are prefetched.
+//  * passes 2 and 3 are separable per drainage tree (every path, carve window and drain target lies inside
+//    one tree), so trees run on a few host cores while each tree keeps the reference's order.
 #include <algorithm>
 #include <atomic>
-#include <numeric>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <thread>
+#include <vector>
 
 #include "host_util.h"
 #include "wo_internal.h"
@@ -40,10 +48,9 @@ inline double cell_noise(int32_t r) {
 }
 
 // Binary min-heap of (key, cell) pairs with the reference's exact sift rules (js/terrain-post.js:18-46):
-// sift-up stops on >=, sift-down prefers the left child unless the right is strictly smaller.  The reference
-// keys the heap through an external Float32Array; every cell is pushed exactly once and its key never changes
-// afterwards, so carrying the key next to the cell id compares the same values while keeping the sifts inside
-// one small contiguous array (the external-array form costs a cache miss per comparison at 10^7 cells).
+// sift-up stops on >=, sift-down compares left with the moving item, then right with the smaller of the two.
+// The reference keys the heap through an external Float32Array; every cell is pushed exactly once and its key
+// never changes afterwards, so carrying the key next to the cell compares the same values.
 using HeapItem = FloodHeapItem;
 struct KeyHeap {
     std::vector<HeapItem>& d;
@@ -61,9 +68,7 @@ struct KeyHeap {
         }
         h[i] = HeapItem{kc, c};
     }
-    // Same comparisons as js/terrain-post.js:36-42 (left vs current, then right vs the smaller of the two),
-    // evaluated with selects instead of branches; slots n and n+1 hold +inf sentinels so absent children lose.
-    int32_t pop() {
+    int32_t pop() {      // selects instead of branches; slots n, n+1 hold +inf so absent children lose
         HeapItem* h = d.data();
         const int32_t top = h[0].cell;
         const HeapItem last = h[--n];
@@ -95,19 +100,37 @@ inline uint32_t asc_bits(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-}  // namespace
-
-void FloodScratch::ensure(int32_t N) {
-    if ((int32_t)surface.size() >= N) return;
-    surface.resize(N); drainTo.resize(N); visited.resize(N); path.resize(N); order.resize(N); order2.resize(N);
-    bits.resize(N); bits2.resize(N);
-    staticValid = false;
+inline uint32_t spread3(uint32_t v) {           // 10 bits -> every third bit
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
 }
 
-// Everything that depends only on (mesh, r_isOcean): the open-ocean mask (largest ocean component, first
-// wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose first open-ocean neighbour in
-// adjacency order exists, ascending r, :118-128).  Both flood calls of an erodeComposite share it.
-static void build_static(int32_t N, const int32_t* off, const int32_t* adj, const uint8_t* ocean, FloodScratch& S) {
+void radix_sort_u32(std::vector<uint32_t>& keys, std::vector<int32_t>& vals) {     // stable LSD, 11/11/10 bits
+    const size_t n = keys.size();
+    std::vector<uint32_t> k2(n); std::vector<int32_t> v2(n);
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = pass * 11; const uint32_t mask = pass == 2 ? 1023u : 2047u;
+        uint32_t cnt[2049]; std::memset(cnt, 0, sizeof(cnt));
+        for (size_t i = 0; i < n; ++i) cnt[((keys[i] >> sh) & mask) + 1]++;
+        for (int i = 0; i < 2048; ++i) cnt[i + 1] += cnt[i];
+        for (size_t i = 0; i < n; ++i) { const uint32_t d = cnt[(keys[i] >> sh) & mask]++; k2[d] = keys[i]; v2[d] = vals[i]; }
+        keys.swap(k2); vals.swap(v2);
+    }
+}
+
+constexpr int32_t UNVISITED = -2, TO_OCEAN = -3, NO_TARGET = -1;
+
+}  // namespace
+
+// Everything that depends only on (mesh, positions, r_isOcean): Morton order, compact land numbering and CSR, the
+// open-ocean component (largest, first wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose
+// first open-ocean neighbour in adjacency order exists, ascending r, :118-128).  Shared by both flood calls of
+// an erodeComposite and kept across calls while the ocean mask is unchanged.
+static void build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S) {
     std::vector<int32_t> label(N, -1), stack(N);
     std::vector<int32_t> sizes;
     for (int32_t r = 0; r < N; ++r) {
@@ -127,18 +150,55 @@ static void build_static(int32_t N, const int32_t* off, const int32_t* adj, cons
     }
     int32_t mainLab = 0;
     for (size_t i = 1; i < sizes.size(); ++i) if (sizes[i] > sizes[mainLab]) mainLab = (int32_t)i;
-    S.seedCell.clear(); S.seedTarget.clear();
+    // land cells in Morton order of their positions (identity order when no positions are given)
+    std::vector<int32_t> landCells;
+    for (int32_t r = 0; r < N; ++r) if (!ocean[r]) landCells.push_back(r);
+    const int32_t L = (int32_t)landCells.size();
+    if (xyz && L > 1) {
+        std::vector<uint32_t> keys(L);
+        parallel_ranges(L, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i) {
+                const int32_t r = landCells[i];
+                auto q = [](float v) { int32_t t = (int32_t)((v + 1.0f) * 511.5f); return (uint32_t)(t < 0 ? 0 : (t > 1023 ? 1023 : t)); };
+                keys[i] = spread3(q(xyz[3 * r])) | (spread3(q(xyz[3 * r + 1])) << 1) | (spread3(q(xyz[3 * r + 2])) << 2);
+            }
+        });
+        radix_sort_u32(keys, landCells);
+    }
+    S.L = L;
+    S.landCell.swap(landCells);
+    S.landIndex.assign(N, -1);
+    for (int32_t i = 0; i < L; ++i) S.landIndex[S.landCell[i]] = i;
+    S.offL.assign(L + 1, 0);
+    for (int32_t i = 0; i < L; ++i) {
+        const int32_t r = S.landCell[i];
+        int32_t c = 0;
+        for (int32_t j = off[r]; j < off[r + 1]; ++j) if (!ocean[adj[j]]) ++c;
+        S.offL[i + 1] = c;
+    }
+    for (int32_t i = 0; i < L; ++i) S.offL[i + 1] += S.offL[i];
+    S.adjL.resize(S.offL[L]);
+    parallel_ranges(L, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t r = S.landCell[i];
+            int32_t o = S.offL[i];
+            for (int32_t j = off[r]; j < off[r + 1]; ++j) { const int32_t nb = adj[j]; if (!ocean[nb]) S.adjL[o++] = S.landIndex[nb]; }
+        }
+    });
+    S.seedCell.clear();                     // land index of each seed, in ascending original id
     for (int32_t r = 0; r < N; ++r) {
         if (ocean[r]) continue;
-        for (int32_t i = off[r]; i < off[r + 1]; ++i) {
-            const int32_t nb = adj[i];
-            if (ocean[nb] && label[nb] == mainLab) { S.seedCell.push_back(r); S.seedTarget.push_back(nb); break; }
+        for (int32_t j = off[r]; j < off[r + 1]; ++j) {
+            const int32_t nb = adj[j];
+            if (ocean[nb] && label[nb] == mainLab) { S.seedCell.push_back(S.landIndex[r]); break; }
         }
     }
+    S.surface.resize(L); S.state.resize(L); S.root.resize(L); S.eL.resize(L);
+    S.order.resize(L); S.order2.resize(L); S.bits.resize(L); S.bits2.resize(L); S.list2.resize(L);
     S.staticValid = true;
 }
 
-void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, float* e,
+void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S) {
     const double EPS = 1e-7;
     const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
@@ -149,58 +209,53 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         std::fprintf(stderr, "[flood] %-10s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
         tp = now;
     };
-    S.ensure(N);
-    if (!S.staticValid) build_static(N, off, adj, ocean, S);
+    if (!S.staticValid || S.staticN != N) { build_static(N, off, adj, xyz, ocean, S); S.staticN = N; }
     lap("static");
-
-    // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed.  The flood's
-    // per-neighbour state (elevation, visited flag, drain target) is packed in one 8-byte record so that
-    // visiting a neighbour costs one cache line, not three: drain == UNVISITED / OCEAN / NO_TARGET(-1) / cell id.
+    const int32_t L = S.L;
+    if (L == 0) return;
+    const int32_t* landCell = S.landCell.data();
+    const int32_t* landIndex = S.landIndex.data();
+    const int32_t* offL = S.offL.data();
+    const int32_t* adjL = S.adjL.data();
+    float* eL = S.eL.data();
     float* surface = S.surface.data();
-    int32_t* drainTo = S.drainTo.data();
-    constexpr int32_t UNVISITED = -2, OCEAN = -3;
-    if ((int32_t)S.state.size() < N) S.state.resize(N);
     FloodCell* st = S.state.data();
-    if ((int32_t)S.root.size() < N) S.root.resize(N);
-    int32_t* root = S.root.data();          // drainage tree id (= ordinal of the seed the cell finally drains through), -1 for none
-    parallel_ranges(N, [&](int64_t b, int64_t en, int) {
-        for (int64_t r = b; r < en; ++r) { st[r].e = e[r]; st[r].drain = ocean[r] ? OCEAN : UNVISITED; root[r] = -1; }
+    int32_t* root = S.root.data();        // drainage tree id (= ordinal of the seed the cell drains through), -1 for none
+
+    // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; surface[i] = v; st[i].e = v; st[i].drain = UNVISITED; root[i] = -1; }
     });
-    std::memcpy(surface, e, sizeof(float) * (size_t)N);
     if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
     KeyHeap heap(S.heapStore);
-    for (size_t i = 0; i < S.seedCell.size(); ++i) {        // :118-128, ascending r
-        const int32_t r = S.seedCell[i];
-        st[r].drain = S.seedTarget[i];
-        root[r] = (int32_t)i;
-        heap.push(r, (float)((double)e[r] + cell_noise(r)));
+    for (size_t s = 0; s < S.seedCell.size(); ++s) {        // :118-128, ascending r
+        const int32_t i = S.seedCell[s];
+        st[i].drain = TO_OCEAN;
+        root[i] = (int32_t)s;
+        heap.push(i, (float)((double)eL[i] + cell_noise(landCell[i])));
     }
     lap("init+seeds");
     // --- pass 1 (:131-147)
-    const FloodHeapItem* hp = S.heapStore.data();
     while (heap.n > 0) {
         const int32_t c = heap.pop();
-        hp = S.heapStore.data();
-        // The cells that pop next sit in the first heap levels: start pulling their rows in now (the flood visits
-        // cells in key order, i.e. scattered over the globe, so every pop would otherwise start with cold misses).
-        {
+        {   // the cells that pop next sit in the first heap levels: start pulling their rows in now
+            const FloodHeapItem* hp = S.heapStore.data();
             const size_t lim2 = heap.n < 7 ? heap.n : 7;
             for (size_t q = 0; q < lim2; ++q) {
                 const int32_t cc = hp[q].cell;
-                __builtin_prefetch(&off[cc]); __builtin_prefetch(&st[cc]); __builtin_prefetch(&surface[cc]); __builtin_prefetch(&root[cc]);
+                __builtin_prefetch(&offL[cc]); __builtin_prefetch(&st[cc]); __builtin_prefetch(&surface[cc]); __builtin_prefetch(&root[cc]);
             }
-            if (heap.n > 0) {          // the very next pop: its row was requested while it sat deeper; now request its neighbours' state
+            if (heap.n > 0) {
                 const int32_t c0 = hp[0].cell;
-                const int32_t o0 = off[c0], o1 = off[c0 + 1];
-                for (int32_t j = o0; j < o1; ++j) __builtin_prefetch(&st[adj[j]]);
+                for (int32_t j = offL[c0]; j < offL[c0 + 1]; ++j) __builtin_prefetch(&st[adjL[j]]);
             }
-            for (size_t q = 1; q < lim2 && q < 3; ++q) __builtin_prefetch(&adj[off[hp[q].cell]]);
+            for (size_t q = 1; q < lim2 && q < 3; ++q) __builtin_prefetch(&adjL[offL[hp[q].cell]]);
         }
         const double lim = (double)surface[c] + EPS;
-        const int32_t iEnd = off[c + 1];
+        const int32_t iEnd = offL[c + 1];
         const int32_t rootC = root[c];
-        for (int32_t i = off[c]; i < iEnd; ++i) {
-            const int32_t nb = adj[i];
+        for (int32_t i = offL[c]; i < iEnd; ++i) {
+            const int32_t nb = adjL[i];
             FloodCell& sn = st[nb];
             if (sn.drain != UNVISITED) continue;
             sn.drain = c;
@@ -208,91 +263,73 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             float k;
             if ((double)sn.e < lim) {
                 surface[nb] = (float)lim;
-                k = (float)((double)surface[nb] + cell_noise(nb));
+                k = (float)((double)surface[nb] + cell_noise(landCell[nb]));
             } else {
-                k = (float)((double)sn.e + cell_noise(nb));
+                k = (float)((double)sn.e + cell_noise(landCell[nb]));
             }
             heap.push(nb, k);
         }
     }
-    // unreachable land (enclosed by inland seas) keeps drainTo = -1 (:108)
-    parallel_ranges(N, [&](int64_t b, int64_t en, int) {
-        for (int64_t r = b; r < en; ++r) { const int32_t d = st[r].drain; drainTo[r] = d >= 0 ? d : -1; }
-    });
     lap("pass1");
     // --- pass 2 (:152-196) and pass 3 (:200-214).  Both are sequential in the reference, but every cell a turn
     // reads or writes (the drain path of r, the carve window on it, r itself; in pass 3 the cell and its
-    // drain target) lies inside r's drainage tree, and trees share no land cell.  So the trees are processed
-    // concurrently on the host's cores while each tree keeps the reference's order (ascending r in pass 2,
-    // ascending (surface, r) in pass 3): identical results, no relaxation.
+    // drain target) lies inside r's drainage tree, and trees share no land cell.  So trees are processed
+    // concurrently while each tree keeps the reference's order (ascending r in pass 2, ascending (surface, r)
+    // in pass 3): identical results, no relaxation.
     const int32_t nTrees = (int32_t)S.seedCell.size();
     std::vector<int32_t> cnt2(nTrees + 1, 0);
-    // all cells of each tree, ascending r inside.  (Not just the cells with an initial deficit: a carve lowers
-    // other cells of the path below their flood surface, and the reference tests `deficit > EPS` against the
-    // current height when it reaches them, :154-155.)
-    int32_t* list2 = S.order.data();
+    // all cells of each tree, ascending ORIGINAL id inside.  (Not just the cells with an initial deficit: a carve
+    // lowers other cells of the path below their flood surface, and the reference tests `deficit > EPS` against
+    // the current height when it reaches them, :154-155.)
+    int32_t* list2 = S.list2.data();
     {
-        for (int32_t r = 0; r < N; ++r) if (root[r] >= 0) cnt2[root[r] + 1]++;
+        for (int32_t i = 0; i < L; ++i) if (root[i] >= 0) cnt2[root[i] + 1]++;
         for (int32_t t = 0; t < nTrees; ++t) cnt2[t + 1] += cnt2[t];
         std::vector<int32_t> fill(cnt2.begin(), cnt2.end() - 1);
-        for (int32_t r = 0; r < N; ++r) if (root[r] >= 0) list2[fill[root[r]]++] = r;
+        for (int32_t r = 0; r < N; ++r) { const int32_t i = landIndex[r]; if (i >= 0 && root[i] >= 0) list2[fill[root[i]]++] = i; }
     }
-    // Trees are numbered by their seed's cell id, i.e. along the Fibonacci spiral: consecutive tree ids are
-    // spatial neighbours.  Workers take contiguous chunks of tree ids so that each core works inside its own
-    // band of the elevation array (random hand-out makes cores fight over shared cache lines and erases the gain).
+    // Trees are numbered by their seed's original id, i.e. along the Fibonacci spiral: consecutive ids are spatial
+    // neighbours, so workers take contiguous chunks.  Measured on the 2-socket EPYC GPU box: 4-8 workers give ~3x
+    // on these pointer-chasing passes; 16+ cores contend in the memory system and per-tree time rises 7x.
     auto for_trees = [&](const std::vector<int32_t>& cnt, auto body) {
-        // measured on the 2-socket EPYC GPU box: 4-8 workers give ~3x on these pointer-chasing passes; 16+ cores
-        // contend in the memory system (cross-CCD/NUMA coherence on the written field) and per-tree time rises 7x
         const int nt = std::max(1, std::min<int>(std::min(host_threads(), 6), nTrees));
         const int64_t total = cnt[nTrees];
         const int64_t perChunk = std::max<int64_t>(2048, total / (nt * 16));
-        std::vector<int32_t> chunkStart;            // chunk boundaries with ~equal cell counts
+        std::vector<int32_t> chunkStart;
         chunkStart.push_back(0);
         for (int32_t t = 0, last = 0; t < nTrees; ++t)
             if (cnt[t + 1] - cnt[last] >= perChunk) { chunkStart.push_back(t + 1); last = t + 1; }
         if (chunkStart.back() != nTrees) chunkStart.push_back(nTrees);
         const size_t nChunks = chunkStart.size() - 1;
         std::atomic<size_t> next{0};
-        std::atomic<int64_t> busyUs{0}, maxTreeUs{0};
         auto worker = [&]() {
-            int64_t myBusy = 0, myMax = 0;
             for (;;) {
                 const size_t c = next.fetch_add(1);
                 if (c >= nChunks) break;
-                for (int32_t t = chunkStart[c]; t < chunkStart[c + 1]; ++t) if (cnt[t + 1] > cnt[t]) {
-                    if (timing) {
-                        auto t0 = std::chrono::steady_clock::now();
-                        body(t);
-                        const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
-                        myBusy += us; if (us > myMax) myMax = us;
-                    } else body(t);
-                }
+                for (int32_t t = chunkStart[c]; t < chunkStart[c + 1]; ++t) if (cnt[t + 1] > cnt[t]) body(t);
             }
-            if (timing) { busyUs += myBusy; int64_t prev = maxTreeUs.load(); while (myMax > prev && !maxTreeUs.compare_exchange_weak(prev, myMax)) {} }
         };
         if (nt == 1) { worker(); return; }
         std::vector<std::thread> th;
         for (int i = 0; i < nt; ++i) th.emplace_back(worker);
         for (auto& t : th) t.join();
-        if (timing) std::fprintf(stderr, "[flood]   %d threads, %zu chunks: summed busy %.1f ms, slowest single tree %.1f ms\n", nt, nChunks, busyUs.load() / 1e3, maxTreeUs.load() / 1e3);
     };
-    std::atomic<int64_t> nDef{0}, totLen{0}, maxTreeLen{0};
     lap("group2");
+    std::atomic<int64_t> nDef{0}, totLen{0};
     for_trees(cnt2, [&](int32_t tree) {
         std::vector<int32_t> path;
-        int64_t myLen = 0;
+        int64_t myLen = 0, myDef = 0;
         for (int32_t q = cnt2[tree]; q < cnt2[tree + 1]; ++q) {
             const int32_t r = list2[q];
-            // the deficit is taken against the CURRENT (already carved) height, as in the reference (:154)
-            const double deficit = (double)surface[r] - (double)e[r];
+            const double deficit = (double)surface[r] - (double)eL[r];      // against the CURRENT height (:154)
             if (deficit <= EPS) continue;
-            if (timing) ++nDef;
+            ++myDef;
             path.clear();
             int32_t peakIdx = -1;
             double peakElev = -INFINITY;
-            for (int32_t cur = r; cur >= 0 && !ocean[cur]; cur = drainTo[cur]) {
+            for (int32_t cur = r; cur >= 0; cur = st[cur].drain) {
                 path.push_back(cur);
-                if ((double)e[cur] > peakElev) { peakElev = e[cur]; peakIdx = (int32_t)path.size() - 1; }
+                if ((double)eL[cur] > peakElev) { peakElev = eL[cur]; peakIdx = (int32_t)path.size() - 1; }
             }
             const int32_t len = (int32_t)path.size();
             myLen += len;
@@ -307,25 +344,24 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             if (kernelSum > 0) {
                 for (int32_t k = k0; k <= k1; ++k) {
                     const double w = (1 - std::fabs((double)(k - peakIdx)) / (radius + 1)) / kernelSum;
-                    float v = (float)((double)e[path[k]] - carveAmount * w);
+                    float v = (float)((double)eL[path[k]] - carveAmount * w);
                     if (v < 0) v = 0;
-                    e[path[k]] = v;
+                    eL[path[k]] = v;
                 }
             }
-            e[r] = (float)((double)e[r] + deficit * (1 - carveStrength));
+            eL[r] = (float)((double)eL[r] + deficit * (1 - carveStrength));
         }
-        if (timing) { totLen += myLen; int64_t prev = maxTreeLen.load(); while (myLen > prev && !maxTreeLen.compare_exchange_weak(prev, myLen)) {} }
+        if (timing) { totLen += myLen; nDef += myDef; }
     });
     if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
-    if (timing) std::fprintf(stderr, "[flood] pass2: largest tree walks %lld path steps\n", (long long)maxTreeLen.load());
     lap("pass2");
-    // --- pass 3: land cells by ascending surface (stable => ties ascending r), then grouped by tree
+    // --- pass 3: land cells by ascending surface (stable => ties ascending original id), then grouped by tree
     int32_t nLand = 0;
     int32_t* order = S.order.data();
     int32_t* order2 = S.order2.data();
     uint32_t* b0 = S.bits.data();
     uint32_t* b1 = S.bits2.data();
-    for (int32_t r = 0; r < N; ++r) if (root[r] >= 0) { order[nLand] = r; b0[nLand] = asc_bits(surface[r]); ++nLand; }
+    for (int32_t r = 0; r < N; ++r) { const int32_t i = landIndex[r]; if (i >= 0 && root[i] >= 0) { order[nLand] = i; b0[nLand] = asc_bits(surface[i]); ++nLand; } }
     for (int pass = 0; pass < 3; ++pass) {          // 11 + 11 + 10 bit LSD radix, stable
         const int sh = pass * 11;
         const uint32_t mask = pass == 2 ? 1023u : 2047u;
@@ -348,12 +384,13 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     }
     for_trees(cnt3, [&](int32_t tree) {
         for (int32_t q = cnt3[tree]; q < cnt3[tree + 1]; ++q) {
-            const int32_t c = order2[q], t = drainTo[c];
-            if (t < 0) continue;
-            const double te = ocean[t] ? 0.0 : (double)e[t];
-            if ((double)e[c] <= te) e[c] = (float)(te + EPS);
+            const int32_t c = order2[q], t = st[c].drain;
+            if (t == NO_TARGET || t == UNVISITED) continue;
+            const double te = (t == TO_OCEAN) ? 0.0 : (double)eL[t];
+            if ((double)eL[c] <= te) eL[c] = (float)(te + EPS);
         }
     });
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     lap("pass3");
 }
 

@@ -245,7 +245,7 @@ static void flood_stage(wo_planet* p, double carveStrength) {
     refresh_host_ocean(p);
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     WO_HIP(hipStreamSynchronize(s));
-    priority_flood_carve_host(p->N, p->h_off.data(), p->h_adj.data(), p->h_pinned, p->h_ocean.data(), carveStrength, p->flood);
+    priority_flood_carve_host(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, p->h_ocean.data(), carveStrength, p->flood);
     WO_HIP(hipMemcpyAsync(p->d_e, p->h_pinned, bytes, hipMemcpyHostToDevice, s));
 }
 

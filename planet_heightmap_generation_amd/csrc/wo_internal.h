@@ -17,16 +17,18 @@ void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float*
 struct FloodHeapItem { float key; int32_t cell; };
 struct FloodCell { float e; int32_t drain; };
 struct FloodScratch {
-    std::vector<int32_t> drainTo, path, order, order2, seedCell, seedTarget, root;
-    std::vector<uint8_t> visited;
-    std::vector<float> surface;
+    // static per (mesh, positions, ocean mask)
+    bool staticValid = false; int32_t staticN = -1; int32_t L = 0;
+    std::vector<int32_t> landCell, landIndex, offL, adjL, seedCell;
+    // per call (land-index space)
+    std::vector<float> surface, eL;
+    std::vector<FloodCell> state;
+    std::vector<int32_t> root, order, order2, list2;
     std::vector<uint32_t> bits, bits2;
     std::vector<FloodHeapItem> heapStore;
-    std::vector<FloodCell> state;
-    bool staticValid = false;       // seed list valid for the current (mesh, r_isOcean)
-    void ensure(int32_t N);
 };
-void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, float* e,
+// xyz (3*N floats) orders the compact land arrays spatially; may be nullptr (index order)
+void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);
 
 // error slot used by every extern "C" entry point (thread-local)

@@ -115,7 +115,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     for (int32_t i = 0; i < F.L; ++i) E.rank[E.land[i]] = i;
     std::vector<int32_t> level(N, 1);
     FloodScratch fs;
-    if (hIters > 0) priority_flood_carve_host(N, off, adj, e, ocean, 0.5, fs);
+    if (hIters > 0) priority_flood_carve_host(N, off, adj, xyz, e, ocean, 0.5, fs);
     const bool glacial = gIters > 0 && gStrength > 0;
     if (glacial) for (int32_t r = 0; r < N; ++r) E.glac[r] = glac_index_cell(F, r, gStrength);
     const double gScale = gIters > 0 ? 1.0 / gIters : 0;
@@ -124,7 +124,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     bool midDone = false;
     int rc = 0;
     for (int32_t iter = 0; iter < total; ++iter) {
-        if (!midDone && iter >= midIter) { midDone = true; priority_flood_carve_host(N, off, adj, e, ocean, 0.85, fs); }
+        if (!midDone && iter >= midIter) { midDone = true; priority_flood_carve_host(N, off, adj, xyz, e, ocean, 0.85, fs); }
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
         if (gNow || hNow) stable_sort_desc(E);
         if (gNow) {
@@ -229,7 +229,7 @@ extern "C" void emu_warp(int32_t N, const int32_t* off, const int32_t* adj, floa
 
 extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, float* e, const uint8_t* ocean, double cs) {
     FloodScratch fs;
-    priority_flood_carve_host(N, off, adj, e, ocean, cs, fs);
+    priority_flood_carve_host(N, off, adj, nullptr, e, ocean, cs, fs);
 }
 
 extern "C" void emu_set_lookahead(int v) { LOOKAHEAD = v; }
