@@ -44,12 +44,20 @@ ALGO_BYTES = {
     "flow_final": (16.0, 4.0),
     "solve_setup": (45.0, 0.0),            # solve family: 45 B/land cell per pass
     "solve_round": (45.0, 0.0),
+    "solve_tail": (45.0, 0.0),
     "solve_final": (8.0, 4.0),
     "thermal_excess": (62.0, 4.0),         # thermal: 106 B/land cell + 4 B/cell split over its two passes
     "thermal_apply": (106.0, 4.0),
     "soil_creep": (82.0 * 0.8, 4.0),       # 82 B per interior-land cell and iteration
     "warp_terrain": (0.0, 20.0 + 100.0 * 24),   # ~20 + 100*hops B/cell, ~24 hops at 10M
 }
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel, collected on the 10M-cell workload (separate passes, committed under
+# profiles/); used to fill roofline.traffic for the dominant kernel when bench.py runs that workload.
+PMC_FILE = REPO / "profiles" / "r01_pmc_fetch_write_per_kernel_10m_after_xcd.json"
+FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": "wo::k_solve_setup",
+                 "thermal_apply": "wo::k_thermal_apply_reg12", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers",
+                 "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "carve_round": "wo::k_carve_round",
+                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final"}
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5)
@@ -200,10 +208,29 @@ def main():
         launches_per_pass = launches / passes
         avg_launch_s = ms / 1e3 / launches
         achieved = bytes_per_pass / launches_per_pass / avg_launch_s / 1e9
+        # per-family view: achieved GB/s on the algorithmic bytes of SURVEY 8(d) (whole passes: bytes / summed launch time)
+        fams = {}
+        for k, (kms, kl) in sorted(rep.items(), key=lambda kv: -kv[1][0]):
+            ent = {"ms": round(kms, 3), "launches": kl}
+            if k in ALGO_BYTES and kms > 0:
+                pl_, pc_ = ALGO_BYTES[k]
+                np_ = int(stats.get("sorts", iters)) if k.startswith("sort") or k == "rank_scatter" else (3 if k == "soil_creep" else (1 if k == "warp_terrain" else iters))
+                gb = (pl_ * L + pc_ * N) * np_ / 1e9
+                ent.update(algorithmic_GB=round(gb, 3), achieved_GBs=round(gb / (kms / 1e3), 1), frac=round(gb / (kms / 1e3) / HBM_PEAK_GBS, 5))
+            fams[k] = ent
+        traffic, traffic_note = None, None
+        if PMC_FILE.exists() and args.cells == 10_000_000 and fam in FAMILY_KERNEL:
+            pmc = json.loads(PMC_FILE.read_text()).get(FAMILY_KERNEL[fam])
+            if pmc and "FETCH_SIZE_KB" in pmc and "WRITE_SIZE_KB" in pmc:
+                traffic = (pmc["FETCH_SIZE_KB"]["per_launch"] + pmc["WRITE_SIZE_KB"]["per_launch"]) * 1024.0
+                traffic_note = ("bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc, separate passes, same workload at 6 iterations "
+                                "(profiles/" + PMC_FILE.name + "); FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x and is "
+                                "uncalibrated for 4-byte gathers, so this is a lower bound")
         roofline = dict(bound="hbm", kernel=fam, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                        traffic=None, launches=launches, avg_launch_us=avg_launch_s * 1e6,
+                        traffic=traffic, traffic_note=traffic_note, launches=launches, avg_launch_us=avg_launch_s * 1e6,
                         algorithmic_bytes_per_launch=bytes_per_pass / launches_per_pass,
-                        families_ms={k: round(v[0], 3) for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])})
+                        note="solve_round is one launch per level of the drainage DAG: bound by launch latency, not by HBM (DESIGN.md §5)",
+                        families=fams)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters)

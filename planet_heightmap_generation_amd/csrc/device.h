@@ -34,6 +34,18 @@ inline int blocks_for(int64_t n, int maxBlocks = 1 << 20) {
     return (int)b;
 }
 
+// grid for WO_XCD_CELLS kernels: one cell per thread, block count rounded up to a multiple of 8
+inline int xcd_tile(int64_t n) {          // blocks per tile: a power of two, ~1/64 of the grid, at most 256 (65 k cells)
+    const int64_t b = (n + WO_BLOCK - 1) / WO_BLOCK;
+    int t = 1;
+    while (t < 256 && (int64_t)t * 128 <= b) t <<= 1;
+    return t;
+}
+inline int xcd_grid(int64_t n) {          // block count padded to whole rounds of 8 tiles
+    const int64_t b = (n + WO_BLOCK - 1) / WO_BLOCK, per = 8 * (int64_t)xcd_tile(n);
+    return (int)(((b + per - 1) / per) * per);
+}
+
 // Kernel families for HIP-event profiling (wo_profile_*) — one entry per distinct kernel of the path.
 enum Family : int {
     FAM_COAST = 0, FAM_SMOOTH, FAM_SHARPEN, FAM_CREEP, FAM_WARP, FAM_NOISE, FAM_SYNTH, FAM_OCEAN,
@@ -125,6 +137,15 @@ inline void launch(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, in
     } else {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, args...);
     }
+}
+
+template <class... KArgs, class... Args>
+inline void launch_shmem(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, int block, size_t shmem, Args... args) {
+    hipStream_t s = p->ctx->stream;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, s, args...);
+    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({fam, a, b}); if (p->pending.size() >= 4096) profile_resolve(p); }
 }
 
 // sort.hip: stable descending sort of the land list by current elevation + rank scatter

@@ -55,6 +55,7 @@ struct alignas(16) SolveOut { Granule self, dep; };
 
 struct Fields {
     int32_t N;                 // numRegions
+    int32_t xcdTile;           // blocks per XCD tile for index-order kernels (device.h: xcd_tile)
     const int32_t* off;        // adjOffset [N+1]
     const int32_t* adj;        // adjList   [E]
     const float* dist;         // neighborDist [E]
@@ -368,16 +369,17 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
     F.totalExcess[r] = total;
 }
 
-// new height of cell c (reads F.e, the pre-thermal field)
-WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, double kThermal) {
+// New height of cell c (reads F.e, the pre-thermal field).  inShare / inRank are caller-provided scratch for the
+// <= degree incoming events, element k at [k * stride] (LDS columns on the device: a per-thread array indexed at
+// run time would live in scratch memory and tripled this kernel's HBM traffic).
+WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, double kThermal, double* inShare, int32_t* inRank, int stride,
+                                      double* outShare = nullptr) {
     if (F.ocean[c]) return F.e[c];
     const double h = F.e[c];
     const int32_t myRank = F.rank[c];
     const double myTotal = F.totalExcess[c];
     const double myTransfer = kThermal * myTotal * 0.5;
-    // incoming shares from higher land neighbours, with the rank of the sender's turn
-    double inShare[WO_MAX_DEG]; int32_t inRank[WO_MAX_DEG]; int nIn = 0;
-    double outShare[WO_MAX_DEG]; int nOut = 0;
+    int nIn = 0, nOut = 0; bool hasOut = false;
     for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
         const int32_t nb = F.adj[j];
         if (F.ocean[nb]) continue;
@@ -386,38 +388,50 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
         if (nh < h) {                       // c sends to nb on c's own turn
             const double slope = (h - nh) / d;
             if (slope > talus && myTotal > 0) {
-                const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
-                outShare[nOut++] = ((double)excess / myTotal) * myTransfer;
+                hasOut = true;
+                if (outShare) { const float excess = (float)((slope - talus) * d); outShare[nOut++ * stride] = ((double)excess / myTotal) * myTransfer; }
             }
         } else if (nh > h) {                // nb may send to c on nb's turn
             const double slope = (nh - h) / d;
             if (slope > talus) {
                 const double tot = F.totalExcess[nb];
                 if (tot > 0) {
-                    const float excess = (float)((slope - talus) * d);
-                    inShare[nIn] = ((double)excess / tot) * (kThermal * tot * 0.5);
-                    inRank[nIn] = F.rank[nb];
+                    const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
+                    inShare[nIn * stride] = ((double)excess / tot) * (kThermal * tot * 0.5);
+                    inRank[nIn * stride] = F.rank[nb];
                     ++nIn;
                 }
             }
         }
     }
-    if (nIn == 0 && nOut == 0) return (float)(h + 0.0);   // e += delta with delta == 0 (also maps -0 -> +0 like the f32 add)
+    if (nIn == 0 && !hasOut) return (float)(h + 0.0);   // e += delta with delta == 0 (also maps -0 -> +0 like the f32 add)
     float delta = 0.0f;
-    bool ownDone = (nOut == 0);
     int32_t last = -1;
-    for (;;) {
-        // next incoming event in rank order
-        int pick = -1; int32_t pr = 0x7fffffff;
-        for (int k = 0; k < nIn; ++k) if (inRank[k] > last && inRank[k] < pr) { pr = inRank[k]; pick = k; }
-        if (!ownDone && (pick < 0 || myRank < pr)) {
-            for (int k = 0; k < nOut; ++k) delta = (float)((double)delta - outShare[k]);
-            ownDone = true;
-            continue;
+    for (int phase = 0; phase < 2; ++phase) {
+        // phase 0: senders whose turn precedes c's own turn; phase 1: the ones after it
+        for (;;) {
+            int pick = -1; int32_t pr = 0x7fffffff;
+            for (int k = 0; k < nIn; ++k) { const int32_t rk = inRank[k * stride]; if (rk > last && rk < pr) { pr = rk; pick = k; } }
+            if (pick < 0 || (phase == 0 && pr > myRank)) break;
+            delta = (float)((double)delta + inShare[pick * stride]);
+            last = pr;
         }
-        if (pick < 0) break;
-        delta = (float)((double)delta + inShare[pick]);
-        last = pr;
+        if (phase == 0 && hasOut && outShare) {      // c's own turn: its sends, in adjacency order (js/terrain-post.js:676-680)
+            for (int k = 0; k < nOut; ++k) delta = (float)((double)delta - outShare[k * stride]);
+        } else if (phase == 0 && hasOut) {
+            for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
+                const int32_t nb = F.adj[j];
+                if (F.ocean[nb]) continue;
+                const double nh = F.e[nb];
+                if (!(nh < h)) continue;
+                const double d = nd_or_eps(F.dist[j]);
+                const double slope = (h - nh) / d;
+                if (slope > talus) {
+                    const float excess = (float)((slope - talus) * d);
+                    delta = (float)((double)delta - ((double)excess / myTotal) * myTransfer);
+                }
+            }
+        }
     }
     return (float)(h + (double)delta);
 }

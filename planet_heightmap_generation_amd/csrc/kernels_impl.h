@@ -13,6 +13,18 @@ namespace wo {
 
 #define WO_GRID_STRIDE(i, n) for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += gridDim.x * blockDim.x)
 
+// XCD-aware cell loop for index-order passes.  Workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md);
+// with the natural mapping the eight L2s each fetch the same +-4.9*sqrt(N) neighbour windows (measured: ~8x the
+// algorithmic bytes in FETCH_SIZE).  Here the blocks are cut into tiles of F.xcdTile consecutive blocks and whole
+// tiles are dealt round-robin to the XCDs: an L2 then sees contiguous index ranges (tile + halo), while land and
+// ocean bands still spread evenly over the eight dies (one contiguous eighth per XCD was measured slower: the land
+// fraction varies with latitude).  Launch with xcd_grid(N, tile) blocks; placement only affects speed, never results.
+#define WO_XCD_CELLS(r, n)                                                                                           \
+    for (int32_t xi_ = (int32_t)(blockIdx.x >> 3), xt_ = F.xcdTile,                                                  \
+                 r = (int32_t)((((xi_ / xt_) * 8 + (int32_t)(blockIdx.x & 7u)) * xt_ + (xi_ % xt_)) * (int32_t)blockDim.x + (int32_t)threadIdx.x), \
+                 once_ = 1;                                                                                          \
+         once_ && r < (n); once_ = 0)
+
 // Block-uniform strided loop: every thread of the workgroup runs the same number of trips (needed around
 // block_append's barriers); `valid` tells whether index i is in range.
 #define WO_BLOCK_STRIDE(i, valid, n)                                                              \
@@ -41,22 +53,22 @@ __device__ inline void block_append(bool flag, int32_t value, int32_t* out, int3
 
 // ---------------------------------------------------------------- fields / Jacobi ---------------
 __global__ __launch_bounds__(WO_BLOCK) void k_coast(Fields F, uint8_t* coast) {
-    WO_GRID_STRIDE(r, F.N) coast[r] = coast_flag(F, r);
+    WO_XCD_CELLS(r, F.N) coast[r] = coast_flag(F, r);
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_ocean_from_elev(const float* e, uint8_t* ocean, int32_t N) {
     WO_GRID_STRIDE(r, N) ocean[r] = (e[r] <= 0.0f) ? 1 : 0;
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_smooth(Fields F, const float* in, float* out, double strength) {
-    WO_GRID_STRIDE(r, F.N) out[r] = smooth_cell(F, in, r, strength);
+    WO_XCD_CELLS(r, F.N) out[r] = smooth_cell(F, in, r, strength);
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_sharpen(Fields F, const float* in, const float* orig, float* out, double strength) {
-    WO_GRID_STRIDE(r, F.N) out[r] = sharpen_cell(F, in, orig, r, strength);
+    WO_XCD_CELLS(r, F.N) out[r] = sharpen_cell(F, in, orig, r, strength);
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_creep(Fields F, const float* in, float* out, double strength) {
-    WO_GRID_STRIDE(r, F.N) out[r] = creep_cell(F, in, r, strength);
+    WO_XCD_CELLS(r, F.N) out[r] = creep_cell(F, in, r, strength);
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_glacial_blend(Fields F, const float* in, float* out) {
-    WO_GRID_STRIDE(r, F.N) out[r] = glacial_blend_cell(F, in, r);
+    WO_XCD_CELLS(r, F.N) out[r] = glacial_blend_cell(F, in, r);
 }
 
 // ---------------------------------------------------------------- noise -------------------------
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_warp(Fields F, const uint8_t* tabl
                                                     double warpBias, const float* hot) {
     __shared__ uint8_t sP[512], sM[512];
     load_tables(tables, sP, sM);
-    WO_GRID_STRIDE(r, F.N) {
+    WO_XCD_CELLS(r, F.N) {
         const int32_t src = warp_source_cell(F, sP, sM, r, maxAmp);
         out[r] = warp_blend(in[r], in[src], warpBias, hot != nullptr, hot ? hot[r] : 0.0f);
     }
@@ -107,10 +119,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_warp(Fields F, const uint8_t* tabl
 __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N) { WO_GRID_STRIDE(r, N) rank[r] = -1; }
 
 // ---------------------------------------------------------------- hydraulic ---------------------
-__global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_GRID_STRIDE(r, F.N) receiver_cell(F, r); }
+__global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_XCD_CELLS(r, F.N) receiver_cell(F, r); }
 
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_init(Fields F) {
-    WO_GRID_STRIDE(r, F.N) {
+    WO_XCD_CELLS(r, F.N) {
         int32_t j = -1; uint32_t a = 0;
         if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
         F.accA[r] = a; F.jumpA[r] = j;
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F) {
-    WO_GRID_STRIDE(c, F.N) {
+    WO_XCD_CELLS(c, F.N) {
         float fl = 0.0f;
         if (!F.ocean[c]) {
             uint32_t f = F.accA[c];
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F) {
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_GRID_STRIDE(r, F.N) solve_setup_cell(F, r); }
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_XCD_CELLS(r, F.N) solve_setup_cell(F, r); }
 
 // One synchronous round of the solve dataflow.  Tasks come from two places: the leftovers of earlier rounds
 // and the bucket of tasks whose level in the previous erosion iteration was exactly this round (levels barely
@@ -243,20 +255,31 @@ __global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const in
 }
 
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level) {
-    WO_GRID_STRIDE(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[r].self.tag; }
+    WO_XCD_CELLS(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[r].self.tag; }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 
 // ---------------------------------------------------------------- thermal -----------------------
-__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_GRID_STRIDE(r, F.N) thermal_excess_cell(F, r, talus); }
-__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out, double talus, double kThermal) {
-    WO_GRID_STRIDE(r, F.N) out[r] = thermal_apply_cell(F, r, talus, kThermal);
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_XCD_CELLS(r, F.N) thermal_excess_cell(F, r, talus); }
+// meshes whose largest degree is <= 12 (every Fibonacci/Delaunay mesh seen so far: max 10-11) keep the event list in
+// registers (a 12-entry private array is promoted to VGPRs: 69 VGPRs, no scratch); larger degrees use the LDS form
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply_reg12(Fields F, float* out, double talus, double kThermal) {
+    WO_XCD_CELLS(r, F.N) {
+        double inShare[12], outShare[12]; int32_t inRank[12];
+        out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, 1, outShare);
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out, double talus, double kThermal, int32_t maxDeg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [maxDeg][256] doubles, then [maxDeg][256] ints
+    double* inShare = reinterpret_cast<double*>(smem) + threadIdx.x;
+    int32_t* inRank = reinterpret_cast<int32_t*>(smem + (size_t)maxDeg * WO_BLOCK * sizeof(double)) + threadIdx.x;
+    WO_XCD_CELLS(r, F.N) out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, WO_BLOCK);
 }
 
 // ---------------------------------------------------------------- glacial -----------------------
-__global__ __launch_bounds__(WO_BLOCK) void k_glac_index(Fields F, double strength) { WO_GRID_STRIDE(r, F.N) F.glac[r] = glac_index_cell(F, r, strength); }
+__global__ __launch_bounds__(WO_BLOCK) void k_glac_index(Fields F, double strength) { WO_XCD_CELLS(r, F.N) F.glac[r] = glac_index_cell(F, r, strength); }
 __global__ __launch_bounds__(WO_BLOCK) void k_ice_receivers(Fields F) {
-    WO_GRID_STRIDE(r, F.N) { ice_receiver_cell(F, r); if (F.ocean[r]) { F.iceFlow[r] = 0.0f; F.iceUp[r] = 0; } }
+    WO_XCD_CELLS(r, F.N) { ice_receiver_cell(F, r); if (F.ocean[r]) { F.iceFlow[r] = 0.0f; F.iceUp[r] = 0; } }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_ice_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
                                                          int32_t* outCount, int32_t* zeroCount, int32_t round) {
@@ -287,7 +310,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDep, double gFjord) {
-    WO_GRID_STRIDE(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
+    WO_XCD_CELLS(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
 }
 
 __global__ void k_set_counters(int32_t* c, int32_t v0, int32_t v1, int32_t v2, int32_t v3) {

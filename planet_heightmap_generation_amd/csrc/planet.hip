@@ -68,7 +68,7 @@ static void ensure_scratch(wo_planet* p) {
 
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
-    F.N = N; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
+    F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.doneAt = d_doneAt;
@@ -250,7 +250,7 @@ static void flood_stage(wo_planet* p, double carveStrength) {
 }
 
 static void coast_flags(wo_planet* p) {
-    launch(p, FAM_COAST, k_coast, blocks_for(p->N), WO_BLOCK, p->fields(), p->d_coast);
+    launch(p, FAM_COAST, k_coast, xcd_grid(p->N), WO_BLOCK, p->fields(), p->d_coast);
 }
 
 // erodeComposite on the resident field (js/terrain-post.js:369-707)
@@ -264,7 +264,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     ensure_scratch(p);
     hipStream_t s = p->ctx->stream;
     const int32_t N = p->N;
-    const int gridN = blocks_for(N);
+    const int gridN = xcd_grid(N);
     StageClock clk(p);
     int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0;
     double floodHostMs = 0;
@@ -361,7 +361,11 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.begin("thermal");
             Fields F = p->fields();
             launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridN, WO_BLOCK, F, talus);
-            launch(p, FAM_THERMAL_APPLY, k_thermal_apply, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+            if (p->maxDeg <= 12)
+                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg12, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+            else
+                launch_shmem(p, FAM_THERMAL_APPLY, k_thermal_apply, gridN, WO_BLOCK, (size_t)p->maxDeg * WO_BLOCK * 12, F, p->d_e2, talus, kThermal,
+                             (int32_t)p->maxDeg);
             swap_elev(p);
             clk.end();
         }
@@ -383,7 +387,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
     if (iterations <= 0) return;
     coast_flags(p);
-    const int gridN = blocks_for(p->N);
+    const int gridN = xcd_grid(p->N);
     hipStream_t s = p->ctx->stream;
     if (kind == 1) WO_HIP(hipMemcpyAsync(p->d_orig, p->d_e, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int32_t it = 0; it < iterations; ++it) {
@@ -406,7 +410,7 @@ static void warp(wo_planet* p, double seed, double strength, bool useHot) {
     if (!(strength > 0)) return;          // js/terrain-post.js:234
     upload_tables(p, seed + 9999);
     const double maxAmp = 0.12 * strength, bias = 0.25 + 0.5 * strength;
-    launch(p, FAM_WARP, k_warp, blocks_for(p->N), WO_BLOCK, p->fields(), (const uint8_t*)p->d_tables, (const float*)p->d_e, p->d_e2,
+    launch(p, FAM_WARP, k_warp, xcd_grid(p->N), WO_BLOCK, p->fields(), (const uint8_t*)p->d_tables, (const float*)p->d_e, p->d_e2,
            maxAmp, bias, useHot ? (const float*)p->d_hot : (const float*)nullptr);
     swap_elev(p);
 }

@@ -180,7 +180,9 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
         }
         if (iter < tIters) {
             for (int32_t r = 0; r < N; ++r) thermal_excess_cell(F, r, talus);
-            for (int32_t r = 0; r < N; ++r) F.e2[r] = thermal_apply_cell(F, r, talus, kThermal);
+            { double inShare[WO_MAX_DEG], outShare[WO_MAX_DEG]; int32_t inRank[WO_MAX_DEG];
+              // alternate the two own-turn forms (stored / recomputed shares) so both stay covered
+              for (int32_t r = 0; r < N; ++r) F.e2[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, 1, (r & 1) ? outShare : nullptr); }
             std::memcpy(e, F.e2, sizeof(float) * (size_t)N);
         }
     }
