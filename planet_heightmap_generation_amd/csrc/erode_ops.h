@@ -37,7 +37,7 @@ namespace wo {
 constexpr int WO_MAX_DEG = 24;          // planets with a larger vertex degree are rejected at creation
 constexpr int32_t WO_NOT_DONE = 0x7fffffff;
 
-// ---- solve dataflow records (one 48-byte record in, one 16-byte record out per task) ----
+// ---- solve dataflow records (one 64-byte record in, one 16-byte record out per task) ----
 // Everything a turn of the implicit solve needs that does not depend on other turns is gathered once, in
 // index order, by solve_setup; a round then costs: list entry -> task record -> <=3 predecessor granules.
 struct alignas(16) SolveTask {
@@ -48,7 +48,10 @@ struct alignas(16) SolveTask {
     float cellDist, cellDistT;         // cellDist[r], cellDist[target]
     int32_t t2;                        // drainTarget[target] or -1
     uint32_t flags;                    // bit0: target is ocean, bit1: t2 is ocean
+    int32_t lpSelf, lpT, lpT2;         // patch-local granule index (2*slotInPatch + which) when the predecessor task
+    int32_t pad_;                      //   belongs to the same spatial patch as r, else -1 (solve_patch kernel)
 };
+constexpr int WO_PATCH = 1024;          // land cells (= solve tasks) per spatial patch / workgroup
 // {value, round tag}: tag 0 = not produced yet.  Written once per pass, consumed only by later rounds.
 struct alignas(8) Granule { float v; int32_t tag; };
 struct alignas(16) SolveOut { Granule self, dep; };
@@ -75,6 +78,7 @@ struct Fields {
     int32_t* jumpA; int32_t* jumpB;     // pointer-doubling ancestors [N]
     // solve dataflow
     SolveTask* task;                    // per-land-cell task record built by solve_setup [N]
+    const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean / unset [N]
     SolveOut* out;                      // per-cell event outputs {own turn, deposit on receiver} [N]
     int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]
     // thermal
@@ -294,23 +298,27 @@ WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
             }
         }
     }
+    T.lpSelf = T.lpT = T.lpT2 = -1; T.pad_ = 0;
+    if (F.slotOf) {
+        const int32_t myPatch = F.slotOf[r] / WO_PATCH;
+        auto local = [&](int32_t g) -> int32_t {
+            if (g < 0) return -1;
+            const int32_t s = F.slotOf[g >> 1];
+            return (s >= 0 && s / WO_PATCH == myPatch) ? ((s % WO_PATCH) * 2 + (g & 1)) : -1;
+        };
+        T.lpSelf = local(T.predSelf); T.lpT = local(T.predT); T.lpT2 = local(T.predT2);
+    }
     F.task[r] = T;
     SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
     F.out[r] = z;
 }
 
-// Returns true when the task ran (all predecessors were produced in rounds < round).
-WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K, double m, double dt) {
-    const SolveTask T = F.task[r];
-    const Granule* G = reinterpret_cast<const Granule*>(F.out);
-    double er = T.e0r, et = T.e0t, et2 = T.e0t2;
-    if (T.predSelf >= 0) { const Granule g = G[T.predSelf]; if (g.tag == 0 || !(g.tag < round)) return false; er = g.v; }
-    if (T.predT >= 0)    { const Granule g = G[T.predT];    if (g.tag == 0 || !(g.tag < round)) return false; et = g.v; }
-    if (T.predT2 >= 0)   { const Granule g = G[T.predT2];   if (g.tag == 0 || !(g.tag < round)) return false; et2 = g.v; }
+// one turn of the implicit solve + deposition (js/terrain-post.js:616-640) given its three inputs
+WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, double et2, int32_t tag, double K, double m, double dt) {
     SolveOut o;
-    o.self.tag = round; o.dep.tag = round;
+    o.self.tag = tag; o.dep.tag = tag;
     if (T.target < 0) {          // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
-        o.self.v = (float)er; o.dep.v = 0; F.out[r] = o; return true;
+        o.self.v = (float)er; o.dep.v = 0; return o;
     }
     const double fl = T.flow;
     const double pw = (m == 0.5) ? sqrt(fl) : pow(fl, m);
@@ -330,7 +338,18 @@ WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K
         if ((double)tval > hn) tval = (float)hn;
     }
     o.self.v = (float)hn; o.dep.v = tval;
-    F.out[r] = o;
+    return o;
+}
+
+// Returns true when the task ran (all predecessors were produced in rounds < round).
+WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K, double m, double dt) {
+    const SolveTask T = F.task[r];
+    const Granule* G = reinterpret_cast<const Granule*>(F.out);
+    double er = T.e0r, et = T.e0t, et2 = T.e0t2;
+    if (T.predSelf >= 0) { const Granule g = G[T.predSelf]; if (g.tag == 0 || !(g.tag < round)) return false; er = g.v; }
+    if (T.predT >= 0)    { const Granule g = G[T.predT];    if (g.tag == 0 || !(g.tag < round)) return false; et = g.v; }
+    if (T.predT2 >= 0)   { const Granule g = G[T.predT2];   if (g.tag == 0 || !(g.tag < round)) return false; et2 = g.v; }
+    F.out[r] = solve_compute(T, er, et, et2, round, K, m, dt);
     return true;
 }
 

@@ -130,7 +130,7 @@ constexpr int32_t UNVISITED = -2, TO_OCEAN = -3, NO_TARGET = -1;
 // open-ocean component (largest, first wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose
 // first open-ocean neighbour in adjacency order exists, ascending r, :118-128).  Shared by both flood calls of
 // an erodeComposite and kept across calls while the ocean mask is unchanged.
-static void build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S) {
+void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S) {
     std::vector<int32_t> label(N, -1), stack(N);
     std::vector<int32_t> sizes;
     for (int32_t r = 0; r < N; ++r) {
@@ -196,6 +196,8 @@ static void build_static(int32_t N, const int32_t* off, const int32_t* adj, cons
     S.surface.resize(L); S.state.resize(L); S.root.resize(L); S.eL.resize(L);
     S.order.resize(L); S.order2.resize(L); S.bits.resize(L); S.bits2.resize(L); S.list2.resize(L);
     S.staticValid = true;
+    S.staticN = N;
+    ++S.staticVersion;
 }
 
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
@@ -209,7 +211,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         std::fprintf(stderr, "[flood] %-10s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
         tp = now;
     };
-    if (!S.staticValid || S.staticN != N) { build_static(N, off, adj, xyz, ocean, S); S.staticN = N; }
+    if (!S.staticValid || S.staticN != N) flood_build_static(N, off, adj, xyz, ocean, S);
     lap("static");
     const int32_t L = S.L;
     if (L == 0) return;

@@ -245,6 +245,94 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
     if (tid == 0) { stats[0] = k; stats[1] = (s_cnt[cur] != 0) ? 2 : 0; }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Patch-local solve.  Land cells are grouped in spatial patches of WO_PATCH cells (Morton order); one workgroup
+// owns one patch and keeps the {value, tag} granules of its tasks in LDS.  In a launch a workgroup runs every task
+// whose predecessors are (a) outside the patch and produced by an EARLIER launch, or (b) inside the patch and already
+// produced — by an earlier launch or by an earlier sub-round of this launch (visible through LDS after a barrier).  So a
+// chain segment that stays inside a patch advances at LDS latency and only patch-crossing edges wait for a kernel
+// boundary.  The dataflow is single-assignment, so the bits do not depend on the schedule (same results as the
+// level-synchronous rounds; checked by the parity tests).  patchPending[p] = tasks of patch p still waiting.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int WO_PATCH_THREADS = 1024;                      // threads per patch workgroup
+constexpr int WO_PATCH_TPT = WO_PATCH / WO_PATCH_THREADS;   // tasks per thread (kept in registers)
+__global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, const int32_t* patchOrder, int32_t L, int32_t launchTag,
+                                                                   int32_t* patchPending, int32_t* totalPending, double K, double m, double dt) {
+    __shared__ Granule s_out[2 * WO_PATCH];
+    __shared__ int32_t s_prog[2];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    if (patchPending[p] == 0) return;                       // block-uniform
+    SolveTask T[WO_PATCH_TPT];
+    double er[WO_PATCH_TPT], et[WO_PATCH_TPT], et2[WO_PATCH_TPT];
+    int32_t cell[WO_PATCH_TPT];
+    bool done[WO_PATCH_TPT], ext[WO_PATCH_TPT];
+    const Granule* G = reinterpret_cast<const Granule*>(F.out);
+#pragma unroll
+    for (int q = 0; q < WO_PATCH_TPT; ++q) {
+        const int ls = q * WO_PATCH_THREADS + tid;           // slot inside the patch (coalesced across the workgroup)
+        const int32_t slot = p * WO_PATCH + ls;
+        const bool have = slot < L;
+        cell[q] = have ? patchOrder[slot] : 0;
+        SolveOut mine; mine.self.v = 0; mine.self.tag = 0; mine.dep.v = 0; mine.dep.tag = 0;
+        if (have) mine = F.out[cell[q]];
+        done[q] = !have || mine.self.tag != 0;
+        s_out[2 * ls] = mine.self; s_out[2 * ls + 1] = mine.dep;
+        ext[q] = false; er[q] = et[q] = et2[q] = 0;
+        if (!done[q]) {
+            T[q] = F.task[cell[q]];
+            er[q] = T[q].e0r; et[q] = T[q].e0t; et2[q] = T[q].e0t2;
+            bool ok = true;
+            if (T[q].predSelf >= 0 && T[q].lpSelf < 0) { const Granule g = G[T[q].predSelf]; if (g.tag == 0 || g.tag >= launchTag) ok = false; else er[q] = g.v; }
+            if (T[q].predT >= 0 && T[q].lpT < 0)       { const Granule g = G[T[q].predT];    if (g.tag == 0 || g.tag >= launchTag) ok = false; else et[q] = g.v; }
+            if (T[q].predT2 >= 0 && T[q].lpT2 < 0)     { const Granule g = G[T[q].predT2];   if (g.tag == 0 || g.tag >= launchTag) ok = false; else et2[q] = g.v; }
+            ext[q] = ok;
+        }
+    }
+    if (tid < 2) s_prog[tid] = 0;
+    __syncthreads();
+    int par = 0;
+    for (;;) {
+        SolveOut o[WO_PATCH_TPT];
+        bool ran[WO_PATCH_TPT];
+#pragma unroll
+        for (int q = 0; q < WO_PATCH_TPT; ++q) {
+            ran[q] = false;
+            if (!done[q] && ext[q]) {
+                bool ok = true;
+                double a = er[q], b = et[q], c = et2[q];
+                if (T[q].lpSelf >= 0) { const Granule g = s_out[T[q].lpSelf]; if (g.tag == 0) ok = false; else a = g.v; }
+                if (T[q].lpT >= 0)    { const Granule g = s_out[T[q].lpT];    if (g.tag == 0) ok = false; else b = g.v; }
+                if (T[q].lpT2 >= 0)   { const Granule g = s_out[T[q].lpT2];   if (g.tag == 0) ok = false; else c = g.v; }
+                if (ok) { o[q] = solve_compute(T[q], a, b, c, launchTag, K, m, dt); F.out[cell[q]] = o[q]; ran[q] = true; }
+            }
+        }
+        __syncthreads();                                   // every read of s_out for this sub-round is done
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < WO_PATCH_TPT; ++q)
+            if (ran[q]) { const int ls = q * WO_PATCH_THREADS + tid; s_out[2 * ls] = o[q].self; s_out[2 * ls + 1] = o[q].dep; done[q] = true; any = true; }
+        if (any) s_prog[par] = 1;
+        if (tid == 0) s_prog[par ^ 1] = 0;
+        __syncthreads();
+        if (s_prog[par] == 0) break;                       // block-uniform: nobody advanced, the rest waits for other patches
+        par ^= 1;
+    }
+    int mineLeft = 0;
+#pragma unroll
+    for (int q = 0; q < WO_PATCH_TPT; ++q) mineLeft += done[q] ? 0 : 1;
+    // block total of the still-pending tasks
+    __shared__ int32_t s_left;
+    if (tid == 0) s_left = 0;
+    __syncthreads();
+    if (mineLeft) atomicAdd(&s_left, mineLeft);
+    __syncthreads();
+    if (tid == 0) { const int32_t left = s_left; patchPending[p] = left; if (left) atomicAdd(totalPending, left); }
+}
+
+__global__ __launch_bounds__(WO_BLOCK) void k_slot_scatter(const int32_t* patchOrder, int32_t* slotOf, int32_t L) {
+    WO_GRID_STRIDE(s, L) slotOf[patchOrder[s]] = s;
+}
+
 // pending = land tasks whose round tag is still 0 (recovery after a tail overflow)
 __global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const int32_t* landIdx, int32_t L, int32_t* out, int32_t* outCount) {
     WO_BLOCK_STRIDE(i, valid, L) {

@@ -23,7 +23,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "elev_collisions", "elev_uplift_fused", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -56,6 +56,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
     p->d_iceUp = dalloc<uint8_t>(N);
     p->d_listA = dalloc<int32_t>(N); p->d_listB = dalloc<int32_t>(N); p->d_counters = dalloc<int32_t>(8);
+    p->d_patchOrder = dalloc<int32_t>(N); p->d_slotOf = dalloc<int32_t>(N); p->d_patchPending = dalloc<int32_t>(N / WO_PATCH + 2);
     p->d_level = dalloc<int32_t>(N); p->d_byLevel = dalloc<int32_t>(N); p->d_levelStart = dalloc<int32_t>(WO_MAX_LEVEL + 2);
     WO_HIP(hipHostMalloc((void**)&p->h_levelStart, (WO_MAX_LEVEL + 2) * sizeof(int32_t)));
     p->sortTempBytes = sort_temp_bytes(p->N);
@@ -71,7 +72,7 @@ wo::Fields wo_planet::fields() const {
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
-    F.task = d_task; F.out = d_out; F.doneAt = d_doneAt;
+    F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank;
     return F;
 }
@@ -219,6 +220,29 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
     return k - 1;
 }
 
+// Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
+static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt) {
+    hipStream_t s = p->ctx->stream;
+    int32_t* c = p->d_counters;
+    const int np = p->numPatches;
+    launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, 1, (int32_t)np);
+    int64_t launches = 0;
+    for (int32_t tag = 1;; ) {
+        // The pending total is read back (one stream sync) after every burst.  The launch count barely changes from one
+        // erosion iteration to the next, so the first burst is sized by the previous count; then small bursts to finish.
+        const int burst = (tag == 1) ? std::max<int>(1, (int)p->lastPatchLaunches - 1) : 3;
+        for (int b = 0; b < burst; ++b, ++tag) {
+            WO_HIP(hipMemsetAsync(c + 6, 0, sizeof(int32_t), s));
+            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, (const int32_t*)p->d_patchOrder, p->L, tag, p->d_patchPending, c + 6, K, m, dt);
+            ++launches;
+        }
+        if (read_count(p, c + 6) == 0) break;
+        if (launches > 4 * (int64_t)p->N + 1024) throw HipError{"patch solve does not converge"};
+    }
+    p->lastPatchLaunches = launches;
+    return launches;
+}
+
 struct StageClock {
     wo_planet* p; std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
     explicit StageClock(wo_planet* pl) : p(pl) {}
@@ -266,7 +290,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t N = p->N;
     const int gridN = xcd_grid(N);
     StageClock clk(p);
-    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0;
+    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0, patchLaunches = 0;
     double floodHostMs = 0;
 
     clk.begin("setup");
@@ -286,6 +310,22 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
         rank_from_land(p);      // thermal-only runs never sort: landCells stays in ascending-r order
         launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_level, 1, N);   // no level history yet: everything in round 1
+        // spatial patches for the patch-local solve: land cells in Morton order (shared with the host flood's layout)
+        if (hIters > 0 && !p->h_xyz.empty() && std::getenv("WO_NO_SOLVE_PATCH") == nullptr) {
+            if (!p->flood.staticValid || p->flood.staticN != N)
+                flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood);
+            if (p->patchVersion != p->flood.staticVersion) {
+                WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->flood.landCell.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_slotOf, -1, N);
+                launch(p, FAM_MISC, k_slot_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_patchOrder, p->d_slotOf, L);
+                WO_HIP(hipStreamSynchronize(s));
+                p->patchVersion = p->flood.staticVersion;
+                p->lastPatchLaunches = 1;
+                p->numPatches = (L + WO_PATCH - 1) / WO_PATCH;
+            }
+        } else {
+            p->patchVersion = -1;
+        }
     }
     const int32_t L = p->L;
     clk.end();
@@ -348,7 +388,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.end();
             clk.begin("solve");
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridN, WO_BLOCK, F);
-            {
+            if (p->patchVersion >= 0) {
+                const int64_t r = run_solve_patches(p, F, K, m, dt);
+                patchLaunches += r; maxSolve = std::max(maxSolve, r);
+            } else {
                 const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
             }
@@ -379,7 +422,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     clk.finish();
     p->erodeStats = {{"land_cells", (double)L}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
-                     {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds},
+                     {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
                      {"carve_rounds_total", (double)carveRounds}, {"flood_host_ms", floodHostMs}};
 }
@@ -526,6 +569,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
+    dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending);
     dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
     if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);
     if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);

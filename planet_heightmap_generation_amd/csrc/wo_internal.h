@@ -18,7 +18,7 @@ struct FloodHeapItem { float key; int32_t cell; };
 struct FloodCell { float e; int32_t drain; };
 struct FloodScratch {
     // static per (mesh, positions, ocean mask)
-    bool staticValid = false; int32_t staticN = -1; int32_t L = 0;
+    bool staticValid = false; int32_t staticN = -1; int32_t L = 0; int64_t staticVersion = 0;
     std::vector<int32_t> landCell, landIndex, offL, adjL, seedCell;
     // per call (land-index space)
     std::vector<float> surface, eL;
@@ -27,6 +27,8 @@ struct FloodScratch {
     std::vector<uint32_t> bits, bits2;
     std::vector<FloodHeapItem> heapStore;
 };
+// (re)builds the mask-dependent tables (Morton-ordered land list `landCell`, compact CSR, seeds)
+void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S);
 // xyz (3*N floats) orders the compact land arrays spatially; may be nullptr (index order)
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);

@@ -86,6 +86,52 @@ int64_t run_solve_rounds_pred(Emu& E, std::vector<int32_t>& level, double K, dou
     return round;
 }
 
+// patch-local solve schedule, mirroring k_solve_patch / run_solve_patches: external predecessors must come from an
+// earlier launch, patch-local ones from any earlier sub-round
+int64_t run_solve_patches_emu(Emu& E, const std::vector<int32_t>& patchOrder, double K, double m, double dt) {
+    const Fields& F = E.F;
+    const int32_t L = (int32_t)patchOrder.size();
+    const int32_t np = (L + WO_PATCH - 1) / WO_PATCH;
+    const Granule* G = reinterpret_cast<const Granule*>(F.out);
+    int64_t launches = 0;
+    for (int32_t tag = 1;; ++tag) {
+        ++launches;
+        int64_t pending = 0;
+        for (int32_t p = 0; p < np; ++p) {
+            const int32_t s0 = p * WO_PATCH, s1 = std::min(L, s0 + WO_PATCH);
+            std::vector<uint8_t> ext(s1 - s0, 0);
+            std::vector<double> er(s1 - s0), et(s1 - s0), et2(s1 - s0);
+            for (int32_t s = s0; s < s1; ++s) {
+                const int32_t c = patchOrder[s];
+                if (F.out[c].self.tag != 0) continue;
+                const SolveTask& T = F.task[c];
+                bool ok = true; double a = T.e0r, b = T.e0t, d = T.e0t2;
+                auto extp = [&](int32_t g, int32_t lp, double& v) { if (g >= 0 && lp < 0) { const Granule q = G[g]; if (q.tag == 0 || q.tag >= tag) ok = false; else v = q.v; } };
+                extp(T.predSelf, T.lpSelf, a); extp(T.predT, T.lpT, b); extp(T.predT2, T.lpT2, d);
+                ext[s - s0] = ok; er[s - s0] = a; et[s - s0] = b; et2[s - s0] = d;
+            }
+            for (;;) {                      // sub-rounds: results of a sub-round become visible to the next one
+                std::vector<std::pair<int32_t, SolveOut>> produced;
+                for (int32_t s = s0; s < s1; ++s) {
+                    const int32_t c = patchOrder[s];
+                    if (F.out[c].self.tag != 0 || !ext[s - s0]) continue;
+                    const SolveTask& T = F.task[c];
+                    bool ok = true; double a = er[s - s0], b = et[s - s0], d = et2[s - s0];
+                    auto loc = [&](int32_t lp, double& v) { if (lp >= 0) { const Granule q = G[2 * patchOrder[s0 + lp / 2] + (lp & 1)]; if (q.tag == 0) ok = false; else v = q.v; } };
+                    loc(T.lpSelf, a); loc(T.lpT, b); loc(T.lpT2, d);
+                    if (ok) produced.push_back({c, solve_compute(T, a, b, d, tag, K, m, dt)});
+                }
+                if (produced.empty()) break;
+                for (auto& pr : produced) F.out[pr.first] = pr.second;
+            }
+            for (int32_t s = s0; s < s1; ++s) if (F.out[patchOrder[s]].self.tag == 0) ++pending;
+        }
+        if (pending == 0) break;
+        if (launches > 8 * (int64_t)F.N) return -launches;
+    }
+    return launches;
+}
+
 }  // namespace
 
 extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t* adj, float* e, const float* xyz,
@@ -114,6 +160,11 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     if (F.L == 0) return 0;
     for (int32_t i = 0; i < F.L; ++i) E.rank[E.land[i]] = i;
     std::vector<int32_t> level(N, 1);
+    // odd iteration counts exercise the patch-local schedule (patches = chunks of the ascending-id land list), even ones the level rounds
+    const bool usePatches = (hIters & 1) != 0;
+    std::vector<int32_t> slotOf(N, -1);
+    for (int32_t i = 0; i < F.L; ++i) slotOf[E.landIdx[i]] = i;
+    F.slotOf = usePatches ? slotOf.data() : nullptr;
     FloodScratch fs;
     if (hIters > 0) priority_flood_carve_host(N, off, adj, xyz, e, ocean, 0.5, fs);
     const bool glacial = gIters > 0 && gStrength > 0;
@@ -172,7 +223,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
                 F.flow[c] = (float)f;
             }
             for (int32_t r = 0; r < N; ++r) solve_setup_cell(F, r);
-            int64_t n3 = run_solve_rounds_pred(E, level, K, m, dt);
+            int64_t n3 = usePatches ? run_solve_patches_emu(E, E.landIdx, K, m, dt) : run_solve_rounds_pred(E, level, K, m, dt);
             if (n3 < 0) rc = 12;
             E.solveRounds += n3; if (n3 > E.maxSolveRounds) E.maxSolveRounds = n3;
             for (int32_t r = 0; r < N; ++r) F.e2[r] = solve_final_cell(F, r);
