@@ -51,7 +51,7 @@ struct alignas(16) SolveTask {
     int32_t lpSelf, lpT, lpT2;         // patch-local granule index (2*slotInPatch + which) when the predecessor task
     int32_t pad_;                      //   belongs to the same spatial patch as r, else -1 (solve_patch kernel)
 };
-constexpr int WO_PATCH = 1024;          // land cells (= solve tasks) per spatial patch / workgroup
+constexpr int WO_PATCH = 512;          // land cells (= solve tasks) per spatial patch / workgroup
 // {value, round tag}: tag 0 = not produced yet.  Written once per pass, consumed only by later rounds.
 struct alignas(8) Granule { float v; int32_t tag; };
 struct alignas(16) SolveOut { Granule self, dep; };

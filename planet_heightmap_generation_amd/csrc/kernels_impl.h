@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
 // boundary.  The dataflow is single-assignment, so the bits do not depend on the schedule (same results as the
 // level-synchronous rounds; checked by the parity tests).  patchPending[p] = tasks of patch p still waiting.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int WO_PATCH_THREADS = 1024;                      // threads per patch workgroup
+constexpr int WO_PATCH_THREADS = 512;                      // threads per patch workgroup
 constexpr int WO_PATCH_TPT = WO_PATCH / WO_PATCH_THREADS;   // tasks per thread (kept in registers)
 __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, const int32_t* patchOrder, int32_t L, int32_t launchTag,
                                                                    int32_t* patchPending, int32_t* totalPending, double K, double m, double dt) {
