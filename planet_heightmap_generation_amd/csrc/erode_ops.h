@@ -89,6 +89,7 @@ struct Fields {
     float* iceFlow;            // [N]
     uint8_t* iceUp;            // numIceUpstream [N]
     int32_t* arank;            // carve: rank if the cell is an active carve task else WO_NOT_DONE [N]
+    int32_t* blocker;          // carve: the unfinished lower-ranked active cell that blocked the task at its last full scan, or -1 [N]
 };
 
 WO_HD inline double nd_or_eps(float d) { return (d == 0.0f || d != d) ? 1e-6 : (double)d; }   // `x || 1e-6`
@@ -530,6 +531,7 @@ WO_HD inline void carve_setup_cell(const Fields& F, int32_t r) {
     const bool active = !F.ocean[r] && ((double)F.iceFlow[r] > 0.1);
     F.arank[r] = active ? F.rank[r] : WO_NOT_DONE;
     F.doneAt[r] = WO_NOT_DONE;
+    F.blocker[r] = -1;
 }
 
 // in-place carve of cell r (js/terrain-post.js:506-526).  Ready when no unfinished active cell within
@@ -537,15 +539,22 @@ WO_HD inline void carve_setup_cell(const Fields& F, int32_t r) {
 WO_HD inline bool carve_task(const Fields& F, int32_t r, int32_t round, double gCarveRate, double gConvergenceBonus,
                              double glacialStrength) {
     const int32_t myRank = F.arank[r];
+    // cheap test first: the cell that blocked us at the last full scan (1-2 loads instead of ~40)
+    const int32_t b0 = F.blocker[r];
+    if (b0 >= 0 && !(F.doneAt[b0] < round)) return false;
+    // full 2-hop scan; remember the unfinished blocker closest to us in rank (it tends to finish last)
+    int32_t blk = -1, blkRank = -1;
     for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
         const int32_t n = F.adj[j];
-        if (F.arank[n] < myRank && !(F.doneAt[n] < round)) return false;
+        { const int32_t a = F.arank[n]; if (a < myRank && a > blkRank && !(F.doneAt[n] < round)) { blk = n; blkRank = a; } }
         for (int32_t q = F.off[n]; q < F.off[n + 1]; ++q) {
             const int32_t mcell = F.adj[q];
             if (mcell == r) continue;
-            if (F.arank[mcell] < myRank && !(F.doneAt[mcell] < round)) return false;
+            const int32_t a = F.arank[mcell];
+            if (a < myRank && a > blkRank && !(F.doneAt[mcell] < round)) { blk = mcell; blkRank = a; }
         }
     }
+    if (blk >= 0) { F.blocker[r] = blk; return false; }
     const double fl = F.iceFlow[r];
     const double deepening = gCarveRate * pow(fl, 0.6) * glacialStrength;
     float er = (float)((double)F.e[r] - deepening);
