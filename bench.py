@@ -102,6 +102,28 @@ def whole_job_value(cells: int, iters: int, steps: int, world: int, wall_s: floa
     return cells * iters * steps * world / wall_s / 1e6
 
 
+def bind_to_gpu_numa_node(local_rank: int):
+    """Pin this rank (and the threads it will create) to the CPUs of the NUMA node its GPU hangs off: the host-resident
+    flood stage is memory-latency bound and loses 20-30 % when the OS places it on the far socket."""
+    try:
+        import torch
+        node = os.environ.get("WO_BENCH_NUMA_NODE")
+        if node is None:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            node = Path(f"/sys/bus/pci/devices/{bdf}/numa_node").read_text().strip()
+        if int(node) < 0:
+            return None
+        cpus = set()
+        for part in Path(f"/sys/devices/system/node/node{int(node)}/cpulist").read_text().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, cpus)
+        return int(node)
+    except Exception:
+        return None
+
+
 def build_inputs(cells: int, seed: int):
     from planet_heightmap_generation_amd import sphere_mesh as S
     t0 = time.time()
@@ -156,6 +178,7 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
     dist = dist_init(world, local_rank, "nccl")
     torch.cuda.set_device(local_rank)
+    numa_node = bind_to_gpu_numa_node(local_rank)
 
     from planet_heightmap_generation_amd import terrain_post as TP
     params = dict(PARAMS)
@@ -247,7 +270,7 @@ def main():
                        "parallelism": f"ensemble x{world} (no collective on the data path)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "stage_ms_last_step": {k: round(v, 2) for k, v in stages.items()},
-            "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "hip_event_ms_per_step": ev_ms / args.steps,
+            "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "host_numa_node": numa_node, "hip_event_ms_per_step": ev_ms / args.steps,
         }
         print(json.dumps(out))
     pl.close()
