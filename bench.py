@@ -45,6 +45,7 @@ ALGO_BYTES = {
     "solve_setup": (45.0, 0.0),            # solve family: 45 B/land cell per pass
     "solve_round": (45.0, 0.0),
     "solve_tail": (45.0, 0.0),
+    "solve_patch": (45.0, 0.0),
     "solve_final": (8.0, 4.0),
     "thermal_excess": (62.0, 4.0),         # thermal: 106 B/land cell + 4 B/cell split over its two passes
     "thermal_apply": (106.0, 4.0),
@@ -55,7 +56,7 @@ ALGO_BYTES = {
 # profiles/); used to fill roofline.traffic for the dominant kernel when bench.py runs that workload.
 PMC_FILE = REPO / "profiles" / "r01_pmc_fetch_write_per_kernel_10m_after_xcd.json"
 FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": "wo::k_solve_setup",
-                 "thermal_apply": "wo::k_thermal_apply_reg12", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers",
+                 "thermal_apply": "wo::k_thermal_apply", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers",
                  "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "carve_round": "wo::k_carve_round",
                  "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final"}
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
@@ -252,7 +253,7 @@ def main():
         roofline = dict(bound="hbm", kernel=fam, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, traffic_note=traffic_note, launches=launches, avg_launch_us=avg_launch_s * 1e6,
                         algorithmic_bytes_per_launch=bytes_per_pass / launches_per_pass,
-                        note="solve_round is one launch per level of the drainage DAG: bound by launch latency, not by HBM (DESIGN.md §5)",
+                        note="the solve kernels (solve_patch / solve_round) walk the drainage DAG level by level: bound by dependency latency, not by HBM (DESIGN.md §5)",
                         families=fams)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -349,11 +349,13 @@ __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, in
 
 // ---------------------------------------------------------------- thermal -----------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_XCD_CELLS(r, F.N) thermal_excess_cell(F, r, talus); }
-// meshes whose largest degree is <= 12 (every Fibonacci/Delaunay mesh seen so far: max 10-11) keep the event list in
-// registers (a 12-entry private array is promoted to VGPRs: 69 VGPRs, no scratch); larger degrees use the LDS form
-__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply_reg12(Fields F, float* out, double talus, double kThermal) {
+// meshes whose largest degree is <= 16 (jittered Fibonacci spheres: 10-11 at 10^4..10^6 cells, 13 at 10^7) keep the event
+// lists in registers (12- or 16-entry private arrays are promoted to VGPRs: 103 / 115 VGPRs, no scratch); larger degrees
+// use the LDS form
+template <int MAXIN>
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply_reg(Fields F, float* out, double talus, double kThermal) {
     WO_XCD_CELLS(r, F.N) {
-        double inShare[12], outShare[12]; int32_t inRank[12];
+        double inShare[MAXIN], outShare[MAXIN]; int32_t inRank[MAXIN];
         out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, 1, outShare);
     }
 }

@@ -405,7 +405,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             Fields F = p->fields();
             launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridN, WO_BLOCK, F, talus);
             if (p->maxDeg <= 12)
-                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg12, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<12>, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+            else if (p->maxDeg <= 16)
+                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<16>, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
             else
                 launch_shmem(p, FAM_THERMAL_APPLY, k_thermal_apply, gridN, WO_BLOCK, (size_t)p->maxDeg * WO_BLOCK * 12, F, p->d_e2, talus, kThermal,
                              (int32_t)p->maxDeg);
