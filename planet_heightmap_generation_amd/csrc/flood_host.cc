@@ -131,28 +131,87 @@ constexpr int32_t UNVISITED = -2, TO_OCEAN = -3, NO_TARGET = -1;
 // first open-ocean neighbour in adjacency order exists, ascending r, :118-128).  Shared by both flood calls of
 // an erodeComposite and kept across calls while the ocean mask is unchanged.
 void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S) {
-    std::vector<int32_t> label(N, -1), stack(N);
-    std::vector<int32_t> sizes;
-    for (int32_t r = 0; r < N; ++r) {
-        if (!ocean[r] || label[r] >= 0) continue;
-        const int32_t lab = (int32_t)sizes.size();
-        int32_t sp = 0, size = 0;
-        stack[sp++] = r; label[r] = lab;
-        while (sp > 0) {
-            const int32_t cur = stack[--sp];
-            ++size;
-            for (int32_t i = off[cur]; i < off[cur + 1]; ++i) {
+    const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flood static] %-12s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+        tp = now;
+    };
+    // Ocean components (:66-94).  The reference labels them by a stack walk in ascending r and keeps the largest, the
+    // first label winning ties — i.e. among the largest components the one holding the smallest cell id.  Only that
+    // choice is observable, so the components come from a concurrent union-find whose roots are the smallest id of
+    // each component (link the larger root under the smaller with a CAS; path halving on the way up).
+    std::vector<int32_t> parentStore(N);
+    int32_t* parent = parentStore.data();
+    auto par = [&](int32_t x) { return reinterpret_cast<std::atomic<int32_t>*>(parent + x); };
+    auto find = [&](int32_t x) {
+        for (;;) {
+            int32_t px = par(x)->load(std::memory_order_relaxed);
+            if (px == x) return x;
+            const int32_t gp = par(px)->load(std::memory_order_relaxed);
+            if (gp != px) par(x)->compare_exchange_weak(px, gp, std::memory_order_relaxed);    // path halving; losing the race is harmless
+            x = gp;
+        }
+    };
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) parent[r] = (int32_t)r; });
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) {
+        for (int64_t r = b; r < e; ++r) {
+            if (!ocean[r]) continue;
+            for (int32_t i = off[r]; i < off[r + 1]; ++i) {
                 const int32_t nb = adj[i];
-                if (ocean[nb] && label[nb] < 0) { label[nb] = lab; stack[sp++] = nb; }
+                if (nb > r || !ocean[nb]) continue;
+                int32_t a = (int32_t)r, c = nb;
+                for (;;) {
+                    a = find(a); c = find(c);
+                    if (a == c) break;
+                    if (a < c) std::swap(a, c);             // a > c: hang a under c
+                    int32_t expect = a;
+                    if (par(a)->compare_exchange_strong(expect, c, std::memory_order_relaxed)) break;
+                }
             }
         }
-        sizes.push_back(size);
+    });
+    // flatten; component sizes per thread as (root, count) runs, merged afterwards
+    std::vector<std::vector<std::pair<int32_t, int64_t>>> runs(host_threads() + 1);
+    parallel_ranges(N, [&](int64_t b, int64_t e, int t) {
+        auto& out = runs[t];
+        int32_t last = -1; int64_t cnt = 0;
+        for (int64_t r = b; r < e; ++r) {
+            if (!ocean[r]) continue;
+            const int32_t root = find((int32_t)r);
+            parent[r] = root;
+            if (root == last) { ++cnt; continue; }
+            if (cnt) out.push_back({last, cnt});
+            last = root; cnt = 1;
+        }
+        if (cnt) out.push_back({last, cnt});
+    });
+    int32_t mainLab = -1;
+    {
+        std::vector<std::pair<int32_t, int64_t>> all;
+        for (auto& v : runs) all.insert(all.end(), v.begin(), v.end());
+        std::sort(all.begin(), all.end());
+        int64_t best = 0;
+        for (size_t i = 0; i < all.size();) {
+            size_t j = i; int64_t sz = 0;
+            while (j < all.size() && all[j].first == all[i].first) sz += all[j++].second;
+            if (sz > best) { best = sz; mainLab = all[i].first; }      // ascending roots: the first of the largest wins
+            i = j;
+        }
     }
-    int32_t mainLab = 0;
-    for (size_t i = 1; i < sizes.size(); ++i) if (sizes[i] > sizes[mainLab]) mainLab = (int32_t)i;
+    const int32_t* label = parent;
+    lap("ocean labels");
     // land cells in Morton order of their positions (identity order when no positions are given)
     std::vector<int32_t> landCells;
-    for (int32_t r = 0; r < N; ++r) if (!ocean[r]) landCells.push_back(r);
+    {
+        std::vector<int64_t> cnt(host_threads() + 2, 0);
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t r = b; r < e; ++r) c += ocean[r] ? 0 : 1; cnt[t + 1] = c; });
+        for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+        landCells.resize(cnt.back());
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t o = cnt[t]; for (int64_t r = b; r < e; ++r) if (!ocean[r]) landCells[o++] = (int32_t)r; });
+    }
     const int32_t L = (int32_t)landCells.size();
     if (xyz && L > 1) {
         std::vector<uint32_t> keys(L);
@@ -165,17 +224,21 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
         });
         radix_sort_u32(keys, landCells);
     }
+    lap("morton sort");
     S.L = L;
     S.landCell.swap(landCells);
-    S.landIndex.assign(N, -1);
-    for (int32_t i = 0; i < L; ++i) S.landIndex[S.landCell[i]] = i;
+    S.landIndex.resize(N);
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) S.landIndex[r] = -1; });
+    parallel_ranges(L, [&](int64_t b, int64_t e, int) { for (int64_t i = b; i < e; ++i) S.landIndex[S.landCell[i]] = (int32_t)i; });
     S.offL.assign(L + 1, 0);
-    for (int32_t i = 0; i < L; ++i) {
-        const int32_t r = S.landCell[i];
-        int32_t c = 0;
-        for (int32_t j = off[r]; j < off[r + 1]; ++j) if (!ocean[adj[j]]) ++c;
-        S.offL[i + 1] = c;
-    }
+    parallel_ranges(L, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i) {
+            const int32_t r = S.landCell[i];
+            int32_t c = 0;
+            for (int32_t j = off[r]; j < off[r + 1]; ++j) if (!ocean[adj[j]]) ++c;
+            S.offL[i + 1] = c;
+        }
+    });
     for (int32_t i = 0; i < L; ++i) S.offL[i + 1] += S.offL[i];
     S.adjL.resize(S.offL[L]);
     parallel_ranges(L, [&](int64_t b, int64_t e, int) {
@@ -185,16 +248,24 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
             for (int32_t j = off[r]; j < off[r + 1]; ++j) { const int32_t nb = adj[j]; if (!ocean[nb]) S.adjL[o++] = S.landIndex[nb]; }
         }
     });
+    lap("compact csr");
     S.seedCell.clear();                     // land index of each seed, in ascending original id
-    for (int32_t r = 0; r < N; ++r) {
-        if (ocean[r]) continue;
-        for (int32_t j = off[r]; j < off[r + 1]; ++j) {
-            const int32_t nb = adj[j];
-            if (ocean[nb] && label[nb] == mainLab) { S.seedCell.push_back(S.landIndex[r]); break; }
-        }
+    {
+        std::vector<std::vector<int32_t>> part(host_threads() + 1);
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) {
+            for (int64_t r = b; r < e; ++r) {
+                if (ocean[r]) continue;
+                for (int32_t j = off[r]; j < off[r + 1]; ++j) {
+                    const int32_t nb = adj[j];
+                    if (ocean[nb] && label[nb] == mainLab) { part[t].push_back(S.landIndex[r]); break; }
+                }
+            }
+        });
+        for (auto& v : part) S.seedCell.insert(S.seedCell.end(), v.begin(), v.end());      // ranges ascend with the thread index
     }
     S.surface.resize(L); S.state.resize(L); S.root.resize(L); S.eL.resize(L);
     S.order.resize(L); S.order2.resize(L); S.bits.resize(L); S.bits2.resize(L); S.list2.resize(L);
+    lap("seeds+alloc");
     S.staticValid = true;
     S.staticN = N;
     ++S.staticVersion;

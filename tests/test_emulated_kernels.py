@@ -66,3 +66,38 @@ def test_emulated_ties_and_flats(emu, oracle):
         rc = emu.emu_erode_composite(mesh.numRegions, P(mesh.adjOffset), P(mesh.adjList), P(e), P(xyz), P(oc), h, 3e-4, 0.5, 1.0, t,
                                      1.16, 0.015, g_, 0.8, P(nd), P(stats))
         assert rc == 0 and np.array_equal(e, ref), (h, t, g_, int((e != ref).sum()))
+
+
+def test_flood_open_ocean_choice(emu, oracle):
+    """The flood seeds only from the largest ocean component, the first one in cell order winning ties
+    (js/terrain-post.js:66-94).  Masks with two equal oceans, with inland seas and with one ocean cell."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(6000, 0.75, 9)
+    N = mesh.numRegions
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    base = oracle.synthetic_terrain(xyz, 9)
+    land = np.abs(base).astype(np.float32) + np.float32(0.01)
+    masks = []
+    # two polar caps: mirror images need not be equal in cell count, so shave the larger one down to a tie
+    y = xyz.reshape(-1, 3)[:, 1]
+    cap_n = np.flatnonzero(y > 0.8)
+    cap_s = np.flatnonzero(y < -0.8)
+    k = min(cap_n.size, cap_s.size)
+    order_n = cap_n[np.argsort(-y[cap_n], kind="stable")][:k]
+    order_s = cap_s[np.argsort(y[cap_s], kind="stable")][:k]
+    m = np.zeros(N, np.uint8); m[order_n] = 1; m[order_s] = 1
+    masks.append(m)
+    # a big ocean plus inland seas that touch land the main ocean never reaches
+    m = (base <= -0.05).astype(np.uint8)
+    masks.append(m)
+    # a single ocean cell; and an ocean made of isolated single cells (all components tie at size 1)
+    m = np.zeros(N, np.uint8); m[1234] = 1
+    masks.append(m)
+    m = np.zeros(N, np.uint8); m[[17, 2500, 5800]] = 1
+    masks.append(m)
+    for i, oc in enumerate(masks):
+        e0 = np.where(oc == 1, np.float32(-0.2), land).astype(np.float32)
+        ref = oracle.priority_flood_carve(om, e0, oc, 0.5)
+        e = e0.copy()
+        emu.emu_flood(N, P(mesh.adjOffset), P(mesh.adjList), P(e), P(oc), 0.5)
+        assert np.array_equal(e, ref), (i, int((e != ref).sum()))
