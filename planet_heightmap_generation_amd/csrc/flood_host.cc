@@ -53,9 +53,9 @@ inline double cell_noise(int32_t r) {
 // never changes afterwards, so carrying the key next to the cell compares the same values.
 using HeapItem = FloodHeapItem;
 struct KeyHeap {
-    std::vector<HeapItem>& d;
+    hvec<HeapItem>& d;
     size_t n = 0;
-    explicit KeyHeap(std::vector<HeapItem>& storage) : d(storage) {}
+    explicit KeyHeap(hvec<HeapItem>& storage) : d(storage) {}
     void push(int32_t c, float kc) {
         size_t i = n++;
         if (d.size() < n + 2) d.resize(d.size() * 2 + 1024);
@@ -68,7 +68,10 @@ struct KeyHeap {
         }
         h[i] = HeapItem{kc, c};
     }
-    int32_t pop() {      // selects instead of branches; slots n, n+1 hold +inf so absent children lose
+    // The reference's sift-down (:33-45) takes the left child unless the right one is strictly smaller and stops when
+    // that child is not smaller than the moving item; choosing the child first keeps the item's key off the
+    // dependency chain between levels (load pair -> compare -> index), which is what bounds a pop.
+    int32_t pop() {      // slots n, n+1 hold +inf so an absent right child loses
         HeapItem* h = d.data();
         const int32_t top = h[0].cell;
         const HeapItem last = h[--n];
@@ -79,12 +82,8 @@ struct KeyHeap {
             for (;;) {
                 const size_t l = 2 * i + 1;
                 if (l >= n) break;
-                const float kl = h[l].key, kr = h[l + 1].key;
-                const bool a = kl < kc;
-                const float mk = a ? kl : kc;
-                size_t s = a ? l : i;
-                s = (kr < mk) ? l + 1 : s;
-                if (s == i) break;
+                const size_t s = l + (h[l + 1].key < h[l].key ? 1 : 0);
+                if (!(h[s].key < kc)) break;
                 h[i] = h[s];
                 i = s;
             }
@@ -109,9 +108,10 @@ inline uint32_t spread3(uint32_t v) {           // 10 bits -> every third bit
     return v;
 }
 
-void radix_sort_u32(std::vector<uint32_t>& keys, std::vector<int32_t>& vals) {     // stable LSD, 11/11/10 bits
+template <class KV, class VV>
+void radix_sort_u32(KV& keys, VV& vals) {     // stable LSD, 11/11/10 bits
     const size_t n = keys.size();
-    std::vector<uint32_t> k2(n); std::vector<int32_t> v2(n);
+    KV k2(n); VV v2(n);
     for (int pass = 0; pass < 3; ++pass) {
         const int sh = pass * 11; const uint32_t mask = pass == 2 ? 1023u : 2047u;
         uint32_t cnt[2049]; std::memset(cnt, 0, sizeof(cnt));
@@ -204,7 +204,7 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     const int32_t* label = parent;
     lap("ocean labels");
     // land cells in Morton order of their positions (identity order when no positions are given)
-    std::vector<int32_t> landCells;
+    hvec<int32_t> landCells;
     {
         std::vector<int64_t> cnt(host_threads() + 2, 0);
         parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t r = b; r < e; ++r) c += ocean[r] ? 0 : 1; cnt[t + 1] = c; });

@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 
+#include "host_util.h"
+
 namespace wo {
 
 // mesh_builder.cc
@@ -19,13 +21,13 @@ struct FloodCell { float e; int32_t drain; };
 struct FloodScratch {
     // static per (mesh, positions, ocean mask)
     bool staticValid = false; int32_t staticN = -1; int32_t L = 0; int64_t staticVersion = 0;
-    std::vector<int32_t> landCell, landIndex, offL, adjL, seedCell;
+    hvec<int32_t> landCell, landIndex, offL, adjL, seedCell;
     // per call (land-index space)
-    std::vector<float> surface, eL;
-    std::vector<FloodCell> state;
-    std::vector<int32_t> root, order, order2, list2;
-    std::vector<uint32_t> bits, bits2;
-    std::vector<FloodHeapItem> heapStore;
+    hvec<float> surface, eL;
+    hvec<FloodCell> state;
+    hvec<int32_t> root, order, order2, list2;
+    hvec<uint32_t> bits, bits2;
+    hvec<FloodHeapItem> heapStore;
 };
 // (re)builds the mask-dependent tables (Morton-ordered land list `landCell`, compact CSR, seeds)
 void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S);
