@@ -37,19 +37,18 @@ namespace wo {
 constexpr int WO_MAX_DEG = 24;          // planets with a larger vertex degree are rejected at creation
 constexpr int32_t WO_NOT_DONE = 0x7fffffff;
 
-// ---- solve dataflow records (one 64-byte record in, one 16-byte record out per task) ----
+// ---- solve dataflow records (one 48-byte record in, one 16-byte record out per task) ----
 // Everything a turn of the implicit solve needs that does not depend on other turns is gathered once, in
-// index order, by solve_setup; a round then costs: list entry -> task record -> <=3 predecessor granules.
+// index order, by solve_setup; a round then costs: task record -> <=3 predecessor granules.
+// Records are stored at the task's *store index*: the cell id, or — for the patch-local solve — the cell's slot in
+// the Morton-ordered patch list, so that a patch's records are contiguous (Fields::slotOf, store_index()).
 struct alignas(16) SolveTask {
-    int32_t predSelf, predT, predT2;   // granule index 2*cell + (0: that cell's own turn, 1: its deposit on its receiver), -1: none
-    int32_t target;                    // drainTarget[r]
+    int32_t predSelf, predT, predT2;   // granule index 2*store + (0: that task's own turn, 1: its deposit on its receiver), -1: none
+    uint32_t flags;                    // bit0: target is ocean, bit1: t2 is ocean, bit2: has a target, bit3: has a t2
     float e0r, e0t, e0t2;              // heights before the pass (used where there is no predecessor event)
     float flow;                        // flow[r]
     float cellDist, cellDistT;         // cellDist[r], cellDist[target]
-    int32_t t2;                        // drainTarget[target] or -1
-    uint32_t flags;                    // bit0: target is ocean, bit1: t2 is ocean
-    int32_t lpSelf, lpT, lpT2;         // patch-local granule index (2*slotInPatch + which) when the predecessor task
-    int32_t pad_;                      //   belongs to the same spatial patch as r, else -1 (solve_patch kernel)
+    int32_t pad_[2];
 };
 constexpr int WO_PATCH = 512;          // land cells (= solve tasks) per spatial patch / workgroup
 // {value, round tag}: tag 0 = not produced yet.  Written once per pass, consumed only by later rounds.
@@ -77,9 +76,10 @@ struct Fields {
     uint32_t* accA; uint32_t* accB;     // pointer-doubling accumulators [N]
     int32_t* jumpA; int32_t* jumpB;     // pointer-doubling ancestors [N]
     // solve dataflow
-    SolveTask* task;                    // per-land-cell task record built by solve_setup [N]
-    const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean / unset [N]
-    SolveOut* out;                      // per-cell event outputs {own turn, deposit on receiver} [N]
+    SolveTask* task;                    // per-land-cell task record built by solve_setup [N], at the store index
+    const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean [N]; nullptr: store index = cell
+    SolveOut* out;                      // per-task event outputs {own turn, deposit on receiver} [N], at the store index
+    int32_t* blk;                       // patch solve: granule that was seen unresolved when the task last failed, or -1 [N], at the store index
     int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]
     // thermal
     double* totalExcess;                // [N]
@@ -272,58 +272,55 @@ WO_HD inline int32_t latest_event_before(const Fields& F, int32_t x, int32_t r) 
     return best;
 }
 
+WO_HD inline int32_t store_index(const Fields& F, int32_t cell) { return F.slotOf ? F.slotOf[cell] : cell; }
 // granule index of the event task p leaves on location x (p == x: own turn, else deposit)
-WO_HD inline int32_t granule_index(int32_t x, int32_t p) { return p < 0 ? -1 : 2 * p + (p == x ? 0 : 1); }
+WO_HD inline int32_t granule_index(const Fields& F, int32_t x, int32_t p) { return p < 0 ? -1 : 2 * store_index(F, p) + (p == x ? 0 : 1); }
 
 WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
     if (F.ocean[r]) return;
     SolveTask T;
     const int32_t t = F.target[r];
-    T.target = t;
-    T.predSelf = granule_index(r, latest_event_before(F, r, r));
-    T.predT = -1; T.predT2 = -1; T.t2 = -1; T.flags = 0;
+    T.predSelf = granule_index(F, r, latest_event_before(F, r, r));
+    T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
     T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
     T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
     if (t >= 0) {
+        T.flags |= 4u;
         T.e0t = F.e[t];
         if (F.ocean[t]) T.flags |= 1u;
         else {
-            T.predT = granule_index(t, latest_event_before(F, t, r));
+            T.predT = granule_index(F, t, latest_event_before(F, t, r));
             const int32_t t2 = F.target[t];
             T.cellDistT = F.cellDist[t];
             if (t2 >= 0 && T.cellDistT > 0) {
-                T.t2 = t2;
+                T.flags |= 8u;
                 T.e0t2 = F.e[t2];
                 if (F.ocean[t2]) T.flags |= 2u;
-                else T.predT2 = granule_index(t2, latest_event_before(F, t2, r));
+                else T.predT2 = granule_index(F, t2, latest_event_before(F, t2, r));
             }
         }
     }
-    T.lpSelf = T.lpT = T.lpT2 = -1; T.pad_ = 0;
-    if (F.slotOf) {
-        const int32_t myPatch = F.slotOf[r] / WO_PATCH;
-        auto local = [&](int32_t g) -> int32_t {
-            if (g < 0) return -1;
-            const int32_t s = F.slotOf[g >> 1];
-            return (s >= 0 && s / WO_PATCH == myPatch) ? ((s % WO_PATCH) * 2 + (g & 1)) : -1;
-        };
-        T.lpSelf = local(T.predSelf); T.lpT = local(T.predT); T.lpT2 = local(T.predT2);
-    }
-    F.task[r] = T;
+    const int32_t si = store_index(F, r);
+    F.task[si] = T;
     SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
-    F.out[r] = z;
+    F.out[si] = z;
+    // any unresolved predecessor is a valid first blocker; the receiver's event usually resolves last
+    if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
 }
 
-// one turn of the implicit solve + deposition (js/terrain-post.js:616-640) given its three inputs
-WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, double et2, int32_t tag, double K, double m, double dt) {
-    SolveOut o;
-    o.self.tag = tag; o.dep.tag = tag;
-    if (T.target < 0) {          // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
-        o.self.v = (float)er; o.dep.v = 0; return o;
-    }
+// one turn of the implicit solve + deposition (js/terrain-post.js:616-640) given its three inputs.
+// solve_factor is the part that does not depend on the predecessors (callers on a dependency chain hoist it).
+WO_HD inline double solve_factor(const SolveTask& T, double K, double m, double dt) {
     const double fl = T.flow;
     const double pw = (m == 0.5) ? sqrt(fl) : pow(fl, m);
-    const double factor = K * pw * dt / (double)T.cellDist;
+    return K * pw * dt / (double)T.cellDist;
+}
+WO_HD inline SolveOut solve_apply(const SolveTask& T, double factor, double er, double et, double et2, int32_t tag) {
+    SolveOut o;
+    o.self.tag = tag; o.dep.tag = tag;
+    if (!(T.flags & 4u)) {       // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
+        o.self.v = (float)er; o.dep.v = 0; return o;
+    }
     const double hr = et > 0 ? et : 0;
     double hn = (er + factor * hr) / (1 + factor);
     if (hn < hr) hn = hr;
@@ -332,7 +329,7 @@ WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, do
     float tval = (float)et;
     if (eroded > 0 && !(T.flags & 1u)) {
         double slope = 0;
-        if (T.t2 >= 0) slope = fabs(et - et2) / (double)T.cellDistT;
+        if (T.flags & 8u) slope = fabs(et - et2) / (double)T.cellDistT;
         const double depositFrac = 0.5 / (1 + slope * 50);
         const double deposit = eroded * depositFrac;
         tval = (float)(et + deposit);
@@ -341,8 +338,12 @@ WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, do
     o.self.v = (float)hn; o.dep.v = tval;
     return o;
 }
+WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, double et2, int32_t tag, double K, double m, double dt) {
+    return solve_apply(T, solve_factor(T, K, m, dt), er, et, et2, tag);
+}
 
-// Returns true when the task ran (all predecessors were produced in rounds < round).
+// Returns true when the task ran (all predecessors were produced in rounds < round).  Level-round schedule only
+// (store index = cell id).
 WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K, double m, double dt) {
     const SolveTask T = F.task[r];
     const Granule* G = reinterpret_cast<const Granule*>(F.out);
@@ -366,7 +367,7 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
         if (k < bestRank) { best = n; bestRank = k; }
     }
     if (best < 0) return F.e[x];
-    return (best == x) ? F.out[x].self.v : F.out[best].dep.v;
+    return (best == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, best)].dep.v;
 }
 
 // ------------------------------------------------------------------------------------------------

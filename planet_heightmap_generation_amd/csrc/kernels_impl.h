@@ -254,77 +254,110 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
 // boundary.  The dataflow is single-assignment, so the bits do not depend on the schedule (same results as the
 // level-synchronous rounds; checked by the parity tests).  patchPending[p] = tasks of patch p still waiting.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int WO_PATCH_THREADS = 512;                      // threads per patch workgroup
-constexpr int WO_PATCH_TPT = WO_PATCH / WO_PATCH_THREADS;   // tasks per thread (kept in registers)
-__global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, const int32_t* patchOrder, int32_t L, int32_t launchTag,
+constexpr int WO_PATCH_THREADS = WO_PATCH;                 // one task per thread
+constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;
+#ifndef WO_PATCH_SLEEP
+#define WO_PATCH_SLEEP 2                                    // x64 clocks between polls
+#endif               // passes of one wave over its tasks before it gives up for this launch
+// Inside a launch the waves of a patch do not meet at barriers: every task polls its patch-local predecessors in LDS
+// and runs as soon as they are there (value stored before tag, tag read before value; LDS operations of a wave stay
+// in order).  A task whose external predecessors are not from an earlier launch marks its granules BLOCKED (-1), and
+// a task that finds a blocked predecessor blocks itself, so every task of the visit ends up done or blocked and each
+// wave leaves its loop; blocked marks live in LDS only.  The set of tasks that complete in a launch (and therefore
+// every tag) is the same as with barrier-separated sub-rounds; only the waiting is finer grained.
+// Most tasks of an inland patch stay blocked for many launches.  F.blk remembers, per task, one granule that was
+// unresolved when the task last failed (initially the receiver's event).  A visit first settles, from those words
+// alone, which tasks are certainly still blocked: a task is if its remembered blocker is an external granule that is
+// not there yet, or a patch-local task that is itself certainly blocked (chains settle by polling LDS).  Only the
+// other tasks load their 48-byte records and look at all three predecessors.
+__global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int32_t L, int32_t launchTag,
                                                                    int32_t* patchPending, int32_t* totalPending, double K, double m, double dt) {
     __shared__ Granule s_out[2 * WO_PATCH];
-    __shared__ int32_t s_prog[2];
+    __shared__ int32_t s_st[WO_PATCH];                      // 0 unsettled, 1 certainly blocked, 2 candidate or done
+    __shared__ int32_t s_left;
     const int p = blockIdx.x, tid = threadIdx.x;
     if (patchPending[p] == 0) return;                       // block-uniform
-    SolveTask T[WO_PATCH_TPT];
-    double er[WO_PATCH_TPT], et[WO_PATCH_TPT], et2[WO_PATCH_TPT];
-    int32_t cell[WO_PATCH_TPT];
-    bool done[WO_PATCH_TPT], ext[WO_PATCH_TPT];
     const Granule* G = reinterpret_cast<const Granule*>(F.out);
-#pragma unroll
-    for (int q = 0; q < WO_PATCH_TPT; ++q) {
-        const int ls = q * WO_PATCH_THREADS + tid;           // slot inside the patch (coalesced across the workgroup)
-        const int32_t slot = p * WO_PATCH + ls;
-        const bool have = slot < L;
-        cell[q] = have ? patchOrder[slot] : 0;
-        SolveOut mine; mine.self.v = 0; mine.self.tag = 0; mine.dep.v = 0; mine.dep.tag = 0;
-        if (have) mine = F.out[cell[q]];
-        done[q] = !have || mine.self.tag != 0;
-        s_out[2 * ls] = mine.self; s_out[2 * ls + 1] = mine.dep;
-        ext[q] = false; er[q] = et[q] = et2[q] = 0;
-        if (!done[q]) {
-            T[q] = F.task[cell[q]];
-            er[q] = T[q].e0r; et[q] = T[q].e0t; et2[q] = T[q].e0t2;
-            bool ok = true;
-            if (T[q].predSelf >= 0 && T[q].lpSelf < 0) { const Granule g = G[T[q].predSelf]; if (g.tag == 0 || g.tag >= launchTag) ok = false; else er[q] = g.v; }
-            if (T[q].predT >= 0 && T[q].lpT < 0)       { const Granule g = G[T[q].predT];    if (g.tag == 0 || g.tag >= launchTag) ok = false; else et[q] = g.v; }
-            if (T[q].predT2 >= 0 && T[q].lpT2 < 0)     { const Granule g = G[T[q].predT2];   if (g.tag == 0 || g.tag >= launchTag) ok = false; else et2[q] = g.v; }
-            ext[q] = ok;
+    const int32_t s = p * WO_PATCH + tid;                   // store index = patch slot
+    const int32_t base = 2 * p * WO_PATCH;                  // first granule of this patch
+    const bool have = s < L;
+    SolveOut mine; mine.self.v = 0; mine.self.tag = 0; mine.dep.v = 0; mine.dep.tag = 0;
+    if (have) mine = F.out[s];
+    bool done = !have || mine.self.tag != 0;
+    auto is_local = [&](int32_t g) { return (uint32_t)(g - base) < (uint32_t)(2 * WO_PATCH); };
+    auto ext_ready = [&](int32_t g, double& v) {            // external granule produced in an earlier launch?
+        const Granule q = G[g];
+        if (q.tag == 0 || q.tag >= launchTag) return false;
+        v = q.v; return true;
+    };
+    // ---- settle the remembered blockers
+    int32_t st = 2, waitOn = -1;
+    if (!done) {
+        const int32_t b = F.blk[s];
+        if (b >= 0) {
+            if (is_local(b)) { st = 0; waitOn = (b - base) >> 1; }
+            else { double unused; st = ext_ready(b, unused) ? 2 : 1; }
         }
     }
-    if (tid < 2) s_prog[tid] = 0;
-    __syncthreads();
-    int par = 0;
-    for (;;) {
-        SolveOut o[WO_PATCH_TPT];
-        bool ran[WO_PATCH_TPT];
-#pragma unroll
-        for (int q = 0; q < WO_PATCH_TPT; ++q) {
-            ran[q] = false;
-            if (!done[q] && ext[q]) {
-                bool ok = true;
-                double a = er[q], b = et[q], c = et2[q];
-                if (T[q].lpSelf >= 0) { const Granule g = s_out[T[q].lpSelf]; if (g.tag == 0) ok = false; else a = g.v; }
-                if (T[q].lpT >= 0)    { const Granule g = s_out[T[q].lpT];    if (g.tag == 0) ok = false; else b = g.v; }
-                if (T[q].lpT2 >= 0)   { const Granule g = s_out[T[q].lpT2];   if (g.tag == 0) ok = false; else c = g.v; }
-                if (ok) { o[q] = solve_compute(T[q], a, b, c, launchTag, K, m, dt); F.out[cell[q]] = o[q]; ran[q] = true; }
-            }
-        }
-        __syncthreads();                                   // every read of s_out for this sub-round is done
-        bool any = false;
-#pragma unroll
-        for (int q = 0; q < WO_PATCH_TPT; ++q)
-            if (ran[q]) { const int ls = q * WO_PATCH_THREADS + tid; s_out[2 * ls] = o[q].self; s_out[2 * ls + 1] = o[q].dep; done[q] = true; any = true; }
-        if (any) s_prog[par] = 1;
-        if (tid == 0) s_prog[par ^ 1] = 0;
-        __syncthreads();
-        if (s_prog[par] == 0) break;                       // block-uniform: nobody advanced, the rest waits for other patches
-        par ^= 1;
-    }
-    int mineLeft = 0;
-#pragma unroll
-    for (int q = 0; q < WO_PATCH_TPT; ++q) mineLeft += done[q] ? 0 : 1;
-    // block total of the still-pending tasks
-    __shared__ int32_t s_left;
+    s_st[tid] = st;
     if (tid == 0) s_left = 0;
     __syncthreads();
-    if (mineLeft) atomicAdd(&s_left, mineLeft);
+    volatile int32_t* vst = s_st;
+    for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
+        if (st == 0) { const int32_t w = vst[waitOn]; if (w != 0) { st = w; vst[tid] = w; } }
+    }
+    // ---- candidates load their record and check the external predecessors
+    SolveTask T;
+    double er = 0, et = 0, et2 = 0, factor = 0;
+    bool unresolved = !done && st == 2;
+    if (!__syncthreads_or(unresolved)) {                    // nothing can move in this patch: same pending count as before
+        if (tid == 0) atomicAdd(totalPending, patchPending[p]);
+        return;
+    }
+    if (unresolved) {
+        T = F.task[s];
+        er = T.e0r; et = T.e0t; et2 = T.e0t2;
+        int32_t fail = -1;
+        if (T.predSelf >= 0 && !is_local(T.predSelf) && !ext_ready(T.predSelf, er)) fail = T.predSelf;
+        if (T.predT >= 0 && !is_local(T.predT) && !ext_ready(T.predT, et)) fail = T.predT;
+        if (T.predT2 >= 0 && !is_local(T.predT2) && !ext_ready(T.predT2, et2)) fail = T.predT2;
+        if (fail >= 0) { F.blk[s] = fail; unresolved = false; }
+        else factor = solve_factor(T, K, m, dt);
+    }
+    if (!done && !unresolved) { mine.self.tag = -1; mine.dep.tag = -1; }
+    s_out[2 * tid] = mine.self; s_out[2 * tid + 1] = mine.dep;
+    __syncthreads();
+    // ---- run: poll the patch-local predecessors
+    volatile Granule* vs = s_out;
+    for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(unresolved); ++spin) {
+        // a wave that only waits should not compete for issue slots with the waves that carry a chain
+        if (spin) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
+        if (!unresolved) continue;
+        int32_t open = 0, fail = -1;
+        double a = er, b = et, c = et2;
+        auto rd = [&](int32_t g, double& v) {
+            if (g < 0 || !is_local(g)) return;
+            const int32_t tg = vs[g - base].tag;
+            if (tg < 0) fail = g;
+            else if (tg == 0) open = 1;
+            else v = vs[g - base].v;
+        };
+        rd(T.predSelf, a); rd(T.predT, b); rd(T.predT2, c);
+        if (fail >= 0) {
+            F.blk[s] = fail;
+            vs[2 * tid].tag = -1; vs[2 * tid + 1].tag = -1;
+            unresolved = false;
+        } else if (!open) {
+            const SolveOut o = solve_apply(T, factor, a, b, c, launchTag);
+            F.out[s] = o;
+            vs[2 * tid].v = o.self.v; vs[2 * tid + 1].v = o.dep.v;
+            __threadfence_block();                          // values before tags
+            vs[2 * tid].tag = launchTag; vs[2 * tid + 1].tag = launchTag;
+            unresolved = false; done = true;
+        }
+    }
+    // block total of the still-pending tasks
+    if (!done) atomicAdd(&s_left, 1);
     __syncthreads();
     if (tid == 0) { const int32_t left = s_left; patchPending[p] = left; if (left) atomicAdd(totalPending, left); }
 }
@@ -343,7 +376,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const in
 }
 
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level) {
-    WO_XCD_CELLS(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[r].self.tag; }
+    WO_XCD_CELLS(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[store_index(F, r)].self.tag; }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 

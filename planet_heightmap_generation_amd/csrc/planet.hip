@@ -56,7 +56,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
     p->d_iceUp = dalloc<uint8_t>(N);
     p->d_listA = dalloc<int32_t>(N); p->d_listB = dalloc<int32_t>(N); p->d_counters = dalloc<int32_t>(8);
-    p->d_patchOrder = dalloc<int32_t>(N); p->d_slotOf = dalloc<int32_t>(N); p->d_patchPending = dalloc<int32_t>(N / WO_PATCH + 2);
+    p->d_patchOrder = dalloc<int32_t>(N); p->d_slotOf = dalloc<int32_t>(N); p->d_patchPending = dalloc<int32_t>(N / WO_PATCH + 2); p->d_patchBlk = dalloc<int32_t>(N);
     p->d_level = dalloc<int32_t>(N); p->d_byLevel = dalloc<int32_t>(N); p->d_levelStart = dalloc<int32_t>(WO_MAX_LEVEL + 2);
     WO_HIP(hipHostMalloc((void**)&p->h_levelStart, (WO_MAX_LEVEL + 2) * sizeof(int32_t)));
     p->sortTempBytes = sort_temp_bytes(p->N);
@@ -72,7 +72,7 @@ wo::Fields wo_planet::fields() const {
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
-    F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.doneAt = d_doneAt;
+    F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
     return F;
 }
@@ -233,7 +233,7 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         const int burst = (tag == 1) ? std::max<int>(1, (int)p->lastPatchLaunches - 1) : 3;
         for (int b = 0; b < burst; ++b, ++tag) {
             WO_HIP(hipMemsetAsync(c + 6, 0, sizeof(int32_t), s));
-            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, (const int32_t*)p->d_patchOrder, p->L, tag, p->d_patchPending, c + 6, K, m, dt);
+            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, c + 6, K, m, dt);
             ++launches;
         }
         if (read_count(p, c + 6) == 0) break;
@@ -571,7 +571,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
-    dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending);
+    dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);
     dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
     if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);
     if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);

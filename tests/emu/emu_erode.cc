@@ -21,7 +21,7 @@ struct Emu {
     std::vector<uint8_t> coast, iceUp;
     std::vector<float> e2, cellDist, flow, glac, iceFlow;
     std::vector<SolveTask> task; std::vector<SolveOut> out;
-    std::vector<int32_t> land, landIdx, rank, target, jumpA, doneAt, iceTarget, arank, blocker;
+    std::vector<int32_t> land, landIdx, rank, target, jumpA, doneAt, iceTarget, arank, blocker, blk;
     std::vector<uint32_t> accA;
     std::vector<double> totalExcess;
     int64_t solveRounds = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, maxSolveRounds = 0;
@@ -82,15 +82,14 @@ int64_t run_solve_rounds_pred(Emu& E, std::vector<int32_t>& level, double K, dou
         if (round + LOOKAHEAD >= maxPred && left.empty()) break;
         if (round > 8 * (int64_t)F.N) return -round;
     }
-    for (int32_t r : E.landIdx) level[r] = F.out[r].self.tag;
+    for (int32_t r : E.landIdx) level[r] = F.out[store_index(F, r)].self.tag;
     return round;
 }
 
-// patch-local solve schedule, mirroring k_solve_patch / run_solve_patches: external predecessors must come from an
-// earlier launch, patch-local ones from any earlier sub-round
-int64_t run_solve_patches_emu(Emu& E, const std::vector<int32_t>& patchOrder, double K, double m, double dt) {
+// patch-local solve schedule, mirroring k_solve_patch / run_solve_patches: records live at the patch slot, external
+// predecessors must come from an earlier launch, patch-local ones from any earlier point of the same visit
+int64_t run_solve_patches_emu(Emu& E, int32_t L, double K, double m, double dt) {
     const Fields& F = E.F;
-    const int32_t L = (int32_t)patchOrder.size();
     const int32_t np = (L + WO_PATCH - 1) / WO_PATCH;
     const Granule* G = reinterpret_cast<const Granule*>(F.out);
     int64_t launches = 0;
@@ -99,32 +98,31 @@ int64_t run_solve_patches_emu(Emu& E, const std::vector<int32_t>& patchOrder, do
         int64_t pending = 0;
         for (int32_t p = 0; p < np; ++p) {
             const int32_t s0 = p * WO_PATCH, s1 = std::min(L, s0 + WO_PATCH);
+            auto local = [&](int32_t g) { return g >= 2 * s0 && g < 2 * (s0 + WO_PATCH); };
             std::vector<uint8_t> ext(s1 - s0, 0);
             std::vector<double> er(s1 - s0), et(s1 - s0), et2(s1 - s0);
             for (int32_t s = s0; s < s1; ++s) {
-                const int32_t c = patchOrder[s];
-                if (F.out[c].self.tag != 0) continue;
-                const SolveTask& T = F.task[c];
+                if (F.out[s].self.tag != 0) continue;
+                const SolveTask& T = F.task[s];
                 bool ok = true; double a = T.e0r, b = T.e0t, d = T.e0t2;
-                auto extp = [&](int32_t g, int32_t lp, double& v) { if (g >= 0 && lp < 0) { const Granule q = G[g]; if (q.tag == 0 || q.tag >= tag) ok = false; else v = q.v; } };
-                extp(T.predSelf, T.lpSelf, a); extp(T.predT, T.lpT, b); extp(T.predT2, T.lpT2, d);
+                auto extp = [&](int32_t g, double& v) { if (g >= 0 && !local(g)) { const Granule q = G[g]; if (q.tag == 0 || q.tag >= tag) ok = false; else v = q.v; } };
+                extp(T.predSelf, a); extp(T.predT, b); extp(T.predT2, d);
                 ext[s - s0] = ok; er[s - s0] = a; et[s - s0] = b; et2[s - s0] = d;
             }
-            for (;;) {                      // sub-rounds: results of a sub-round become visible to the next one
+            for (;;) {                      // sweeps: results of a sweep become visible to the next one
                 std::vector<std::pair<int32_t, SolveOut>> produced;
                 for (int32_t s = s0; s < s1; ++s) {
-                    const int32_t c = patchOrder[s];
-                    if (F.out[c].self.tag != 0 || !ext[s - s0]) continue;
-                    const SolveTask& T = F.task[c];
+                    if (F.out[s].self.tag != 0 || !ext[s - s0]) continue;
+                    const SolveTask& T = F.task[s];
                     bool ok = true; double a = er[s - s0], b = et[s - s0], d = et2[s - s0];
-                    auto loc = [&](int32_t lp, double& v) { if (lp >= 0) { const Granule q = G[2 * patchOrder[s0 + lp / 2] + (lp & 1)]; if (q.tag == 0) ok = false; else v = q.v; } };
-                    loc(T.lpSelf, a); loc(T.lpT, b); loc(T.lpT2, d);
-                    if (ok) produced.push_back({c, solve_compute(T, a, b, d, tag, K, m, dt)});
+                    auto loc = [&](int32_t g, double& v) { if (g >= 0 && local(g)) { const Granule q = G[g]; if (q.tag == 0) ok = false; else v = q.v; } };
+                    loc(T.predSelf, a); loc(T.predT, b); loc(T.predT2, d);
+                    if (ok) produced.push_back({s, solve_compute(T, a, b, d, tag, K, m, dt)});
                 }
                 if (produced.empty()) break;
                 for (auto& pr : produced) F.out[pr.first] = pr.second;
             }
-            for (int32_t s = s0; s < s1; ++s) if (F.out[patchOrder[s]].self.tag == 0) ++pending;
+            for (int32_t s = s0; s < s1; ++s) if (F.out[s].self.tag == 0) ++pending;
         }
         if (pending == 0) break;
         if (launches > 8 * (int64_t)F.N) return -launches;
@@ -151,7 +149,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     F.e2 = E.e2.data(); F.rank = E.rank.data(); F.target = E.target.data(); F.cellDist = E.cellDist.data();
     F.flow = E.flow.data(); F.accA = E.accA.data(); F.jumpA = E.jumpA.data(); F.task = E.task.data(); F.out = E.out.data();
     F.doneAt = E.doneAt.data(); F.totalExcess = E.totalExcess.data(); F.glac = E.glac.data();
-    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data(); E.blocker.assign(N, -1); F.blocker = E.blocker.data();
+    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data(); E.blocker.assign(N, -1); F.blocker = E.blocker.data(); E.blk.assign(N, -1); F.blk = E.blk.data();
     F.coast = E.coast.data();
     for (int32_t r = 0; r < N; ++r) E.coast[r] = coast_flag(F, r);
     for (int32_t r = 0; r < N; ++r) if (!ocean[r]) E.land.push_back(r);
@@ -223,7 +221,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
                 F.flow[c] = (float)f;
             }
             for (int32_t r = 0; r < N; ++r) solve_setup_cell(F, r);
-            int64_t n3 = usePatches ? run_solve_patches_emu(E, E.landIdx, K, m, dt) : run_solve_rounds_pred(E, level, K, m, dt);
+            int64_t n3 = usePatches ? run_solve_patches_emu(E, F.L, K, m, dt) : run_solve_rounds_pred(E, level, K, m, dt);
             if (n3 < 0) rc = 12;
             E.solveRounds += n3; if (n3 > E.maxSolveRounds) E.maxSolveRounds = n3;
             for (int32_t r = 0; r < N; ++r) F.e2[r] = solve_final_cell(F, r);
