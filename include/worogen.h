@@ -122,6 +122,20 @@ int wo_assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plate_tab
                         float* r_elevation, float* r_stress, float* debugLayers,
                         int32_t* mountain_r, int32_t* coastline_r, int32_t* ocean_r, int32_t* setCounts);
 
+/* ------------------------------------------------ plate projection ----------- */
+/* projectCoarsePlates(mesh, r_xyz, coarseMesh, coarse_xyz, coarse_r_plate, seed, numPlates) -> r_plate
+ *                                                                       js/coarse-plates.js:51-117
+ * Runs on the planet's resident r_xyz; the coarse mesh (coarseMesh.adjOffset / adjList, coarse_xyz, coarse_r_plate,
+ * as generateCoarsePlates returns them, js/coarse-plates.js:19-42) is borrowed for the call.  numPlates < 0 stands
+ * for `numPlates == null`.  r_plate: numRegions ints, bit-exact plate ids. */
+int wo_project_coarse_plates(wo_planet* p, int32_t coarseRegions, const int32_t* coarseAdjOffset, const int32_t* coarseAdjList,
+                             const float* coarse_xyz, const int32_t* coarse_r_plate, double seed, int32_t numPlates, int32_t* r_plate);
+/* smoothAndReconnectPlates(mesh, r_plate, plateSeeds, numPasses)         js/plates.js:241-348
+ * Host stage (order-defined in-place passes); needs no GPU.  plateSeeds in the Set's iteration order; r_plate is
+ * rewritten in place. */
+int wo_smooth_reconnect_plates(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, int32_t* r_plate,
+                               const int32_t* plateSeeds, int32_t numPlateSeeds, int32_t numPasses);
+
 /* ------------------------------------------------ device-resident variants -------------------- */
 /* The "reapply" pattern (js/planet-worker.js:341-440): fields stay in HBM, only scalars arrive.
  * wo_planet_upload sets the resident r_elevation (and r_isOcean when not NULL); the *_resident

@@ -40,6 +40,8 @@ def lib() -> C.CDLL:
             getattr(L, f).argtypes = [_i32, _p, _p, _p, _p, _i32, _f64]
         L.wo_or_priority_flood_carve.argtypes = [_i32, _p, _p, _p, _p, _f64]
         L.wo_or_erode_composite.argtypes = [_i32, _p, _p, _p, _p, _p, _i32, _f64, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _p]
+        L.wo_or_project_coarse_plates.argtypes = [_i32, _p, _i32, _p, _p, _p, _p, _f64, _i32, _p]
+        L.wo_or_smooth_reconnect_plates.argtypes = [_i32, _p, _p, _p, _i32, _p, _i32]
         _lib = L
     return _lib
 
@@ -129,3 +131,21 @@ def erode_composite(mesh, r_elevation, r_xyz, r_isOcean, hIters, K, m, dt, tIter
                                 int(hIters), float(K), float(m), float(dt), int(tIters), float(talusSlope), float(kThermal),
                                 int(gIters), float(glacialStrength), _ptr(nd))
     return e
+
+
+def project_coarse_plates(mesh, r_xyz, coarse_mesh, coarse_xyz, coarse_r_plate, seed, numPlates=None) -> np.ndarray:
+    """js/coarse-plates.js:51 projectCoarsePlates -> Int32Array r_plate."""
+    N = mesh.numRegions
+    out = np.empty(N, np.int32)
+    xyz, cxyz, cp = _c(r_xyz, np.float32), _c(coarse_xyz, np.float32), _c(coarse_r_plate, np.int32)
+    lib().wo_or_project_coarse_plates(N, _ptr(xyz), coarse_mesh.numRegions, _ptr(coarse_mesh.adjOffset), _ptr(coarse_mesh.adjList),
+                                      _ptr(cxyz), _ptr(cp), float(seed), -1 if numPlates is None else int(numPlates), _ptr(out))
+    return out
+
+
+def smooth_reconnect_plates(mesh, r_plate, plate_seeds, numPasses) -> np.ndarray:
+    """js/plates.js:241 smoothAndReconnectPlates (returns the updated copy)."""
+    rp = _c(r_plate, np.int32).copy()
+    seeds = _c(np.asarray(list(plate_seeds)), np.int32)
+    lib().wo_or_smooth_reconnect_plates(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(rp), seeds.size, _ptr(seeds), int(numPasses))
+    return rp

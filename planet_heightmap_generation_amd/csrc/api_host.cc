@@ -68,4 +68,15 @@ int wo_noise_tables(double seed, uint8_t* perm512, uint8_t* pm12_512) {
     return 0;
 }
 
+int wo_smooth_reconnect_plates(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, int32_t* r_plate,
+                               const int32_t* plateSeeds, int32_t numPlateSeeds, int32_t numPasses) {
+    if (numRegions < 1 || !adjOffset || !adjList || !r_plate || numPlateSeeds < 0 || (numPlateSeeds > 0 && !plateSeeds)) {
+        wo::set_error("wo_smooth_reconnect_plates: bad arguments"); return 1;
+    }
+    try {
+        wo::smooth_reconnect_plates_host(numRegions, adjOffset, adjList, r_plate, numPlateSeeds, plateSeeds, numPasses);
+    } catch (const std::exception& e) { wo::set_error(std::string("wo_smooth_reconnect_plates: ") + e.what()); return 3; }
+    return 0;
+}
+
 }  // extern "C"

@@ -145,43 +145,15 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     // each component (link the larger root under the smaller with a CAS; path halving on the way up).
     std::vector<int32_t> parentStore(N);
     int32_t* parent = parentStore.data();
-    auto par = [&](int32_t x) { return reinterpret_cast<std::atomic<int32_t>*>(parent + x); };
-    auto find = [&](int32_t x) {
-        for (;;) {
-            int32_t px = par(x)->load(std::memory_order_relaxed);
-            if (px == x) return x;
-            const int32_t gp = par(px)->load(std::memory_order_relaxed);
-            if (gp != px) par(x)->compare_exchange_weak(px, gp, std::memory_order_relaxed);    // path halving; losing the race is harmless
-            x = gp;
-        }
-    };
-    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) parent[r] = (int32_t)r; });
-    parallel_ranges(N, [&](int64_t b, int64_t e, int) {
-        for (int64_t r = b; r < e; ++r) {
-            if (!ocean[r]) continue;
-            for (int32_t i = off[r]; i < off[r + 1]; ++i) {
-                const int32_t nb = adj[i];
-                if (nb > r || !ocean[nb]) continue;
-                int32_t a = (int32_t)r, c = nb;
-                for (;;) {
-                    a = find(a); c = find(c);
-                    if (a == c) break;
-                    if (a < c) std::swap(a, c);             // a > c: hang a under c
-                    int32_t expect = a;
-                    if (par(a)->compare_exchange_strong(expect, c, std::memory_order_relaxed)) break;
-                }
-            }
-        }
-    });
-    // flatten; component sizes per thread as (root, count) runs, merged afterwards
+    mesh_components(N, off, adj, [&](int32_t r) { return ocean[r] != 0; }, [](int32_t, int32_t) { return true; }, parent);
+    // component sizes per thread as (root, count) runs, merged afterwards
     std::vector<std::vector<std::pair<int32_t, int64_t>>> runs(host_threads() + 1);
     parallel_ranges(N, [&](int64_t b, int64_t e, int t) {
         auto& out = runs[t];
         int32_t last = -1; int64_t cnt = 0;
         for (int64_t r = b; r < e; ++r) {
             if (!ocean[r]) continue;
-            const int32_t root = find((int32_t)r);
-            parent[r] = root;
+            const int32_t root = parent[r];
             if (root == last) { ++cnt; continue; }
             if (cnt) out.push_back({last, cnt});
             last = root; cnt = 1;

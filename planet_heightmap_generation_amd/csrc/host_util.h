@@ -1,6 +1,7 @@
 // Host-side helpers shared by the native (non-kernel) parts of libworogen.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -57,6 +58,42 @@ inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
         th.emplace_back([=, &fn]() { fn(b, e, (int)c); });
     }
     for (auto& t : th) t.join();
+}
+
+// Connected components of the cells r with member(r), joined along mesh edges (r, nb) with joined(r, nb): a concurrent
+// union-find (link the larger root under the smaller with a CAS, path halving on the way up).  On return parent[r] is
+// the smallest cell id of r's component (parent[r] == r for non-members).
+template <class Member, class Joined>
+inline void mesh_components(int32_t N, const int32_t* off, const int32_t* adj, Member member, Joined joined, int32_t* parent) {
+    auto par = [&](int32_t x) { return reinterpret_cast<std::atomic<int32_t>*>(parent + x); };
+    auto find = [&](int32_t x) {
+        for (;;) {
+            int32_t px = par(x)->load(std::memory_order_relaxed);
+            if (px == x) return x;
+            const int32_t gp = par(px)->load(std::memory_order_relaxed);
+            if (gp != px) par(x)->compare_exchange_weak(px, gp, std::memory_order_relaxed);    // path halving; losing the race is harmless
+            x = gp;
+        }
+    };
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) parent[r] = (int32_t)r; });
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) {
+        for (int64_t r = b; r < e; ++r) {
+            if (!member((int32_t)r)) continue;
+            for (int32_t i = off[r]; i < off[r + 1]; ++i) {
+                const int32_t nb = adj[i];
+                if (nb > r || !member(nb) || !joined((int32_t)r, nb)) continue;
+                int32_t a = (int32_t)r, c = nb;
+                for (;;) {
+                    a = find(a); c = find(c);
+                    if (a == c) break;
+                    if (a < c) std::swap(a, c);             // a > c: hang a under c
+                    int32_t expect = a;
+                    if (par(a)->compare_exchange_strong(expect, c, std::memory_order_relaxed)) break;
+                }
+            }
+        }
+    });
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) if (member((int32_t)r)) parent[r] = find((int32_t)r); });
 }
 
 // Park-Miller LCG exactly as the reference seeds and steps it (js/rng.js:3-6).

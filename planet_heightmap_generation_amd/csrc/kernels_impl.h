@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device.h"
+#include "plates_ops.h"
 
 namespace wo {
 
@@ -113,6 +114,19 @@ __global__ __launch_bounds__(WO_BLOCK) void k_warp(Fields F, const uint8_t* tabl
         const int32_t src = warp_source_cell(F, sP, sM, r, maxAmp);
         out[r] = warp_blend(in[r], in[src], warpBias, hot != nullptr, hot ? hot[r] : 0.0f);
     }
+}
+
+// ---------------------------------------------------------------- plate projection --------------
+// js/coarse-plates.js:51-117: one thread per hi-res cell (12 noise3D from LDS tables, then a greedy ascent over the
+// 20 k-cell coarse mesh, which stays in L2); the start cells come from a small (z, longitude) bucket grid.
+__global__ __launch_bounds__(WO_BLOCK) void k_plate_grid(CoarsePlates C, int32_t* grid) {
+    WO_GRID_STRIDE(b, C.gridZ * C.gridLon) grid[b] = plate_grid_cell(C, b);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_plate_project(CoarsePlates C, const uint8_t* tables, const float* r_xyz, int32_t N, double perturbAmp,
+                                                             int32_t* r_plate) {
+    __shared__ uint8_t sP[512], sM[512];
+    load_tables(tables, sP, sM);
+    WO_GRID_STRIDE(r, N) r_plate[r] = plate_project_cell(C, sP, sM, r_xyz, r, perturbAmp);
 }
 
 // ---------------------------------------------------------------- land list ---------------------

@@ -23,7 +23,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -750,6 +750,47 @@ int wo_erode_composite(wo_planet* p, float* e, const uint8_t* oc, int32_t hIters
     ErodeArgs a{hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength};
     return with_host_field(p, "wo_erode_composite", e, oc, true,
                            [](wo_planet* q, void* v) { auto* x = (ErodeArgs*)v; erode_composite(q, x->h, x->K, x->m, x->dt, x->t, x->talus, x->kT, x->g, x->gs); }, &a);
+}
+
+// projectCoarsePlates (js/coarse-plates.js:51-117) on the planet's resident r_xyz
+int wo_project_coarse_plates(wo_planet* p, int32_t coarseRegions, const int32_t* coarseAdjOffset, const int32_t* coarseAdjList,
+                             const float* coarse_xyz, const int32_t* coarse_r_plate, double seed, int32_t numPlates, int32_t* r_plate) {
+    if (!check_planet(p, "wo_project_coarse_plates")) return 1;
+    if (coarseRegions < 1 || !coarseAdjOffset || !coarseAdjList || !coarse_xyz || !coarse_r_plate || !r_plate) {
+        set_error("wo_project_coarse_plates: bad arguments"); return 1;
+    }
+    int32_t *d_off = nullptr, *d_adj = nullptr, *d_plate = nullptr, *d_grid = nullptr, *d_out = nullptr; float* d_cxyz = nullptr;
+    WO_TRY
+    hipStream_t s = p->ctx->stream;
+    const int32_t NC = coarseRegions, E = coarseAdjOffset[NC];
+    CoarsePlates C;
+    C.NC = NC; C.gridZ = 64; C.gridLon = 128;
+    d_off = dalloc<int32_t>(NC + 1); d_adj = dalloc<int32_t>(E); d_plate = dalloc<int32_t>(NC); d_cxyz = dalloc<float>(3 * (size_t)NC);
+    d_grid = dalloc<int32_t>((size_t)C.gridZ * C.gridLon); d_out = dalloc<int32_t>(p->N);
+    WO_HIP(hipMemcpyAsync(d_off, coarseAdjOffset, (size_t)(NC + 1) * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(d_adj, coarseAdjList, (size_t)E * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(d_plate, coarse_r_plate, (size_t)NC * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(d_cxyz, coarse_xyz, (size_t)NC * 12, hipMemcpyHostToDevice, s));
+    C.off = d_off; C.adj = d_adj; C.xyz = d_cxyz; C.plate = d_plate; C.grid = nullptr;
+    launch(p, FAM_PLATE_GRID, k_plate_grid, blocks_for((int64_t)C.gridZ * C.gridLon), WO_BLOCK, C, d_grid);
+    C.grid = d_grid;
+    upload_tables(p, seed + 999);                                                       // :57
+    const double coarseEdgeRad = 3.141592653589793 / std::sqrt((double)NC);              // :58
+    double lowPlateT = 0;                                                                // :59 (numPlates < 0: null)
+    if (numPlates >= 0) lowPlateT = std::max(0.0, std::min(1.0, (80 - numPlates) / 60.0));
+    const double perturbAmp = coarseEdgeRad * (1.5 + 1.0 * lowPlateT);                   // :60
+    launch(p, FAM_PLATE_PROJECT, k_plate_project, blocks_for(p->N), WO_BLOCK, C, (const uint8_t*)p->d_tables, (const float*)p->d_xyz, p->N, perturbAmp, d_out);
+    WO_HIP(hipMemcpyAsync(r_plate, d_out, (size_t)p->N * 4, hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    dfree(d_off); dfree(d_adj); dfree(d_plate); dfree(d_cxyz); dfree(d_grid); dfree(d_out);
+    return 0;
+    } catch (const HipError& e) {
+        dfree(d_off); dfree(d_adj); dfree(d_plate); dfree(d_cxyz); dfree(d_grid); dfree(d_out);
+        set_error(std::string("wo_project_coarse_plates: ") + e.msg); return 2;
+    } catch (const std::exception& e) {
+        dfree(d_off); dfree(d_adj); dfree(d_plate); dfree(d_cxyz); dfree(d_grid); dfree(d_out);
+        set_error(std::string("wo_project_coarse_plates: ") + e.what()); return 3;
+    }
 }
 
 int wo_noise_eval(wo_ctx* ctx, double seed, int32_t kind, int32_t octaves, double p0, double p1, double p2, int64_t n,

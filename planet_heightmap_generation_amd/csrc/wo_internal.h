@@ -35,6 +35,10 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);
 
+// plates_host.cc — js/plates.js:241-348 (r_plate rewritten in place; plateSeeds in the Set's iteration order)
+void smooth_reconnect_plates_host(int32_t N, const int32_t* off, const int32_t* adj, int32_t* r_plate, int32_t numSeeds,
+                                  const int32_t* plateSeeds, int32_t numPasses);
+
 // error slot used by every extern "C" entry point (thread-local)
 void set_error(const std::string& msg);
 

@@ -68,3 +68,15 @@ def test_terrain_post_bit_exact(oracle, tag):
         ref = g["ref_" + name]
         assert np.array_equal(got, ref), f"{tag}/{name}: {(got != ref).sum()} cells differ, max {np.abs(got - ref).max():.3e}"
         assert (ref != g["elevation0"]).any(), f"{tag}/{name}: case is a no-op"
+
+
+@pytest.mark.parametrize("name", __import__("plates_common").PLATE_CASES)
+def test_plate_projection_bit_exact(oracle, name):
+    """projectCoarsePlates + smoothAndReconnectPlates vs the reference's own outputs (plate ids are integers: exact)."""
+    from plates_common import plate_case
+    c = plate_case(name)
+    om, oc = oracle.Mesh(c["mesh"].adjOffset, c["mesh"].adjList), oracle.Mesh(c["cmesh"].adjOffset, c["cmesh"].adjList)
+    proj = oracle.project_coarse_plates(om, c["xyz"], oc, c["cxyz"], c["coarse_r_plate"], c["meta"]["seed"], c["meta"]["P"])
+    assert np.array_equal(proj, c["projected"]), int((proj != c["projected"]).sum())
+    sm = oracle.smooth_reconnect_plates(om, c["projected"], c["seeds"], c["meta"]["passes"])
+    assert np.array_equal(sm, c["smoothed"]), int((sm != c["smoothed"]).sum())
