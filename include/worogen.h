@@ -78,6 +78,9 @@ wo_planet* wo_planet_create(wo_ctx* ctx, int32_t numRegions, const int32_t* adjO
 void       wo_planet_destroy(wo_planet* p);
 
 /* ------------------------------------------------ terrain-post, JS call surface --------------- */
+/* mesh.numRegions the planet was created with (0 for a NULL planet) */
+int32_t wo_planet_num_regions(const wo_planet* p);
+
 /* Each mutates r_elevation (host, numRegions floats) in place and returns nothing else, exactly like
  * the five exports of js/terrain-post.js.  r_isOcean is numRegions bytes, read-only. */
 /* warpTerrain(mesh, r_elevation, r_xyz, seed, strength, r_hotspot?)   js/terrain-post.js:233 */

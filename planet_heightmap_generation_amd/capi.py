@@ -39,6 +39,7 @@ SIGNATURES = {
     "wo_ctx_destroy": (None, [_p]),
     "wo_planet_create": (_p, [_p, _c_i32, _p, _p, _p, _p]),
     "wo_planet_destroy": (None, [_p]),
+    "wo_planet_num_regions": (_c_i32, [_p]),
     "wo_warp_terrain": (C.c_int, [_p, _p, _c_f64, _c_f64, _p]),
     "wo_smooth_elevation": (C.c_int, [_p, _p, _p, _c_i32, _c_f64]),
     "wo_erode_composite": (C.c_int, [_p, _p, _p, _c_i32, _c_f64, _c_f64, _c_f64, _c_i32, _c_f64, _c_f64, _c_i32, _c_f64]),

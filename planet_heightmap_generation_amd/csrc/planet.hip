@@ -752,6 +752,8 @@ int wo_erode_composite(wo_planet* p, float* e, const uint8_t* oc, int32_t hIters
                            [](wo_planet* q, void* v) { auto* x = (ErodeArgs*)v; erode_composite(q, x->h, x->K, x->m, x->dt, x->t, x->talus, x->kT, x->g, x->gs); }, &a);
 }
 
+int32_t wo_planet_num_regions(const wo_planet* p) { return p ? p->N : 0; }
+
 // projectCoarsePlates (js/coarse-plates.js:51-117) on the planet's resident r_xyz
 int wo_project_coarse_plates(wo_planet* p, int32_t coarseRegions, const int32_t* coarseAdjOffset, const int32_t* coarseAdjList,
                              const float* coarse_xyz, const int32_t* coarse_r_plate, double seed, int32_t numPlates, int32_t* r_plate) {

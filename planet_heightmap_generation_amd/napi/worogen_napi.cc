@@ -316,6 +316,35 @@ napi_value AssignElevation(napi_env env, napi_callback_info info) {
     return o;
 }
 
+// projectCoarsePlates(planet, coarseAdjOffset, coarseAdjList, coarse_xyz, coarse_r_plate, seed, numPlates|null) -> Int32Array
+napi_value ProjectCoarsePlates(napi_env env, napi_callback_info info) {
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    size_t no, na, nx, np_;
+    int32_t* off = (int32_t*)a.ta(1, napi_int32_array, &no); if (!a.ok) return nullptr;
+    int32_t* adj = (int32_t*)a.ta(2, napi_int32_array, &na); if (!a.ok) return nullptr;
+    float* xyz = (float*)a.ta(3, napi_float32_array, &nx); if (!a.ok) return nullptr;
+    int32_t* pl = (int32_t*)a.ta(4, napi_int32_array, &np_); if (!a.ok) return nullptr;
+    if (no < 2 || nx != 3 * (no - 1) || np_ != no - 1) { napi_throw_range_error(env, nullptr, "coarse mesh arrays do not match"); return nullptr; }
+    const int32_t n = wo_planet_num_regions(p);
+    if (n < 1) return throw_wo(env, "projectCoarsePlates");
+    void* d; napi_value out = make_ta(env, napi_int32_array, (size_t)n, 4, &d);
+    if (wo_project_coarse_plates(p, (int32_t)(no - 1), off, adj, xyz, pl, a.num(5), a.has(6) ? a.i32(6) : -1, (int32_t*)d)) return throw_wo(env, "projectCoarsePlates");
+    return out;
+}
+// smoothAndReconnectPlates(numRegions, adjOffset, adjList, r_plate (in place), plateSeeds Int32Array, numPasses)
+napi_value SmoothAndReconnectPlates(napi_env env, napi_callback_info info) {
+    Args a(env, info);
+    size_t no, na, nr, ns;
+    int32_t* off = (int32_t*)a.ta(1, napi_int32_array, &no); if (!a.ok) return nullptr;
+    int32_t* adj = (int32_t*)a.ta(2, napi_int32_array, &na); if (!a.ok) return nullptr;
+    int32_t* rp = (int32_t*)a.ta(3, napi_int32_array, &nr); if (!a.ok) return nullptr;
+    int32_t* seeds = (int32_t*)a.ta(4, napi_int32_array, &ns); if (!a.ok) return nullptr;
+    const int32_t n = a.i32(0);
+    if ((size_t)n + 1 != no || (size_t)n != nr) { napi_throw_range_error(env, nullptr, "mesh / r_plate length mismatch"); return nullptr; }
+    if (wo_smooth_reconnect_plates(n, off, adj, rp, seeds, (int32_t)ns, a.i32(5))) return throw_wo(env, "smoothAndReconnectPlates");
+    return nullptr;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"fibSpherePoints", FibSpherePoints}, {"sphereDelaunay", SphereDelaunay}, {"meshCsr", MeshCsr}, {"neighborDist", NeighborDist},
@@ -330,6 +359,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"erodeCompositeResident", ErodeCompositeResident}, {"sharpenRidgesResident", SharpenRidgesResident},
         {"applySoilCreepResident", ApplySoilCreepResident}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
         {"lastStageTiming", LastStageTiming}, {"assignElevation", AssignElevation},
+        {"projectCoarsePlates", ProjectCoarsePlates}, {"smoothAndReconnectPlates", SmoothAndReconnectPlates},
     };
     for (auto& f : fns) {
         napi_value v;

@@ -101,6 +101,24 @@ async function main() {
             result.elevKeys = Object.keys(r).sort(); result.layerKeys = Object.keys(r.debugLayers).sort();
             break;
         }
+        case 'smooth_plates': {           // host stage: no GPU needed
+            const PL = await imp('plates.js');
+            const m = { numRegions: j.numRegions, adjOffset: readArr(j.off, Int32Array), adjList: readArr(j.adj, Int32Array) };
+            const rp = readArr(j.r_plate, Int32Array);
+            const ret = PL.smoothAndReconnectPlates(m, rp, new Set(Array.from(readArr(j.seeds, Int32Array))), j.passes);
+            if (ret !== undefined) throw new Error('smoothAndReconnectPlates must return undefined');
+            writeArr(j.out, rp);
+            break;
+        }
+        case 'project_plates': {
+            const CP = await imp('coarse-plates.js');
+            const m = { numRegions: j.numRegions, adjOffset: readArr(j.off, Int32Array), adjList: readArr(j.adj, Int32Array) };
+            const cm = { numRegions: j.coarseRegions, adjOffset: readArr(j.coff, Int32Array), adjList: readArr(j.cadj, Int32Array) };
+            const rp = CP.projectCoarsePlates(m, readArr(j.xyz, Float32Array), cm, readArr(j.cxyz, Float32Array), readArr(j.cplate, Int32Array), j.seed, j.P);
+            if (!(rp instanceof Int32Array)) throw new Error('projectCoarsePlates must return an Int32Array');
+            writeArr(j.out, rp);
+            break;
+        }
         case 'error_paths': {
             const errs = [];
             const e = readArr(j.elevation, Float32Array), oc = readArr(j.isOcean, Uint8Array);

@@ -115,3 +115,30 @@ def test_js_assign_elevation(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "ae.ocean", np.int32), g["ref_ocean"])
     assert res["elevKeys"] == sorted(["r_elevation", "mountain_r", "coastline_r", "ocean_r", "r_stress", "debugLayers", "_timing"])
     assert "superPlates" in res["layerKeys"] and len(res["layerKeys"]) == 13
+
+
+def _dump_plate_case(tmp_path, c):
+    for k, arr in (("off", c["mesh"].adjOffset), ("adj", c["mesh"].adjList), ("xyz", c["xyz"]), ("coff", c["cmesh"].adjOffset), ("cadj", c["cmesh"].adjList),
+                   ("cxyz", c["cxyz"]), ("cplate", c["coarse_r_plate"]), ("seeds", c["seeds"]), ("proj", c["projected"])):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"{k}.bin")
+
+
+def test_js_smooth_and_reconnect_plates(tmp_path):
+    """plates.js drop-in (host stage, runs without a GPU): mutates r_plate in place like the reference."""
+    from plates_common import plate_case
+    c = plate_case("plates_N10000_s1_P80")
+    _dump_plate_case(tmp_path, c)
+    run_node(tmp_path, [{"op": "smooth_plates", "numRegions": c["mesh"].numRegions, "off": "off.bin", "adj": "adj.bin", "r_plate": "proj.bin",
+                         "seeds": "seeds.bin", "passes": c["meta"]["passes"], "out": "smoothed.bin"}])
+    assert np.array_equal(np.fromfile(tmp_path / "smoothed.bin", np.int32), c["smoothed"])
+
+
+@pytest.mark.gpu
+def test_js_project_coarse_plates(tmp_path):
+    from plates_common import plate_case
+    c = plate_case("plates_N10000_s1_P80")
+    _dump_plate_case(tmp_path, c)
+    run_node(tmp_path, [{"op": "project_plates", "numRegions": c["mesh"].numRegions, "off": "off.bin", "adj": "adj.bin", "xyz": "xyz.bin",
+                         "coarseRegions": c["cmesh"].numRegions, "coff": "coff.bin", "cadj": "cadj.bin", "cxyz": "cxyz.bin", "cplate": "cplate.bin",
+                         "seed": c["meta"]["seed"], "P": c["meta"]["P"], "out": "rp.bin"}])
+    assert np.array_equal(np.fromfile(tmp_path / "rp.bin", np.int32), c["projected"])
