@@ -139,6 +139,12 @@ int wo_project_coarse_plates(wo_planet* p, int32_t coarseRegions, const int32_t*
 int wo_smooth_reconnect_plates(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, int32_t* r_plate,
                                const int32_t* plateSeeds, int32_t numPlateSeeds, int32_t numPasses);
 
+/* ------------------------------------------------ climate-util --------------- */
+/* smoothField(mesh, field, passes)                                       js/climate-util.js:5-25
+ * `passes` Jacobi sweeps of (self + neighbours) / (1 + degree) on a caller-owned Float32Array (numRegions floats,
+ * rewritten in place); the planet's resident elevation is untouched. */
+int wo_smooth_field(wo_planet* p, float* field, int32_t passes);
+
 /* ------------------------------------------------ device-resident variants -------------------- */
 /* The "reapply" pattern (js/planet-worker.js:341-440): fields stay in HBM, only scalars arrive.
  * wo_planet_upload sets the resident r_elevation (and r_isOcean when not NULL); the *_resident

@@ -40,6 +40,7 @@ def lib() -> C.CDLL:
             getattr(L, f).argtypes = [_i32, _p, _p, _p, _p, _i32, _f64]
         L.wo_or_priority_flood_carve.argtypes = [_i32, _p, _p, _p, _p, _f64]
         L.wo_or_erode_composite.argtypes = [_i32, _p, _p, _p, _p, _p, _i32, _f64, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _p]
+        L.wo_or_smooth_field.argtypes = [_i32, _p, _p, _p, _i32]
         L.wo_or_project_coarse_plates.argtypes = [_i32, _p, _i32, _p, _p, _p, _p, _f64, _i32, _p]
         L.wo_or_smooth_reconnect_plates.argtypes = [_i32, _p, _p, _p, _i32, _p, _i32]
         _lib = L
@@ -149,3 +150,10 @@ def smooth_reconnect_plates(mesh, r_plate, plate_seeds, numPasses) -> np.ndarray
     seeds = _c(np.asarray(list(plate_seeds)), np.int32)
     lib().wo_or_smooth_reconnect_plates(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(rp), seeds.size, _ptr(seeds), int(numPasses))
     return rp
+
+
+def smooth_field(mesh, field, passes) -> np.ndarray:
+    """js/climate-util.js:5 smoothField (returns the smoothed copy)."""
+    f = _c(field, np.float32).copy()
+    lib().wo_or_smooth_field(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(f), int(passes))
+    return f

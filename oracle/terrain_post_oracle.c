@@ -650,3 +650,22 @@ void wo_or_soil_creep(int32_t N, const int32_t* adjOffset, const int32_t* adjLis
     }
     free(interior); free(tmp);
 }
+
+
+/* js/climate-util.js:5-25 smoothField: `passes` Jacobi sweeps of (self + neighbours) / (1 + degree), Float32Array ping-pong */
+void wo_or_smooth_field(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, float* field, int32_t passes) {
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)numRegions);
+    float *src = field, *dst = tmp;
+    for (int32_t pass = 0; pass < passes; ++pass) {
+        for (int32_t r = 0; r < numRegions; ++r) {
+            double sum = src[r];
+            int32_t count = 1;
+            const int32_t end = adjOffset[r + 1];
+            for (int32_t ni = adjOffset[r]; ni < end; ++ni) { sum += src[adjList[ni]]; count++; }
+            dst[r] = (float)(sum / count);
+        }
+        float* sw = src; src = dst; dst = sw;
+    }
+    if (src != field) memcpy(field, src, sizeof(float) * (size_t)numRegions);
+    free(tmp);
+}

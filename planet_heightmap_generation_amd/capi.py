@@ -46,6 +46,7 @@ SIGNATURES = {
     "wo_sharpen_ridges": (C.c_int, [_p, _p, _p, _c_i32, _c_f64]),
     "wo_soil_creep": (C.c_int, [_p, _p, _p, _c_i32, _c_f64]),
     "wo_assign_elevation": (C.c_int, [_p, _p, _p, _p, _c_i32, _p, _p, _p, _p, _c_f64, _c_f64, _c_f64, _p, _p, _p, _p, _p, _p, _p]),
+    "wo_smooth_field": (C.c_int, [_p, _p, _c_i32]),
     "wo_project_coarse_plates": (C.c_int, [_p, _c_i32, _p, _p, _p, _p, _c_f64, _c_i32, _p]),
     "wo_smooth_reconnect_plates": (C.c_int, [_c_i32, _p, _p, _p, _p, _c_i32, _c_i32]),
     "wo_planet_upload": (C.c_int, [_p, _p, _p]),

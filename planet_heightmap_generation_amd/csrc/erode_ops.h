@@ -94,6 +94,14 @@ struct Fields {
 
 WO_HD inline double nd_or_eps(float d) { return (d == 0.0f || d != d) ? 1e-6 : (double)d; }   // `x || 1e-6`
 
+// js/climate-util.js:13-21 smoothField: (self + neighbours) / (1 + degree), double sum in adjacency order, f32 store
+WO_HD inline float smooth_field_cell(const Fields& F, const float* src, int32_t r) {
+    double sum = src[r];
+    int32_t count = 1;
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) { sum += src[F.adj[j]]; ++count; }
+    return (float)(sum / count);
+}
+
 // sort key: descending elevation, -0 == +0 (comparator (a,b)=>e[b]-e[a], js/terrain-post.js:471)
 WO_HD inline uint32_t desc_key(float f) {
     if (f == 0.0f) f = 0.0f;

@@ -116,6 +116,11 @@ __global__ __launch_bounds__(WO_BLOCK) void k_warp(Fields F, const uint8_t* tabl
     }
 }
 
+// ---------------------------------------------------------------- climate-util smoothField ------
+__global__ __launch_bounds__(WO_BLOCK) void k_smooth_field(Fields F, const float* src, float* dst) {
+    WO_XCD_CELLS(r, F.N) dst[r] = smooth_field_cell(F, src, r);
+}
+
 // ---------------------------------------------------------------- plate projection --------------
 // js/coarse-plates.js:51-117: one thread per hi-res cell (12 noise3D from LDS tables, then a greedy ascent over the
 // 20 k-cell coarse mesh, which stays in L2); the start cells come from a small (z, longitude) bucket grid.

@@ -23,7 +23,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -750,6 +750,30 @@ int wo_erode_composite(wo_planet* p, float* e, const uint8_t* oc, int32_t hIters
     ErodeArgs a{hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength};
     return with_host_field(p, "wo_erode_composite", e, oc, true,
                            [](wo_planet* q, void* v) { auto* x = (ErodeArgs*)v; erode_composite(q, x->h, x->K, x->m, x->dt, x->t, x->talus, x->kT, x->g, x->gs); }, &a);
+}
+
+// smoothField (js/climate-util.js:5-25) on a caller-owned field; the planet's resident elevation is not touched
+int wo_smooth_field(wo_planet* p, float* field, int32_t passes) {
+    if (!check_planet(p, "wo_smooth_field")) return 1;
+    if (!field) { set_error("wo_smooth_field: null field"); return 1; }
+    if (passes <= 0) return 0;
+    float *a = nullptr, *b = nullptr;
+    try {
+        hipStream_t s = p->ctx->stream;
+        const size_t bytes = (size_t)p->N * sizeof(float);
+        a = dalloc<float>(p->N); b = dalloc<float>(p->N);
+        WO_HIP(hipMemcpyAsync(a, field, bytes, hipMemcpyHostToDevice, s));
+        Fields F = p->fields();
+        for (int32_t pass = 0; pass < passes; ++pass) {
+            launch(p, FAM_SMOOTH_FIELD, k_smooth_field, xcd_grid(p->N), WO_BLOCK, F, (const float*)a, b);
+            std::swap(a, b);
+        }
+        WO_HIP(hipMemcpyAsync(field, a, bytes, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipStreamSynchronize(s));
+        dfree(a); dfree(b);
+        return 0;
+    } catch (const HipError& e) { dfree(a); dfree(b); set_error(std::string("wo_smooth_field: ") + e.msg); return 2; }
+      catch (const std::exception& e) { dfree(a); dfree(b); set_error(std::string("wo_smooth_field: ") + e.what()); return 3; }
 }
 
 int32_t wo_planet_num_regions(const wo_planet* p) { return p ? p->N : 0; }

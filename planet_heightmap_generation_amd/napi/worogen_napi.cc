@@ -316,6 +316,13 @@ napi_value AssignElevation(napi_env env, napi_callback_info info) {
     return o;
 }
 
+// smoothField(planet, field Float32Array (in place), passes)
+napi_value SmoothField(napi_env env, napi_callback_info info) {
+    PLANET_AND_ELEV();
+    if ((int32_t)ne != wo_planet_num_regions(p)) { napi_throw_range_error(env, nullptr, "field length must equal mesh.numRegions"); return nullptr; }
+    if (wo_smooth_field(p, e, a.i32(2))) return throw_wo(env, "smoothField");
+    return nullptr;
+}
 // projectCoarsePlates(planet, coarseAdjOffset, coarseAdjList, coarse_xyz, coarse_r_plate, seed, numPlates|null) -> Int32Array
 napi_value ProjectCoarsePlates(napi_env env, napi_callback_info info) {
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
@@ -359,7 +366,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"erodeCompositeResident", ErodeCompositeResident}, {"sharpenRidgesResident", SharpenRidgesResident},
         {"applySoilCreepResident", ApplySoilCreepResident}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
         {"lastStageTiming", LastStageTiming}, {"assignElevation", AssignElevation},
-        {"projectCoarsePlates", ProjectCoarsePlates}, {"smoothAndReconnectPlates", SmoothAndReconnectPlates},
+        {"projectCoarsePlates", ProjectCoarsePlates}, {"smoothField", SmoothField}, {"smoothAndReconnectPlates", SmoothAndReconnectPlates},
     };
     for (auto& f : fns) {
         napi_value v;

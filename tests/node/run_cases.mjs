@@ -119,6 +119,14 @@ async function main() {
             writeArr(j.out, rp);
             break;
         }
+        case 'smooth_field': {
+            const CU = await imp('climate-util.js');
+            const fld = readArr(j.field, Float32Array);
+            const ret = CU.smoothField(mesh, fld, j.passes);
+            if (ret !== undefined) throw new Error('smoothField must return undefined');
+            writeArr(j.out, fld);
+            break;
+        }
         case 'error_paths': {
             const errs = [];
             const e = readArr(j.elevation, Float32Array), oc = readArr(j.isOcean, Uint8Array);
