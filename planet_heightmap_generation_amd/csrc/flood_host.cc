@@ -263,20 +263,18 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     const int32_t* offL = S.offL.data();
     const int32_t* adjL = S.adjL.data();
     float* eL = S.eL.data();
-    float* surface = S.surface.data();
     FloodCell* st = S.state.data();
-    int32_t* root = S.root.data();        // drainage tree id (= ordinal of the seed the cell drains through), -1 for none
 
     // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed
     parallel_ranges(L, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; surface[i] = v; st[i].e = v; st[i].drain = UNVISITED; root[i] = -1; }
+        for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
     });
     if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
     KeyHeap heap(S.heapStore);
     for (size_t s = 0; s < S.seedCell.size(); ++s) {        // :118-128, ascending r
         const int32_t i = S.seedCell[s];
         st[i].drain = TO_OCEAN;
-        root[i] = (int32_t)s;
+        st[i].root = (int32_t)s;
         heap.push(i, (float)((double)eL[i] + cell_noise(landCell[i])));
     }
     lap("init+seeds");
@@ -288,7 +286,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             const size_t lim2 = heap.n < 7 ? heap.n : 7;
             for (size_t q = 0; q < lim2; ++q) {
                 const int32_t cc = hp[q].cell;
-                __builtin_prefetch(&offL[cc]); __builtin_prefetch(&st[cc]); __builtin_prefetch(&surface[cc]); __builtin_prefetch(&root[cc]);
+                __builtin_prefetch(&offL[cc]); __builtin_prefetch(&st[cc]);
             }
             if (heap.n > 0) {
                 const int32_t c0 = hp[0].cell;
@@ -296,19 +294,19 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             }
             for (size_t q = 1; q < lim2 && q < 3; ++q) __builtin_prefetch(&adjL[offL[hp[q].cell]]);
         }
-        const double lim = (double)surface[c] + EPS;
+        const double lim = (double)st[c].surface + EPS;
         const int32_t iEnd = offL[c + 1];
-        const int32_t rootC = root[c];
+        const int32_t rootC = st[c].root;
         for (int32_t i = offL[c]; i < iEnd; ++i) {
             const int32_t nb = adjL[i];
             FloodCell& sn = st[nb];
             if (sn.drain != UNVISITED) continue;
             sn.drain = c;
-            root[nb] = rootC;
+            st[nb].root = rootC;
             float k;
             if ((double)sn.e < lim) {
-                surface[nb] = (float)lim;
-                k = (float)((double)surface[nb] + cell_noise(landCell[nb]));
+                st[nb].surface = (float)lim;
+                k = (float)((double)st[nb].surface + cell_noise(landCell[nb]));
             } else {
                 k = (float)((double)sn.e + cell_noise(landCell[nb]));
             }
@@ -316,6 +314,10 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         }
     }
     lap("pass1");
+    // passes 2 and 3 stream over surface / tree id: give them compact arrays again
+    float* surface = S.surface.data();
+    int32_t* root = S.root.data();
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) { surface[i] = st[i].surface; root[i] = st[i].root; } });
     // --- pass 2 (:152-196) and pass 3 (:200-214).  Both are sequential in the reference, but every cell a turn
     // reads or writes (the drain path of r, the carve window on it, r itself; in pass 3 the cell and its
     // drain target) lies inside r's drainage tree, and trees share no land cell.  So trees are processed

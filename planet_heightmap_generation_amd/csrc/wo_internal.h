@@ -17,13 +17,13 @@ void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float*
 
 // flood_host.cc
 struct FloodHeapItem { float key; int32_t cell; };
-struct FloodCell { float e; int32_t drain; };
+struct FloodCell { float e; int32_t drain; float surface; int32_t root; };   // one 16-byte record per land cell: a pop touches one line for all four
 struct FloodScratch {
     // static per (mesh, positions, ocean mask)
     bool staticValid = false; int32_t staticN = -1; int32_t L = 0; int64_t staticVersion = 0;
     hvec<int32_t> landCell, landIndex, offL, adjL, seedCell;
     // per call (land-index space)
-    hvec<float> surface, eL;
+    hvec<float> surface, eL;                 // surface / root: compact copies of the pass-1 results for passes 2 and 3
     hvec<FloodCell> state;
     hvec<int32_t> root, order, order2, list2;
     hvec<uint32_t> bits, bits2;
