@@ -202,6 +202,13 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     S.landIndex.resize(N);
     parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) S.landIndex[r] = -1; });
     parallel_ranges(L, [&](int64_t b, int64_t e, int) { for (int64_t i = b; i < e; ++i) S.landIndex[S.landCell[i]] = (int32_t)i; });
+    {   // land indices in ascending original id (the order passes 2 and 3 are defined in)
+        std::vector<int64_t> cnt(host_threads() + 2, 0);
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t r = b; r < e; ++r) c += ocean[r] ? 0 : 1; cnt[t + 1] = c; });
+        for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+        S.landByR.resize(L);
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t o = cnt[t]; for (int64_t r = b; r < e; ++r) if (!ocean[r]) S.landByR[o++] = S.landIndex[r]; });
+    }
     S.offL.assign(L + 1, 0);
     parallel_ranges(L, [&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; ++i) {
@@ -259,7 +266,6 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     const int32_t L = S.L;
     if (L == 0) return;
     const int32_t* landCell = S.landCell.data();
-    const int32_t* landIndex = S.landIndex.data();
     const int32_t* offL = S.offL.data();
     const int32_t* adjL = S.adjL.data();
     float* eL = S.eL.data();
@@ -333,7 +339,8 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         for (int32_t i = 0; i < L; ++i) if (root[i] >= 0) cnt2[root[i] + 1]++;
         for (int32_t t = 0; t < nTrees; ++t) cnt2[t + 1] += cnt2[t];
         std::vector<int32_t> fill(cnt2.begin(), cnt2.end() - 1);
-        for (int32_t r = 0; r < N; ++r) { const int32_t i = landIndex[r]; if (i >= 0 && root[i] >= 0) list2[fill[root[i]]++] = i; }
+        const int32_t* byR = S.landByR.data();
+        for (int32_t k = 0; k < L; ++k) { const int32_t i = byR[k]; if (root[i] >= 0) list2[fill[root[i]]++] = i; }
     }
     // Trees are numbered by their seed's original id, i.e. along the Fibonacci spiral: consecutive ids are spatial
     // neighbours, so workers take contiguous chunks.  Measured on the 2-socket EPYC GPU box: 4-8 workers give ~3x
@@ -399,46 +406,39 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             eL[r] = (float)((double)eL[r] + deficit * (1 - carveStrength));
         }
         if (timing) { totLen += myLen; nDef += myDef; }
-    });
-    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
-    lap("pass2");
-    // --- pass 3: land cells by ascending surface (stable => ties ascending original id), then grouped by tree
-    int32_t nLand = 0;
-    int32_t* order = S.order.data();
-    int32_t* order2 = S.order2.data();
-    uint32_t* b0 = S.bits.data();
-    uint32_t* b1 = S.bits2.data();
-    for (int32_t r = 0; r < N; ++r) { const int32_t i = landIndex[r]; if (i >= 0 && root[i] >= 0) { order[nLand] = i; b0[nLand] = asc_bits(surface[i]); ++nLand; } }
-    for (int pass = 0; pass < 3; ++pass) {          // 11 + 11 + 10 bit LSD radix, stable
-        const int sh = pass * 11;
-        const uint32_t mask = pass == 2 ? 1023u : 2047u;
-        uint32_t cnt[2049];
-        std::memset(cnt, 0, sizeof(cnt));
-        for (int32_t i = 0; i < nLand; ++i) cnt[((b0[i] >> sh) & mask) + 1]++;
-        for (int i = 0; i < 2048; ++i) cnt[i + 1] += cnt[i];
-        for (int32_t i = 0; i < nLand; ++i) {
-            const uint32_t d = cnt[(b0[i] >> sh) & mask]++;
-            b1[d] = b0[i]; order2[d] = order[i];
+        // --- pass 3 for this tree (:199-214): its cells by ascending surface, ties by ascending original id (the
+        // reference's stable sort of an ascending-id list), then the ordered fix-up.  The tree's cells are hot in cache.
+        const int32_t q0 = cnt2[tree], n = cnt2[tree + 1] - q0;
+        int32_t* cells = list2 + q0;                        // ascending original id
+        if (n > 1) {
+            if (n <= 2048) {
+                std::stable_sort(cells, cells + n, [&](int32_t a, int32_t b) { return asc_bits(surface[a]) < asc_bits(surface[b]); });
+            } else {                                        // big trees: stable LSD radix on the key bits
+                std::vector<uint32_t> k0(n), k1(n); std::vector<int32_t> c1(n);
+                for (int32_t i = 0; i < n; ++i) k0[i] = asc_bits(surface[cells[i]]);
+                uint32_t* ka = k0.data(); uint32_t* kb = k1.data(); int32_t* ca = cells; int32_t* cb = c1.data();
+                for (int pass = 0; pass < 3; ++pass) {
+                    const int sh = pass * 11; const uint32_t mask = pass == 2 ? 1023u : 2047u;
+                    uint32_t cnt[2049]; std::memset(cnt, 0, sizeof(cnt));
+                    for (int32_t i = 0; i < n; ++i) cnt[((ka[i] >> sh) & mask) + 1]++;
+                    for (int i = 0; i < 2048; ++i) cnt[i + 1] += cnt[i];
+                    for (int32_t i = 0; i < n; ++i) { const uint32_t d = cnt[(ka[i] >> sh) & mask]++; kb[d] = ka[i]; cb[d] = ca[i]; }
+                    std::swap(ka, kb); std::swap(ca, cb);
+                }
+                if (ca != cells) std::memcpy(cells, ca, sizeof(int32_t) * (size_t)n);     // 3 passes: result sits in c1
+            }
         }
-        std::swap(b0, b1); std::swap(order, order2);
-    }
-    std::vector<int32_t> cnt3(nTrees + 1, 0);
-    for (int32_t i = 0; i < nLand; ++i) cnt3[root[order[i]] + 1]++;
-    for (int32_t t = 0; t < nTrees; ++t) cnt3[t + 1] += cnt3[t];
-    {
-        std::vector<int32_t> fill(cnt3.begin(), cnt3.end() - 1);
-        for (int32_t i = 0; i < nLand; ++i) { const int32_t c = order[i]; order2[fill[root[c]]++] = c; }   // stable
-    }
-    for_trees(cnt3, [&](int32_t tree) {
-        for (int32_t q = cnt3[tree]; q < cnt3[tree + 1]; ++q) {
-            const int32_t c = order2[q], t = st[c].drain;
+        for (int32_t q = 0; q < n; ++q) {
+            const int32_t c = cells[q], t = st[c].drain;
             if (t == NO_TARGET || t == UNVISITED) continue;
             const double te = (t == TO_OCEAN) ? 0.0 : (double)eL[t];
             if ((double)eL[c] <= te) eL[c] = (float)(te + EPS);
         }
     });
+    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
+    lap("pass2+3");
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
-    lap("pass3");
+    lap("writeback");
 }
 
 }  // namespace wo

@@ -21,7 +21,7 @@ struct FloodCell { float e; int32_t drain; float surface; int32_t root; };   // 
 struct FloodScratch {
     // static per (mesh, positions, ocean mask)
     bool staticValid = false; int32_t staticN = -1; int32_t L = 0; int64_t staticVersion = 0;
-    hvec<int32_t> landCell, landIndex, offL, adjL, seedCell;
+    hvec<int32_t> landCell, landIndex, offL, adjL, seedCell, landByR;   // landByR: land indices in ascending original id
     // per call (land-index space)
     hvec<float> surface, eL;                 // surface / root: compact copies of the pass-1 results for passes 2 and 3
     hvec<FloodCell> state;
