@@ -266,11 +266,24 @@ struct StageClock {
 static void flood_stage(wo_planet* p, double carveStrength) {
     hipStream_t s = p->ctx->stream;
     const size_t bytes = (size_t)p->N * sizeof(float);
+    const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flood stage] %-10s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
+    if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("drain gpu"); }
     refresh_host_ocean(p);
+    lap("ocean mask");
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     WO_HIP(hipStreamSynchronize(s));
+    lap("D2H");
     priority_flood_carve_host(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, p->h_ocean.data(), carveStrength, p->flood);
+    lap("host flood");
     WO_HIP(hipMemcpyAsync(p->d_e, p->h_pinned, bytes, hipMemcpyHostToDevice, s));
+    if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("H2D"); }
 }
 
 static void coast_flags(wo_planet* p) {
