@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include "host_util.h"
+
 #include "erode_ops.h"
 #include "wo_internal.h"
 
@@ -68,9 +70,9 @@ struct wo_planet {
     wo_ctx* ctx = nullptr;
     int32_t N = 0, E = 0, maxDeg = 0;
     // host copies kept for the host-resident flood stage
-    std::vector<int32_t> h_off, h_adj;
-    std::vector<float> h_xyz;
-    std::vector<uint8_t> h_ocean;
+    wo::hvec<int32_t> h_off, h_adj;          // host mirrors walked in data-dependent order: huge-page advised (host_util.h)
+    wo::hvec<float> h_xyz;
+    wo::hvec<uint8_t> h_ocean;
     bool h_ocean_valid = false;
     float* h_pinned = nullptr;          // N floats, pinned
     int32_t* h_count = nullptr;         // pinned scalar(s) for round-count read-back

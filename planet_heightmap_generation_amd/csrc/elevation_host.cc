@@ -5,7 +5,11 @@
 // are restated serially; independent fields are computed on separate host threads.  The per-cell work
 // (collisions, the uplift loop, coastal roughening, arcs, hotspots) is in elevation_ops.h / the HIP kernels.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -28,51 +32,117 @@ struct OrderedSet {
     void add(int32_t r) { if (!in[r]) { in[r] = 1; items.push_back(r); } }
 };
 
-// propagateStress (js/elevation.js:127-159)
+// propagateStress (js/elevation.js:127-159).  The relaxation is in place and order-defined inside a pass (a frontier
+// entry may have been raised earlier in the same pass; entries may repeat), but it never crosses a plate boundary
+// (`r_plate[nb] === plate`): the sub-sequences of different plates touch disjoint cells and commute.  So the start
+// frontier is split by plate, stably, and every plate runs all its passes on its own — same values, plates in
+// parallel.  Within a plate the reference's order is kept entry for entry.
 void propagate_stress(const ElevMesh& M, float* stress, float* subduct, const int32_t* plate, const uint8_t* plateIsOcean,
                       double decayFactor, double subductDecayFactor, int32_t numPasses) {
-    std::vector<int32_t> frontier, next;
-    for (int32_t r = 0; r < M.N; ++r) if ((double)stress[r] > 0.01) frontier.push_back(r);
-    for (int32_t pass = 0; pass < numPasses && !frontier.empty(); ++pass) {
-        next.clear();
-        for (int32_t r : frontier) {
-            const int32_t pl = plate[r];
-            if (plateIsOcean[pl]) continue;
-            const float sfF = subduct[r];
-            const double sf = sfF;
-            const double effDecay = sf > 0.5 ? subductDecayFactor : decayFactor;
-            const double propagated = (double)stress[r] * effDecay;
-            if (propagated < 0.005) continue;
-            for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni) {
-                const int32_t nb = M.adj[ni];
-                if (plate[nb] == pl && propagated > (double)stress[nb]) {
-                    stress[nb] = (float)propagated;
-                    subduct[nb] = sfF;
-                    next.push_back(nb);
+    // start frontier (:132-135), grouped by plate id in first-appearance order, ascending r inside a group
+    std::vector<int32_t> all;
+    for (int32_t r = 0; r < M.N; ++r) if ((double)stress[r] > 0.01) all.push_back(r);
+    std::vector<int32_t> groupOf;                     // plate id -> group, grown on demand
+    std::vector<std::vector<int32_t>> groups;
+    for (int32_t r : all) {
+        const int32_t pl = plate[r];
+        if (plateIsOcean[pl]) continue;               // :141 ocean plates never propagate (and are never pushed by others)
+        if ((size_t)pl >= groupOf.size()) groupOf.resize((size_t)pl + 1, -1);
+        if (groupOf[pl] < 0) { groupOf[pl] = (int32_t)groups.size(); groups.emplace_back(); }
+        groups[groupOf[pl]].push_back(r);
+    }
+    auto run_plate = [&](std::vector<int32_t>& frontier) {
+        std::vector<int32_t> next;
+        const int32_t pl = plate[frontier[0]];
+        for (int32_t pass = 0; pass < numPasses && !frontier.empty(); ++pass) {
+            next.clear();
+            const size_t nf = frontier.size();
+            for (size_t fi = 0; fi < nf; ++fi) {
+                // the frontier of a pass is fixed: pull the rows of the entries a few steps ahead
+                if (fi + 12 < nf) { const int32_t a = frontier[fi + 12]; __builtin_prefetch(&M.off[a]); __builtin_prefetch(&stress[a]); __builtin_prefetch(&subduct[a]); }
+                if (fi + 6 < nf) { const int32_t a = frontier[fi + 6]; __builtin_prefetch(&M.adj[M.off[a]]); }
+                if (fi + 3 < nf) { const int32_t a = frontier[fi + 3]; for (int32_t ni = M.off[a]; ni < M.off[a + 1]; ++ni) { __builtin_prefetch(&stress[M.adj[ni]]); __builtin_prefetch(&plate[M.adj[ni]]); } }
+                const int32_t r = frontier[fi];
+                const float sfF = subduct[r];
+                const double sf = sfF;
+                const double effDecay = sf > 0.5 ? subductDecayFactor : decayFactor;
+                const double propagated = (double)stress[r] * effDecay;
+                if (propagated < 0.005) continue;
+                for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni) {
+                    const int32_t nb = M.adj[ni];
+                    if (plate[nb] == pl && propagated > (double)stress[nb]) {
+                        stress[nb] = (float)propagated;
+                        subduct[nb] = sfF;
+                        next.push_back(nb);
+                    }
                 }
             }
+            frontier.swap(next);
         }
-        frontier.swap(next);
-    }
+    };
+    // largest groups first so the pool drains evenly
+    std::vector<int32_t> order(groups.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int32_t)i;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return groups[a].size() > groups[b].size(); });
+    std::atomic<size_t> nextGroup{0};
+    auto worker = [&]() { for (;;) { const size_t k = nextGroup.fetch_add(1); if (k >= order.size()) break; run_plate(groups[order[k]]); } };
+    const int nt = std::max(1, std::min<int>({host_threads(), 16, (int)groups.size()}));
+    if (nt == 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (int i = 0; i < nt; ++i) th.emplace_back(worker);
+    for (auto& t : th) t.join();
 }
 
-// assignDistanceField (js/elevation.js:164-189)
+// assignDistanceField (js/elevation.js:164-189): random-pick frontier growth — step qi draws u, takes the queue entry
+// at qi + floor(u * (length - qi)), moves entry qi into its place and expands it.  The order is defined by the RNG,
+// so the walk is serial; what can be hidden is its memory latency (every step lands on a random queue slot, a random
+// cell and its neighbours: ~5 cold lines at 10^7 cells).  The draws do not depend on the walk, so they are produced
+// a few steps ahead and the slots they will *probably* select (the queue length is only known to within a few
+// entries) are prefetched in stages: queue line -> cell row and distance -> neighbours' distances.
 void distance_field(const ElevMesh& M, const std::vector<int32_t>& seeds, const uint8_t* isStop, double rngSeed, float* dist) {
     ParkMiller rng(rngSeed);
     for (int32_t r = 0; r < M.N; ++r) dist[r] = INFINITY;
-    std::vector<int32_t> queue;
-    queue.reserve(M.N);
-    for (int32_t r : seeds) { queue.push_back(r); dist[r] = 0; }
-    for (size_t qi = 0; qi < queue.size(); ++qi) {
-        const size_t pos = qi + (size_t)std::floor(rng.next() * (double)(queue.size() - qi));
+    hvec<int32_t> queueStore((size_t)M.N + seeds.size() + 16);   // a seed entry plus at most one entry per cell
+    int32_t* queue = queueStore.data();
+    size_t len = 0;
+    for (int32_t r : seeds) { queue[len++] = r; dist[r] = 0; }    // seeds are distinct cells (Set / filtered lists)
+    constexpr int LOOK = 16;                                       // draws kept ahead (ring)
+    double u[LOOK];
+    for (int k = 0; k < LOOK; ++k) u[k] = rng.next();
+    auto guess = [&](size_t step, size_t lenNow, size_t qiNow) -> size_t {        // probable slot of a later step
+        const size_t lenThen = lenNow + (step - qiNow);                            // steady frontier: one push per pop
+        if (step >= lenThen) return lenNow - 1;
+        size_t p = step + (size_t)std::floor(u[step % LOOK] * (double)(lenThen - step));
+        return p < lenNow ? p : lenNow - 1;
+    };
+    for (size_t qi = 0; qi < len; ++qi) {
+        {   // staged prefetch for steps qi+12, qi+8, qi+4, qi+2
+            __builtin_prefetch(&queue[guess(qi + 12, len, qi)]);
+            const int32_t c8 = queue[guess(qi + 8, len, qi)];
+            __builtin_prefetch(&M.off[c8]); __builtin_prefetch(&dist[c8]);
+            const int32_t c4 = queue[guess(qi + 4, len, qi)];
+            __builtin_prefetch(&M.adj[M.off[c4]]);
+            const int32_t c2 = queue[guess(qi + 2, len, qi)];
+            for (int32_t ni = M.off[c2]; ni < M.off[c2 + 1]; ++ni) { __builtin_prefetch(&dist[M.adj[ni]]); if (isStop) __builtin_prefetch(&isStop[M.adj[ni]]); }
+        }
+        const size_t pos = qi + (size_t)std::floor(u[qi % LOOK] * (double)(len - qi));
+        u[qi % LOOK] = rng.next();                                 // the draw for step qi + LOOK
         const int32_t cur = queue[pos];
         queue[pos] = queue[qi];
         const float dn = (float)((double)dist[cur] + 1);
         for (int32_t ni = M.off[cur]; ni < M.off[cur + 1]; ++ni) {
             const int32_t nb = M.adj[ni];
-            if (dist[nb] == INFINITY && !(isStop && isStop[nb])) { dist[nb] = dn; queue.push_back(nb); }
+            if (dist[nb] == INFINITY && !(isStop && isStop[nb])) { dist[nb] = dn; queue[len++] = nb; }
         }
     }
+}
+
+// FIFO walks know their next entries exactly: pull the rows / distances of the entries a few steps ahead
+inline void fifo_prefetch(const ElevMesh& M, const std::vector<int32_t>& queue, size_t qi, const float* dist) {
+    const size_t n = queue.size();
+    if (qi + 12 < n) { const int32_t a = queue[qi + 12]; __builtin_prefetch(&M.off[a]); __builtin_prefetch(&dist[a]); }
+    if (qi + 6 < n) { const int32_t a = queue[qi + 6]; __builtin_prefetch(&M.adj[M.off[a]]); }
+    if (qi + 3 < n) { const int32_t a = queue[qi + 3]; for (int32_t ni = M.off[a]; ni < M.off[a + 1]; ++ni) __builtin_prefetch(&dist[M.adj[ni]]); }
 }
 
 // bounded FIFO BFS used by rift / ridge / fracture / back-arc / island-arc fields
@@ -80,6 +150,7 @@ void distance_field(const ElevMesh& M, const std::vector<int32_t>& seeds, const 
 void bounded_bfs(const ElevMesh& M, std::vector<int32_t>& queue, float* dist, double maxDist,
                  const std::function<bool(int32_t, int32_t)>& pass, float* carry) {
     for (size_t qi = 0; qi < queue.size(); ++qi) {
+        fifo_prefetch(M, queue, qi, dist);
         const int32_t r = queue[qi];
         const double nd = (double)dist[r] + 1;
         if (nd > maxDist) continue;
@@ -128,6 +199,14 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     const int32_t N = M.N;
     const bool hasSuper = P != nullptr;
     const double SMALL_W = 0.05, SUPER_W = 0.95;
+    const bool timing = std::getenv("WO_ELEV_TIMING") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[elevation host] %-16s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+        tp = now;
+    };
 
     // ---- sets (:257-271) ----
     OrderedSet mountain(N), coastline(N), ocean(N);
@@ -142,6 +221,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     }
     blend_collision_layers(N, S, P, H);
 
+    lap("sets+blend");
     // ---- stress propagation (:329-362) ----
     const double scaleFactor = std::sqrt((double)N / 10000);
     const double baseDecay = 0.5 + I.spread * 0.04;
@@ -162,6 +242,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
         }
     }
 
+    lap("stress");
     // ---- plate representatives (:368-382) ----
     {
         std::vector<int32_t> rep(I.plates.numIds, -1);
@@ -193,6 +274,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     for (int32_t r : coastline.items) stopAll[r] = 1;
     for (int32_t r : ocean.items) stopAll[r] = 1;
 
+    lap("reps+seeds");
     // ---- five distance fields (:392-426), independent -> one host thread each ----
     H.distMountain.resize(N); H.distOcean.resize(N); H.distCoastline.resize(N); H.distCoast.resize(N); H.distCoastLand.resize(N);
     {
@@ -204,6 +286,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
         a.join(); b.join(); c.join(); d.join();
     }
 
+    lap("distance fields");
     // ---- scalars (:431-460) ----
     auto rnd = [](double x) { return std::floor(x + 0.5); };
     Q.N = N; Q.scaleFactor = scaleFactor; Q.noiseMag = I.noiseMag;
@@ -217,8 +300,8 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
             if ((double)H.stress[r] > maxStress) maxStress = H.stress[r];
         }
         if (!vals.empty()) {
-            std::sort(vals.begin(), vals.end());
             const size_t idx = std::min(vals.size() - 1, (size_t)std::floor((double)vals.size() * 0.97));
+            std::nth_element(vals.begin(), vals.begin() + (std::ptrdiff_t)idx, vals.end());     // the value a full sort leaves at idx
             maxStress = vals[idx];
         }
         if (maxStress < 0.01) maxStress = 1;
@@ -238,6 +321,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     Q.maxArcDist = (int32_t)std::max(5.0, rnd(5 * scaleFactor));
     const double maxStress = Q.maxStress;
 
+    lap("scalars+pctl");
     // ---- BFS fields (independent of each other) ----
     H.dBdry.assign(N, (float)(maxCD + 1)); H.coastStressMax.assign(N, 0.f); H.coastSubductMax.assign(N, 0.f); H.coastConvergent.assign(N, 0);
     H.riftDist.assign(N, INFINITY); H.ridgeDist.assign(N, INFINITY); H.fractureDist.assign(N, INFINITY);
@@ -256,6 +340,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
             H.coastConvergent[r] = H.btype[r] == 1 ? 1 : 0;
         }
         for (size_t qi = 0; qi < q.size(); ++qi) {
+            fifo_prefetch(M, q, qi, H.dBdry.data());
             const int32_t r = q[qi];
             const double nd = (double)H.dBdry[r] + 1;
             if (nd > maxCD) continue;
@@ -308,6 +393,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
         a.join(); b.join(); c.join(); d.join(); e.join();
     }
 
+    lap("bfs fields");
     // ---- hotspot dome list (:1116-1261) ----
     domes.clear();
     {

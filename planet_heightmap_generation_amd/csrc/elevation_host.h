@@ -3,6 +3,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "host_util.h"
+
 #include "elevation_ops.h"
 
 namespace wo {
@@ -27,12 +29,12 @@ struct CollisionHost {               // one layer's findCollisions output, downl
 };
 
 struct ElevHostState {
-    std::vector<float> stress, subduct;
+    hvec<float> stress, subduct;
     std::vector<int8_t> btype;
-    std::vector<uint8_t> bothOcean, hasOcean, isOcean, coastConvergent;
+    hvec<uint8_t> bothOcean, hasOcean, isOcean, coastConvergent;
     std::vector<int32_t> mountain, coastline, ocean;         // Sets in insertion order
-    std::vector<float> distMountain, distOcean, distCoastline, distCoast, distCoastLand;
-    std::vector<float> dBdry, coastStressMax, coastSubductMax, riftDist, ridgeDist, fractureDist, backArcDist, backArcStress, arcDist, arcStress;
+    hvec<float> distMountain, distOcean, distCoastline, distCoast, distCoastLand;
+    hvec<float> dBdry, coastStressMax, coastSubductMax, riftDist, ridgeDist, fractureDist, backArcDist, backArcStress, arcDist, arcStress;
 };
 
 void blend_collision_layers(int32_t N, const CollisionHost& S, const CollisionHost* P, ElevHostState& H);

@@ -86,7 +86,7 @@ static inline void ocean_changed(wo_planet* p) { p->h_ocean_valid = false; }
 static void refresh_host_ocean(wo_planet* p) {
     if (p->h_ocean_valid) return;
     hipStream_t s = p->ctx->stream;
-    std::vector<uint8_t> tmp(p->N);
+    hvec<uint8_t> tmp(p->N);
     WO_HIP(hipMemcpyAsync(tmp.data(), p->d_ocean, p->N, hipMemcpyDeviceToHost, s));
     WO_HIP(hipStreamSynchronize(s));
     if (tmp.size() != p->h_ocean.size() || std::memcmp(tmp.data(), p->h_ocean.data(), tmp.size()) != 0) {
@@ -949,7 +949,7 @@ struct DevCollision {
 
 static PlateTable host_table(const wo_plate_table& h) { PlateTable t; t.numIds = h.numIds; t.hasVec = h.hasVec; t.pole = h.pole; t.omega = h.omega; t.isOcean = h.isOcean; t.density = h.density; return t; }
 
-template <class T> static T* upload_vec(const std::vector<T>& v, hipStream_t s) {
+template <class T, class A> static T* upload_vec(const std::vector<T, A>& v, hipStream_t s) {
     T* d = dalloc<T>(v.size());
     WO_HIP(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return d;
