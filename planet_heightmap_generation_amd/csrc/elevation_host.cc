@@ -329,9 +329,16 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     H.arcDist.assign(N, (float)(Q.maxArcDist + 1)); H.arcStress.assign(N, 0.f);
     auto coast_bfs = [&]() {                                   // :464-509
         std::vector<int32_t> q;
-        for (int32_t r = 0; r < N; ++r) {
-            const uint8_t rOc = H.isOcean[r];
-            for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni) if (H.isOcean[M.adj[ni]] != rOc) { q.push_back(r); break; }
+        {   // boundary cells in ascending r: scanned in parallel, concatenated in range order
+            std::vector<std::vector<int32_t>> part(host_threads() + 1);
+            parallel_ranges(N, [&](int64_t b, int64_t e, int t) {
+                for (int64_t r = b; r < e; ++r) {
+                    const uint8_t rOc = H.isOcean[r];
+                    for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni) if (H.isOcean[M.adj[ni]] != rOc) { part[t].push_back((int32_t)r); break; }
+                }
+            });
+            q.reserve((size_t)N + 16);
+            for (auto& v : part) q.insert(q.end(), v.begin(), v.end());
         }
         for (int32_t r : q) {
             H.dBdry[r] = 0;

@@ -10,6 +10,9 @@ sys.path.insert(0, ".")
 from planet_heightmap_generation_amd import coarse_plates as CP, elevation as EL, sphere_mesh as S  # noqa: E402
 from planet_heightmap_generation_amd.terrain_post import Planet  # noqa: E402
 
+import bench  # noqa: E402  (NUMA pinning helper)
+
+print("numa node:", bench.bind_to_gpu_numa_node(0))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 t = time.time(); mesh, xyz, nd = S.build_sphere(N, 0.75, 1); print(f"mesh {N}: {time.time() - t:.1f} s")
 cm, cxyz, _ = S.build_sphere(20000, 0.75, 138)
