@@ -217,3 +217,46 @@ def test_full_size_properties(TP):
     st = pl.last_stage_timing()
     assert "solve" in st and "thermal" in st and "priority_flood(host)" in st
     pl.close()
+
+
+def test_headline_size_properties(TP):
+    """BASELINE config 3 size (10 M cells, the bench workload): size-independent properties — bit-deterministic run
+    to run (two different schedules of the same dataflow: the launch-count prediction differs between the runs),
+    ocean cells never written, land stays >= 0 and finite, zero iterations leave the field alone, and the patch
+    solve equals the level-round solve (same DAG, other schedule) on the first iterations."""
+    import os
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(10_000_000, 0.75, 1)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(1)
+    pl.warp_terrain_resident(1, 0.75)
+    pl.ocean_from_elevation()
+    pl.save_state()
+    e0, oc = pl.download(), pl.download_ocean()
+    pl.erode_composite_resident(0, 3e-4, 0.5, 1.0, 0, 1.16, 0.015, 0, 0.5)
+    assert np.array_equal(pl.download(), e0)
+    outs = []
+    for _ in range(2):
+        pl.restore_state()
+        pl.erode_composite_resident(6, 3e-4, 0.5, 1.0, 6, 1.16, 0.015, 2, 0.5)
+        pl.apply_soil_creep_resident(3, 0.1125)
+        outs.append(pl.download())
+    assert np.array_equal(outs[0], outs[1])
+    out = outs[0]
+    assert np.isfinite(out).all()
+    assert np.array_equal(out[oc == 1], e0[oc == 1])
+    assert (out[oc == 0] >= 0).all()
+    st = pl.last_erode_stats()
+    assert st["solve_patch_launches_total"] > 0 and st["land_cells"] == float((oc == 0).sum())
+    pl.close()
+    os.environ["WO_NO_SOLVE_PATCH"] = "1"                        # level-synchronous rounds instead of Morton patches
+    try:
+        pl2 = TP.Planet(mesh, xyz, nd)
+        pl2.upload(e0, oc)
+        pl2.erode_composite_resident(6, 3e-4, 0.5, 1.0, 6, 1.16, 0.015, 2, 0.5)
+        pl2.apply_soil_creep_resident(3, 0.1125)
+        assert np.array_equal(pl2.download(), out)
+        assert pl2.last_erode_stats()["solve_patch_launches_total"] == 0
+        pl2.close()
+    finally:
+        del os.environ["WO_NO_SOLVE_PATCH"]
