@@ -17,6 +17,10 @@
  *   - "numRegions" is the reference's mesh.numRegions (requested N + 1: the pole cell is appended,
  *     js/sphere-mesh.js:179-184).  CSR arrays are mesh.adjOffset (numRegions+1) / mesh.adjList.
  *   - device entry points fail (never fall back to the CPU) when no HIP device is usable.
+ *   - threading: a wo_ctx (device + stream) and the planets created on it belong to one host thread at a time, like
+ *     the reference's single worker.  Different contexts may be driven from different threads concurrently (the
+ *     library keeps no shared mutable state); several planets in flight on one GPU this way raise throughput ~2x
+ *     (DESIGN.md section 7).
  */
 #ifndef WOROGEN_H
 #define WOROGEN_H
