@@ -55,6 +55,8 @@ constexpr int WO_PATCH = 512;          // land cells (= solve tasks) per spatial
 struct alignas(8) Granule { float v; int32_t tag; };
 struct alignas(16) SolveOut { Granule self, dep; };
 
+// {drainTarget, rank} of a cell in one 8-byte word: the solve's setup/final passes ask both of every neighbour
+struct alignas(8) TargetRank { int32_t target; int32_t rank; };
 struct Fields {
     int32_t N;                 // numRegions
     int32_t xcdTile;           // blocks per XCD tile for index-order kernels (device.h: xcd_tile)
@@ -71,6 +73,7 @@ struct Fields {
     int32_t* land;             // landCells in current order [L]
     int32_t* rank;             // rank[c] = index of c in land, -1 for ocean [N]
     int32_t* target;           // drainTarget [N]
+    TargetRank* tr;            // {target, rank} written by the receivers pass [N] (ocean: {-1, -1})
     float* cellDist;           // [N]
     float* flow;               // [N]
     uint32_t* accA; uint32_t* accB;     // pointer-doubling accumulators [N]
@@ -231,7 +234,7 @@ WO_HD inline float warp_blend(float origF, float warpedF, double warpBias, bool 
 // Hydraulic: receivers (js/terrain-post.js:566-601)
 // ------------------------------------------------------------------------------------------------
 WO_HD inline void receiver_cell(const Fields& F, int32_t r) {
-    if (F.ocean[r]) { F.target[r] = -1; return; }
+    if (F.ocean[r]) { F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z; return; }
     const double h = F.e[r];
     int32_t bestNb = -1, bestJ = -1;
     double bestDrop = -INFINITY;
@@ -250,6 +253,7 @@ WO_HD inline void receiver_cell(const Fields& F, int32_t r) {
         }
     }
     F.target[r] = bestNb;
+    { TargetRank v; v.target = bestNb; v.rank = F.rank[r]; F.tr[r] = v; }
     if (bestNb >= 0) { const float d = F.dist[bestJ]; F.cellDist[r] = (d == 0.0f || d != d) ? (float)1e-6 : d; }
 }
 
@@ -268,14 +272,15 @@ WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
 // latest event on location x strictly before the turn of task r (exclusive of r itself):
 // events on x are x's own turn and the turns of its donors (neighbours n with target[n]==x).
 WO_HD inline int32_t latest_event_before(const Fields& F, int32_t x, int32_t r) {
-    const int32_t rr = F.rank[r];
+    const int32_t rr = F.tr[r].rank;
     int32_t best = -1, bestRank = -1;          // earlier == larger rank; want the smallest rank that is > rr
-    if (x != r && F.target[x] >= 0) { const int32_t k = F.rank[x]; if (k > rr) { best = x; bestRank = k; } }
+    if (x != r) { const TargetRank v = F.tr[x]; if (v.target >= 0 && v.rank > rr) { best = x; bestRank = v.rank; } }
     for (int32_t j = F.off[x]; j < F.off[x + 1]; ++j) {
         const int32_t n = F.adj[j];
-        if (n == r || F.ocean[n] || F.target[n] != x) continue;
-        const int32_t k = F.rank[n];
-        if (k > rr && (best < 0 || k < bestRank)) { best = n; bestRank = k; }
+        if (n == r) continue;
+        const TargetRank v = F.tr[n];          // ocean cells carry target -1, never == x
+        if (v.target != x) continue;
+        if (v.rank > rr && (best < 0 || v.rank < bestRank)) { best = n; bestRank = v.rank; }
     }
     return best;
 }
@@ -367,12 +372,12 @@ WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K
 WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
     if (F.ocean[x]) return F.e[x];
     int32_t best = -1, bestRank = 0x7fffffff;      // latest == smallest rank
-    if (F.target[x] >= 0) { best = x; bestRank = F.rank[x]; }
+    { const TargetRank v = F.tr[x]; if (v.target >= 0) { best = x; bestRank = v.rank; } }
     for (int32_t j = F.off[x]; j < F.off[x + 1]; ++j) {
         const int32_t n = F.adj[j];
-        if (F.ocean[n] || F.target[n] != x) continue;
-        const int32_t k = F.rank[n];
-        if (k < bestRank) { best = n; bestRank = k; }
+        const TargetRank v = F.tr[n];              // ocean cells carry target -1, never == x
+        if (v.target != x) continue;
+        if (v.rank < bestRank) { best = n; bestRank = v.rank; }
     }
     if (best < 0) return F.e[x];
     return (best == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, best)].dep.v;
