@@ -92,7 +92,7 @@ struct wo_planet {
     int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
     uint32_t* d_keys[2] = {nullptr, nullptr};
     float *d_cellDist = nullptr, *d_flow = nullptr;
-    wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; wo::TargetRank* d_tr = nullptr;
+    wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; wo::TargetRank* d_tr = nullptr; float* d_me = nullptr;
     uint32_t *d_acc = nullptr, *d_snap = nullptr;
     int32_t *d_jump = nullptr, *d_nj = nullptr;
     int32_t* d_doneAt = nullptr;

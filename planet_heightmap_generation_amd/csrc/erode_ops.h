@@ -68,6 +68,7 @@ struct Fields {
     const uint8_t* coast;      // land cell with >=1 ocean neighbour [N]
     float* e;                  // r_elevation [N] (current)
     float* e2;                 // second elevation buffer (Jacobi ping-pong)
+    float* me;                 // thermal: elevation with ocean cells at +inf (one gather per neighbour instead of e + isOcean)
     // erodeComposite scratch
     int32_t L;                 // land cells
     int32_t* land;             // landCells in current order [L]
@@ -386,14 +387,16 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
 // ------------------------------------------------------------------------------------------------
 // Thermal (js/terrain-post.js:645-686) in exact gather form
 // ------------------------------------------------------------------------------------------------
+// F.me[r] = isOcean ? +inf : e.  An ocean neighbour then fails `nh < h`, and in the `nh > h` branch it contributes
+// nothing because its totalExcess is 0 — exactly the effect of the reference's `if (r_isOcean[nb]) continue`.
+WO_HD inline float masked_elev_cell(const Fields& F, int32_t r) { return F.ocean[r] ? INFINITY : F.e[r]; }
+
 WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) {
     double total = 0;
     if (!F.ocean[r]) {
         const double h = F.e[r];
         for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
-            const int32_t nb = F.adj[j];
-            if (F.ocean[nb]) continue;
-            const double nh = F.e[nb];
+            const double nh = F.me[F.adj[j]];
             if (nh >= h) continue;
             const double d = nd_or_eps(F.dist[j]);
             const double slope = (h - nh) / d;
@@ -416,8 +419,7 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
     int nIn = 0, nOut = 0; bool hasOut = false;
     for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
         const int32_t nb = F.adj[j];
-        if (F.ocean[nb]) continue;
-        const double nh = F.e[nb];
+        const double nh = F.me[nb];         // +inf for ocean neighbours: falls into the branch below and finds totalExcess 0
         const double d = nd_or_eps(F.dist[j]);
         if (nh < h) {                       // c sends to nb on c's own turn
             const double slope = (h - nh) / d;
@@ -454,9 +456,7 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
             for (int k = 0; k < nOut; ++k) delta = (float)((double)delta - outShare[k * stride]);
         } else if (phase == 0 && hasOut) {
             for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
-                const int32_t nb = F.adj[j];
-                if (F.ocean[nb]) continue;
-                const double nh = F.e[nb];
+                const double nh = F.me[F.adj[j]];
                 if (!(nh < h)) continue;
                 const double d = nd_or_eps(F.dist[j]);
                 const double slope = (h - nh) / d;

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, 
 __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 
 // ---------------------------------------------------------------- thermal -----------------------
+__global__ __launch_bounds__(WO_BLOCK) void k_masked_elev(Fields F) { WO_XCD_CELLS(r, F.N) F.me[r] = masked_elev_cell(F, r); }
 __global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_XCD_CELLS(r, F.N) thermal_excess_cell(F, r, talus); }
 // meshes whose largest degree is <= 16 (jittered Fibonacci spheres: 10-11 at 10^4..10^6 cells, 13 at 10^7) keep the event
 // lists in registers (12- or 16-entry private arrays are promoted to VGPRs: 103 / 115 VGPRs, no scratch); larger degrees

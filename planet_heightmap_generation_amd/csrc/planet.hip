@@ -49,7 +49,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
-    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_tr = dalloc<TargetRank>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_tr = dalloc<TargetRank>(N); p->d_me = dalloc<float>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
@@ -70,7 +70,7 @@ static void ensure_scratch(wo_planet* p) {
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.me = d_me; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -416,6 +416,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         if (iter < tIters) {
             clk.begin("thermal");
             Fields F = p->fields();
+            launch(p, FAM_THERMAL_EXCESS, k_masked_elev, gridN, WO_BLOCK, F);
             launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridN, WO_BLOCK, F, talus);
             if (p->maxDeg <= 12)
                 launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<12>, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
@@ -581,7 +582,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);

@@ -24,6 +24,7 @@ struct Emu {
     std::vector<SolveTask> task; std::vector<SolveOut> out;
     std::vector<int32_t> land, landIdx, rank, target, jumpA, doneAt, iceTarget, arank, blocker, blk;
     std::vector<TargetRank> tr;
+    std::vector<float> me;
     std::vector<uint32_t> accA;
     std::vector<double> totalExcess;
     int64_t solveRounds = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, maxSolveRounds = 0;
@@ -151,7 +152,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     F.e2 = E.e2.data(); F.rank = E.rank.data(); F.target = E.target.data(); F.cellDist = E.cellDist.data();
     F.flow = E.flow.data(); F.accA = E.accA.data(); F.jumpA = E.jumpA.data(); F.task = E.task.data(); F.out = E.out.data();
     F.doneAt = E.doneAt.data(); F.totalExcess = E.totalExcess.data(); F.glac = E.glac.data();
-    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data(); E.blocker.assign(N, -1); F.blocker = E.blocker.data(); E.blk.assign(N, -1); F.blk = E.blk.data(); E.tr.assign(N, TargetRank{-1, -1}); F.tr = E.tr.data();
+    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data(); E.blocker.assign(N, -1); F.blocker = E.blocker.data(); E.blk.assign(N, -1); F.blk = E.blk.data(); E.tr.assign(N, TargetRank{-1, -1}); F.tr = E.tr.data(); E.me.assign(N, 0.f); F.me = E.me.data();
     F.coast = E.coast.data();
     for (int32_t r = 0; r < N; ++r) E.coast[r] = coast_flag(F, r);
     for (int32_t r = 0; r < N; ++r) if (!ocean[r]) E.land.push_back(r);
@@ -230,6 +231,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
             std::memcpy(e, F.e2, sizeof(float) * (size_t)N);
         }
         if (iter < tIters) {
+            for (int32_t r = 0; r < N; ++r) F.me[r] = masked_elev_cell(F, r);
             for (int32_t r = 0; r < N; ++r) thermal_excess_cell(F, r, talus);
             { double inShare[WO_MAX_DEG], outShare[WO_MAX_DEG]; int32_t inRank[WO_MAX_DEG];
               // alternate the two own-turn forms (stored / recomputed shares) so both stay covered
