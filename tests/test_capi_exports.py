@@ -38,3 +38,25 @@ def test_product_does_not_reference_the_oracle():
     for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.cc")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + list(pkg.rglob("*.js")) + list(pkg.rglob("*.mjs")):
         txt = f.read_text(errors="ignore")
         assert "pyoracle" not in txt and "liboracle" not in txt and "wo_or_" not in txt, f
+
+
+def test_host_entry_points_reject_bad_arguments():
+    """Status 1 + a message instead of a crash: null pointers, sizes that cannot be right, malformed meshes."""
+    import numpy as np
+    from planet_heightmap_generation_amd import capi
+    L = capi.lib()
+    i32 = np.zeros(8, np.int32)
+    f32 = np.zeros(24, np.float32)
+    assert L.wo_fib_sphere_points(0, 0.75, 1.0, capi.ptr(f32)) != 0 and "wo_fib_sphere_points" in capi.last_error()
+    assert L.wo_fib_sphere_points(4, 0.75, 1.0, None) != 0
+    assert L.wo_sphere_delaunay(8, None, capi.ptr(i32), capi.ptr(i32)) != 0 and "wo_sphere_delaunay" in capi.last_error()
+    assert L.wo_neighbor_dist(4, None, None, None, None) != 0
+    assert L.wo_smooth_reconnect_plates(0, capi.ptr(i32), capi.ptr(i32), capi.ptr(i32), None, 0, 3) != 0
+    assert L.wo_smooth_reconnect_plates(4, capi.ptr(i32), capi.ptr(i32), None, None, 0, 3) != 0 and "wo_smooth_reconnect_plates" in capi.last_error()
+    assert L.wo_smooth_reconnect_plates(4, capi.ptr(i32), capi.ptr(i32), capi.ptr(i32), None, 2, 3) != 0
+    # device entry points with a NULL planet / context never dereference it
+    assert L.wo_planet_num_regions(None) == 0
+    assert L.wo_smooth_field(None, capi.ptr(f32), 1) != 0
+    assert L.wo_project_coarse_plates(None, 4, capi.ptr(i32), capi.ptr(i32), capi.ptr(f32), capi.ptr(i32), 1.0, 8, capi.ptr(i32)) != 0
+    assert L.wo_erode_composite_resident(None, 1, 3e-4, 0.5, 1.0, 1, 1.16, 0.015, 0, 0.0) != 0
+    assert not L.wo_planet_create(None, 4, capi.ptr(i32), capi.ptr(i32), capi.ptr(f32), None)
