@@ -72,14 +72,51 @@ def run_case(ref_js: Path, work: Path, name: str, N: int, seed: int, P: int, sup
     print(f"wrote tests/golden/{name}.npz ({(GOLD / (name + '.npz')).stat().st_size / 1024:.0f} KiB)  timing:", [(t['stage'], round(t['ms'])) for t in meta["timing"]])
 
 
+def run_case_large(ref_js: Path, work: Path, name: str, N: int, seed: int, P: int):
+    """A case past the reference's N > 200 000 switches (js/elevation.js: 2 warp octaves instead of 3, scaled reach /
+    pass counts).  Too large to keep whole: the mesh is rebuilt by the tests (checksums recorded here), the debug
+    layers are kept as checksums + three sampled layers, elevation / stress / Sets in full."""
+    import zlib
+    d = work / name
+    d.mkdir()
+    trs = []
+    for n, jit, sd in ((N, 0.75, seed), (20000, 0.75, seed + 137)):
+        t, h = planar_triangulation(n, jit, sd)
+        t.tofile(d / f"tri_{n}.bin"); h.tofile(d / f"he_{n}.bin")
+        trs.append({"n": n, "triangles": str(d / f"tri_{n}.bin"), "halfedges": str(d / f"he_{n}.bin")})
+    job = dict(triangulations=trs, N=N, P=P, jitter=0.75, nMag=0.4, numContinents=4, seed=seed, superPlates=True, params=None, out=str(d) + "/o_")
+    (d / "job.json").write_text(json.dumps(job))
+    subprocess.run(["node", "--max-old-space-size=12000", str(HARNESS), str(ref_js), str(d / "job.json")], check=True)
+    meta = json.loads((d / "o_meta.json").read_text())
+    rd = lambda k, dt: np.fromfile(d / f"o_{k}.bin", dtype=dt)
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes())
+    for k, dt in (("xyz", np.float32), ("adjOffset", np.int32), ("adjList", np.int32), ("neighborDist", np.float32)):
+        meta["crc_" + k] = crc(rd(k, dt))
+    for l in meta["layers"]:
+        meta["crc_dl_" + l] = crc(rd("ref_dl_" + l, np.float32))
+    meta["N"] = N
+    data = {"meta_json": np.frombuffer(json.dumps(meta).encode(), np.uint8)}
+    types = {"r_plate": np.int32, "plateSeeds": np.int32, "plateVec": np.float64, "plateDensity": np.float64, "plateIsOcean": np.uint8,
+             "r_superPlate": np.int32, "superPlateVec": np.float64, "superPlateDensity": np.float64, "superPlateIsOcean": np.uint8,
+             "ref_elevation": np.float32, "ref_stress": np.float32, "ref_mountain": np.int32, "ref_coastline": np.int32, "ref_ocean": np.int32}
+    for k, dt in types.items():
+        data[k] = rd(k, dt)
+    np.savez_compressed(GOLD / f"{name}.npz", **data)
+    print(f"wrote tests/golden/{name}.npz ({(GOLD / (name + '.npz')).stat().st_size / 1024:.0f} KiB)  timing:", [(t['stage'], round(t['ms'])) for t in meta["timing"]])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only-large", action="store_true")
     args = ap.parse_args()
     ui = dict(terrainWarp=0.75, smoothing=0.10, glacialErosion=0.5, hydraulicErosion=0.5, thermalErosion=0.1, ridgeSharpening=0.5)
     with tempfile.TemporaryDirectory(prefix="wo_golden_el_") as td:
         work = Path(td)
         ref_js = prepare_reference(Path(args.ref), work)
+        run_case_large(ref_js, work, "elev_N250000_s4_large", 250000, 4, 40)
+        if args.only_large:
+            return
         # config 1 of BASELINE.json: 10k cells, seed 1, UI defaults (P=80, super plates on), full pipeline
         run_case(ref_js, work, "elev_config1_N10000_s1", 10000, 1, 80, True, ui)
         run_case(ref_js, work, "elev_N5000_s3_nosuper", 5000, 3, 24, False, None)

@@ -48,3 +48,21 @@ def test_assign_elevation(name):
         assert np.array_equal(oc, g["ref_final_isOcean"])
         assert rms(e, g["ref_final_elevation"]) < 1e-5
     pl.close()
+
+
+def test_assign_elevation_large():
+    """250 k cells (past the reference's N > 200 000 switches) on the device against the reference's output."""
+    from planet_heightmap_generation_amd import elevation as EL, terrain_post as TP
+    from test_elevation_emulated import large_case
+    g, meta, mesh, xyz, nd, crc = large_case()
+    _, ids, vec, dens, is_ocean, sup = load_case(g)
+    pl = TP.Planet(mesh, xyz, nd)
+    res = EL.assign_elevation(mesh, xyz, is_ocean, g["r_plate"], vec, ids, EL.SimplexNoise(meta["seed"]), meta["nMag"], meta["seed"], meta["spread"],
+                              dens, sup, planet=pl)
+    assert res["mountain_r"] == g["ref_mountain"].tolist() and res["coastline_r"] == g["ref_coastline"].tolist() and res["ocean_r"] == g["ref_ocean"].tolist()
+    nbad = int((res["r_elevation"] != g["ref_elevation"]).sum())
+    nlay = sum(crc(res["debugLayers"][l]) != meta["crc_dl_" + l] for l in meta["layers"])
+    print(f"250k: elevation non-identical cells {nbad}, rms {rms(res['r_elevation'], g['ref_elevation']):.2e}; layers with a different checksum {nlay}; "
+          f"stages {[(t['stage'], round(t['ms'], 1)) for t in res['_timing']]}")
+    assert rms(res["r_elevation"], g["ref_elevation"]) < 1e-5 and rms(res["r_stress"], g["ref_stress"]) < 1e-5
+    pl.close()
