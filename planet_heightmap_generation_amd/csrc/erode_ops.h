@@ -57,6 +57,7 @@ struct alignas(16) SolveOut { Granule self, dep; };
 
 // {drainTarget, rank} of a cell in one 8-byte word: the solve's setup/final passes ask both of every neighbour
 struct alignas(8) TargetRank { int32_t target; int32_t rank; };
+constexpr int WO_CARVE_DEPS = 16;       // dependency slots per active carve task
 struct Fields {
     int32_t N;                 // numRegions
     int32_t xcdTile;           // blocks per XCD tile for index-order kernels (device.h: xcd_tile)
@@ -93,6 +94,10 @@ struct Fields {
     float* iceFlow;            // [N]
     uint8_t* iceUp;            // numIceUpstream [N]
     int32_t* arank;            // carve: rank if the cell is an active carve task else WO_NOT_DONE [N]
+    const int32_t* carveSlot;  // carve: position of an active cell in the activation list [N] (valid for active cells)
+    int32_t* carveDeps;        // carve: the lower-ranked active cells within two hops of each active task, WO_CARVE_DEPS per slot
+    int32_t* carveDepCnt;      // carve: how many (or -1: more than fit, use the full scan); entries before carveDepPos are finished
+    int32_t* carveDepPos;
     int32_t* blocker;          // carve: the unfinished lower-ranked active cell that blocked the task at its last full scan, or -1 [N]
 };
 
@@ -550,25 +555,57 @@ WO_HD inline void carve_setup_cell(const Fields& F, int32_t r) {
 
 // in-place carve of cell r (js/terrain-post.js:506-526).  Ready when no unfinished active cell within
 // two hops has a lower rank.
+// the cells a carve task must wait for: lower-ranked active cells within two hops, listed once per glacial step so
+// that a round does not walk the two-hop neighbourhood again (a round lasts as long as its slowest task, and the
+// nested adjacency walk is five dependent loads deep)
+WO_HD inline void carve_deps_cell(const Fields& F, int32_t r, int32_t slot) {
+    const int32_t myRank = F.arank[r];
+    int32_t n = 0;
+    int32_t* deps = F.carveDeps + (size_t)slot * WO_CARVE_DEPS;
+    auto note = [&](int32_t c) {
+        if (!(F.arank[c] < myRank)) return;
+        for (int i = 0; i < n && i < WO_CARVE_DEPS; ++i) if (deps[i] == c) return;       // two-hop walks meet cells twice
+        if (n < WO_CARVE_DEPS) deps[n] = c;
+        ++n;
+    };
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        note(nb);
+        for (int32_t q = F.off[nb]; q < F.off[nb + 1]; ++q) { const int32_t m = F.adj[q]; if (m != r) note(m); }
+    }
+    F.carveDepCnt[slot] = n <= WO_CARVE_DEPS ? n : -1;
+    F.carveDepPos[slot] = 0;
+}
+
 WO_HD inline bool carve_task(const Fields& F, int32_t r, int32_t round, double gCarveRate, double gConvergenceBonus,
                              double glacialStrength) {
     const int32_t myRank = F.arank[r];
-    // cheap test first: the cell that blocked us at the last full scan (1-2 loads instead of ~40)
-    const int32_t b0 = F.blocker[r];
-    if (b0 >= 0 && !(F.doneAt[b0] < round)) return false;
-    // full 2-hop scan; remember the unfinished blocker closest to us in rank (it tends to finish last)
-    int32_t blk = -1, blkRank = -1;
-    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
-        const int32_t n = F.adj[j];
-        { const int32_t a = F.arank[n]; if (a < myRank && a > blkRank && !(F.doneAt[n] < round)) { blk = n; blkRank = a; } }
-        for (int32_t q = F.off[n]; q < F.off[n + 1]; ++q) {
-            const int32_t mcell = F.adj[q];
-            if (mcell == r) continue;
-            const int32_t a = F.arank[mcell];
-            if (a < myRank && a > blkRank && !(F.doneAt[mcell] < round)) { blk = mcell; blkRank = a; }
+    int32_t depCnt = -1, slot = -1;
+    if (F.carveDeps) { slot = F.carveSlot[r]; depCnt = F.carveDepCnt[slot]; }
+    if (depCnt >= 0) {
+        // listed dependencies: resume at the first one that was still open last time
+        const int32_t* deps = F.carveDeps + (size_t)slot * WO_CARVE_DEPS;
+        int32_t i = F.carveDepPos[slot];
+        while (i < depCnt && F.doneAt[deps[i]] < round) ++i;
+        if (i < depCnt) { F.carveDepPos[slot] = i; return false; }
+    } else {
+        // cheap test first: the cell that blocked us at the last full scan (1-2 loads instead of ~40)
+        const int32_t b0 = F.blocker[r];
+        if (b0 >= 0 && !(F.doneAt[b0] < round)) return false;
+        // full 2-hop scan; remember the unfinished blocker closest to us in rank (it tends to finish last)
+        int32_t blk = -1, blkRank = -1;
+        for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+            const int32_t n = F.adj[j];
+            { const int32_t a = F.arank[n]; if (a < myRank && a > blkRank && !(F.doneAt[n] < round)) { blk = n; blkRank = a; } }
+            for (int32_t q = F.off[n]; q < F.off[n + 1]; ++q) {
+                const int32_t mcell = F.adj[q];
+                if (mcell == r) continue;
+                const int32_t a = F.arank[mcell];
+                if (a < myRank && a > blkRank && !(F.doneAt[mcell] < round)) { blk = mcell; blkRank = a; }
+            }
         }
+        if (blk >= 0) { F.blocker[r] = blk; return false; }
     }
-    if (blk >= 0) { F.blocker[r] = blk; return false; }
     const double fl = F.iceFlow[r];
     const double deepening = gCarveRate * pow(fl, 0.6) * glacialStrength;
     float er = (float)((double)F.e[r] - deepening);

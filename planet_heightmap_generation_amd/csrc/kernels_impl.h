@@ -441,6 +441,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_setup(Fields F, int32_t* lis
         block_append(act, r, list, count);
     }
 }
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_deps(Fields F, const int32_t* list, const int32_t* count, int32_t* carveSlot) {
+    const int32_t n = *count;
+    WO_GRID_STRIDE(i, n) { const int32_t r = list[i]; carveSlot[r] = i; carve_deps_cell(F, r, i); }
+}
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
                                                            int32_t* outCount, int32_t* zeroCount, int32_t round, double gCarve,
                                                            double gConv, double gStrength) {

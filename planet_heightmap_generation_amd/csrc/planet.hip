@@ -49,7 +49,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
-    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_tr = dalloc<TargetRank>(N); p->d_me = dalloc<float>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_tr = dalloc<TargetRank>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
@@ -70,7 +70,7 @@ static void ensure_scratch(wo_planet* p) {
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.me = d_me; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -374,6 +374,18 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 });
             WO_HIP(hipMemsetAsync(p->d_counters + 3, 0, sizeof(int32_t), s));
             launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
+            {   // dependency lists of the active tasks (once per glacial step)
+                const int32_t active = read_count(p, p->d_counters + 3);
+                if ((int64_t)active > p->carveCap) {
+                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos);
+                    p->carveCap = (int64_t)active + active / 4 + 1024;
+                    p->d_carveDeps = dalloc<int32_t>((size_t)p->carveCap * WO_CARVE_DEPS);
+                    p->d_carveDepCnt = dalloc<int32_t>((size_t)p->carveCap); p->d_carveDepPos = dalloc<int32_t>((size_t)p->carveCap);
+                }
+                F.carveDeps = p->d_carveDeps; F.carveDepCnt = p->d_carveDepCnt; F.carveDepPos = p->d_carveDepPos;
+                if (active > 0)
+                    launch(p, FAM_CARVE_SETUP, k_carve_deps, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveSlot);
+            }
             // the activation list was written to listB; rounds alternate A/B starting with out = A
             carveRounds += run_rounds(p, p->d_listB, 0, true, 16,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
@@ -582,7 +594,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);
