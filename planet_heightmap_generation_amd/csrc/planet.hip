@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -553,6 +554,17 @@ wo_planet* wo_planet_create(wo_ctx* ctx, int32_t numRegions, const int32_t* adjO
         }
         if (maxDeg > WO_MAX_DEG) { set_error("wo_planet_create: vertex degree " + std::to_string(maxDeg) + " exceeds the supported maximum " + std::to_string(WO_MAX_DEG)); return nullptr; }
         for (int32_t i = 0; i < E; ++i) if (adjList[i] < 0 || adjList[i] >= N) { set_error("wo_planet_create: adjList entry out of range"); return nullptr; }
+        {   // simple graph: the order-exact parallel passes rely on a cell's neighbours being distinct cells other than itself
+            std::atomic<int> bad{0};
+            parallel_ranges(N, [&](int64_t b, int64_t e, int) {
+                for (int64_t r = b; r < e && !bad.load(std::memory_order_relaxed); ++r)
+                    for (int32_t i = adjOffset[r]; i < adjOffset[r + 1]; ++i) {
+                        if (adjList[i] == r) { bad = 1; break; }
+                        for (int32_t j = adjOffset[r]; j < i; ++j) if (adjList[j] == adjList[i]) { bad = 2; break; }
+                    }
+            });
+            if (bad) { set_error(bad == 1 ? "wo_planet_create: a cell lists itself as a neighbour" : "wo_planet_create: a cell lists the same neighbour twice"); return nullptr; }
+        }
         p = new wo_planet();
         p->ctx = ctx; p->N = N; p->E = E; p->maxDeg = maxDeg;
         p->h_off.assign(adjOffset, adjOffset + N + 1);
