@@ -175,6 +175,12 @@ def test_edge_cases(TP, oracle):
     with pytest.raises(capi.WorogenError):
         pl.warp_terrain_resident(1, 0.5, use_hotspot=True)      # no hotspot uploaded
     pl.close()
+    # malformed meshes are refused at creation: a repeated neighbour, a self loop, an index out of range
+    for pos, val, msg in ((mesh.adjOffset[5], mesh.adjList[mesh.adjOffset[5] + 1], "twice"), (mesh.adjOffset[7], 7, "itself"), (3, V + 5, "out of range")):
+        bad = mesh.adjList.copy()
+        bad[pos] = val
+        with pytest.raises(capi.WorogenError, match=msg):
+            TP.Planet(oracle.Mesh(mesh.adjOffset, bad), xyz, None)
 
 
 def test_ties_on_larger_mesh(TP, oracle):
