@@ -298,3 +298,27 @@ def test_headline_size_against_oracle(TP, oracle):
     pl.apply_soil_creep(got2, oc, 3, 0.1125)
     assert np.array_equal(got2, ref4)
     pl.close()
+
+
+def test_planets_in_flight_match_sequential(TP):
+    """Four planets in flight on one GPU (own context / stream / host thread each) give bit for bit what the same
+    seeds give one after the other: the library shares no mutable state between planets."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    from planet_heightmap_generation_amd.ensemble import EnsembleRunner
+    mesh, xyz, nd = S.build_sphere(60000, 0.75, 5)
+
+    def job(pl, seed):
+        pl.synthetic_terrain(seed)
+        pl.warp_terrain_resident(seed, 0.75)
+        pl.ocean_from_elevation()
+        pl.erode_composite_resident(8, 3e-4, 0.5, 1.0, 8, 1.16, 0.015, 3, 0.5)
+        pl.apply_soil_creep_resident(3, 0.1125)
+        return pl.download()
+    seeds = [1, 2, 3, 4, 5, 6, 7, 8]
+    seq = EnsembleRunner(mesh, xyz, nd, in_flight=1).map(job, seeds)
+    par = EnsembleRunner(mesh, xyz, nd, in_flight=4).map(job, seeds)
+    for a, b in zip(seq, par):
+        assert np.array_equal(a, b)
+    assert not np.array_equal(seq[0], seq[1])
+    with pytest.raises(ZeroDivisionError):
+        EnsembleRunner(mesh, xyz, nd, in_flight=2).map(lambda pl, s: 1 // 0, [1, 2, 3])
