@@ -343,10 +343,12 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         for (int32_t k = 0; k < L; ++k) { const int32_t i = byR[k]; if (root[i] >= 0) list2[fill[root[i]]++] = i; }
     }
     // Trees are numbered by their seed's original id, i.e. along the Fibonacci spiral: consecutive ids are spatial
-    // neighbours, so workers take contiguous chunks.  Measured on the 2-socket EPYC GPU box: 4-8 workers give ~3x
-    // on these pointer-chasing passes; 16+ cores contend in the memory system and per-tree time rises 7x.
+    // neighbours, so workers take contiguous chunks.  Measured on the 2-socket EPYC GPU box with the packed records and
+    // huge pages: 6 workers 199 ms, 12 -> 136, 24 -> 102, 48 -> 91 ms for the two calls of a step; 24 is the default
+    // (WO_FLOOD_THREADS overrides), which leaves room for several ranks / planets per socket.
     auto for_trees = [&](const std::vector<int32_t>& cnt, auto body) {
-        const int nt = std::max(1, std::min<int>(std::min(host_threads(), 6), nTrees));
+        static const int capThreads = [] { const char* e = std::getenv("WO_FLOOD_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 24; }();
+        const int nt = std::max(1, std::min<int>(std::min(host_threads(), capThreads), nTrees));
         const int64_t total = cnt[nTrees];
         const int64_t perChunk = std::max<int64_t>(2048, total / (nt * 16));
         std::vector<int32_t> chunkStart;
