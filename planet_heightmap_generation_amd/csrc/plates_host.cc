@@ -26,36 +26,68 @@ void smooth_reconnect_plates_host(int32_t N, const int32_t* off, const int32_t* 
         if (pid >= 0 && pid < N && r_plate[pid] == pid) isSeed[pid] = 1;
     }
     // :265-287 majority vote, in place, ascending r.  Distinct plates are collected in neighbour order; the first
-    // plate reaching the highest count wins (strict > while scanning).
-    int32_t cand[64]; int32_t cnt[64];
-    for (int32_t pass = 0; pass < numPasses; ++pass) {
-        const double threshold = pass == 0 ? 0.4 : 0.5;
-        for (int32_t r = 0; r < N; ++r) {
-            const int32_t b = off[r], e = off[r + 1], deg = e - b;
-            int32_t nd = 0;
-            bool overflow = false;
+    // plate reaching the highest count wins (strict > while scanning).  A cell whose neighbours all carry its own plate
+    // keeps it (the vote returns that plate), so only cells with a differing neighbour need the vote: the boundary
+    // cells at the start of the pass (parallel scan, ascending) plus, as the sweep moves on, higher-numbered neighbours
+    // of cells it has just changed (a small min-heap merged into the sweep).  Same visiting order for every cell that
+    // can change, a few per cent of the cells visited.
+    auto vote = [&](int32_t r, double threshold) -> bool {
+        int32_t cand[64]; int32_t cnt[64];
+        const int32_t b = off[r], e = off[r + 1], deg = e - b;
+        int32_t nd = 0;
+        bool overflow = false;
+        for (int32_t j = b; j < e; ++j) {
+            const int32_t p = r_plate[adj[j]];
+            int32_t k = 0;
+            while (k < nd && cand[k] != p) ++k;
+            if (k < nd) { ++cnt[k]; continue; }
+            if (nd == 64) { overflow = true; break; }
+            cand[nd] = p; cnt[nd] = 1; ++nd;
+        }
+        int32_t bestPlate = r_plate[r], bestCount = 0;
+        if (!overflow) {
+            for (int32_t k = 0; k < nd; ++k) if (cnt[k] > bestCount) { bestCount = cnt[k]; bestPlate = cand[k]; }
+        } else {                                    // more than 64 distinct neighbour plates: general path
+            std::vector<std::pair<int32_t, int32_t>> v;
             for (int32_t j = b; j < e; ++j) {
                 const int32_t p = r_plate[adj[j]];
-                int32_t k = 0;
-                while (k < nd && cand[k] != p) ++k;
-                if (k < nd) { ++cnt[k]; continue; }
-                if (nd == 64) { overflow = true; break; }
-                cand[nd] = p; cnt[nd] = 1; ++nd;
+                size_t k = 0;
+                while (k < v.size() && v[k].first != p) ++k;
+                if (k < v.size()) ++v[k].second; else v.push_back({p, 1});
             }
-            int32_t bestPlate = r_plate[r], bestCount = 0;
-            if (!overflow) {
-                for (int32_t k = 0; k < nd; ++k) if (cnt[k] > bestCount) { bestCount = cnt[k]; bestPlate = cand[k]; }
-            } else {                                    // more than 64 distinct neighbour plates: general path
-                std::vector<std::pair<int32_t, int32_t>> v;
-                for (int32_t j = b; j < e; ++j) {
-                    const int32_t p = r_plate[adj[j]];
-                    size_t k = 0;
-                    while (k < v.size() && v[k].first != p) ++k;
-                    if (k < v.size()) ++v[k].second; else v.push_back({p, 1});
+            for (auto& pr : v) if (pr.second > bestCount) { bestCount = pr.second; bestPlate = pr.first; }
+        }
+        if ((double)bestCount > deg * threshold && !isSeed[r] && r_plate[r] != bestPlate) { r_plate[r] = bestPlate; return true; }
+        return false;
+    };
+    std::vector<uint8_t> queued(N, 0);
+    for (int32_t pass = 0; pass < numPasses; ++pass) {
+        const double threshold = pass == 0 ? 0.4 : 0.5;
+        std::vector<std::vector<int32_t>> part(host_threads() + 1);
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) {
+            for (int64_t r = b; r < e; ++r) {
+                const int32_t own = r_plate[r];
+                for (int32_t j = off[r]; j < off[r + 1]; ++j) if (r_plate[adj[j]] != own) { part[t].push_back((int32_t)r); break; }
+            }
+        });
+        std::vector<int32_t> sweep;
+        for (auto& v : part) sweep.insert(sweep.end(), v.begin(), v.end());           // ascending: ranges ascend with t
+        for (int32_t r : sweep) queued[r] = 1;
+        std::vector<int32_t> heap;                                                     // cells that became boundary during this pass
+        auto cmp = [](int32_t a, int32_t b) { return a > b; };
+        size_t si = 0;
+        for (;;) {
+            int32_t r;
+            if (!heap.empty() && (si >= sweep.size() || heap.front() < sweep[si])) { std::pop_heap(heap.begin(), heap.end(), cmp); r = heap.back(); heap.pop_back(); }
+            else if (si < sweep.size()) r = sweep[si++];
+            else break;
+            queued[r] = 0;
+            if (vote(r, threshold)) {
+                for (int32_t j = off[r]; j < off[r + 1]; ++j) {
+                    const int32_t n = adj[j];
+                    if (n > r && !queued[n]) { queued[n] = 1; heap.push_back(n); std::push_heap(heap.begin(), heap.end(), cmp); }
                 }
-                for (auto& pr : v) if (pr.second > bestCount) { bestCount = pr.second; bestPlate = pr.first; }
             }
-            if ((double)bestCount > deg * threshold && !isSeed[r]) r_plate[r] = bestPlate;
         }
     }
     // :292-320 components of equal plate id; per plate the largest, the first found winning ties
