@@ -335,12 +335,30 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
     // lowers other cells of the path below their flood surface, and the reference tests `deficit > EPS` against
     // the current height when it reaches them, :154-155.)
     int32_t* list2 = S.list2.data();
-    {
-        for (int32_t i = 0; i < L; ++i) if (root[i] >= 0) cnt2[root[i] + 1]++;
-        for (int32_t t = 0; t < nTrees; ++t) cnt2[t + 1] += cnt2[t];
-        std::vector<int32_t> fill(cnt2.begin(), cnt2.end() - 1);
+    {   // stable counting sort of the ascending-id land list by tree, in parallel: per-worker counts per tree
+        // ([tree][worker] so the prefix runs sequentially), then every worker scatters its own contiguous share
         const int32_t* byR = S.landByR.data();
-        for (int32_t k = 0; k < L; ++k) { const int32_t i = byR[k]; if (root[i] >= 0) list2[fill[root[i]]++] = i; }
+        const int T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)host_threads(), 16, (int64_t)L / 65536 + 1}));
+        std::vector<int32_t> cw((size_t)nTrees * T, 0);
+        auto share = [&](int t, int64_t& b, int64_t& e) { b = (int64_t)L * t / T; e = (int64_t)L * (t + 1) / T; };
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+            int64_t b, e; share(t, b, e);
+            for (int64_t k = b; k < e; ++k) { const int32_t r = root[byR[k]]; if (r >= 0) ++cw[(size_t)r * T + t]; }
+        });
+        for (auto& x : th) x.join();
+        int32_t run = 0;
+        for (int32_t tr = 0; tr < nTrees; ++tr) {
+            cnt2[tr] = run;
+            for (int t = 0; t < T; ++t) { const int32_t c = cw[(size_t)tr * T + t]; cw[(size_t)tr * T + t] = run; run += c; }
+        }
+        cnt2[nTrees] = run;
+        th.clear();
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t]() {
+            int64_t b, e; share(t, b, e);
+            for (int64_t k = b; k < e; ++k) { const int32_t i = byR[k]; const int32_t r = root[i]; if (r >= 0) list2[cw[(size_t)r * T + t]++] = i; }
+        });
+        for (auto& x : th) x.join();
     }
     // Trees are numbered by their seed's original id, i.e. along the Fibonacci spiral: consecutive ids are spatial
     // neighbours, so workers take contiguous chunks.  Measured on the 2-socket EPYC GPU box with the packed records and
