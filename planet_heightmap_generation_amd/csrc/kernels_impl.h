@@ -346,8 +346,12 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
     if (!done && !unresolved) { mine.self.tag = -1; mine.dep.tag = -1; }
     s_out[2 * tid] = mine.self; s_out[2 * tid + 1] = mine.dep;
     __syncthreads();
-    // ---- run: poll the patch-local predecessors
-    volatile Granule* vs = s_out;
+    // ---- run: poll the patch-local predecessors.  A granule is one aligned 64-bit LDS word {value, tag}: it is published
+    // and read with single 64-bit accesses, so no fence sits on the chain (a workgroup fence would also wait for the
+    // global store of the result, hundreds of cycles per chain step) and a poll is one LDS round trip, not two.
+    volatile unsigned long long* vs = reinterpret_cast<volatile unsigned long long*>(s_out);
+    auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
+    const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
     for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(unresolved); ++spin) {
         // a wave that only waits should not compete for issue slots with the waves that carry a chain
         if (spin) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
@@ -356,22 +360,21 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
         double a = er, b = et, c = et2;
         auto rd = [&](int32_t g, double& v) {
             if (g < 0 || !is_local(g)) return;
-            const int32_t tg = vs[g - base].tag;
+            const unsigned long long w = vs[g - base];
+            const int32_t tg = (int32_t)(w >> 32);
             if (tg < 0) fail = g;
             else if (tg == 0) open = 1;
-            else v = vs[g - base].v;
+            else v = __uint_as_float((uint32_t)w);
         };
         rd(T.predSelf, a); rd(T.predT, b); rd(T.predT2, c);
         if (fail >= 0) {
+            vs[2 * tid] = BLOCKED; vs[2 * tid + 1] = BLOCKED;
             F.blk[s] = fail;
-            vs[2 * tid].tag = -1; vs[2 * tid + 1].tag = -1;
             unresolved = false;
         } else if (!open) {
             const SolveOut o = solve_apply(T, factor, a, b, c, launchTag);
-            F.out[s] = o;
-            vs[2 * tid].v = o.self.v; vs[2 * tid + 1].v = o.dep.v;
-            __threadfence_block();                          // values before tags
-            vs[2 * tid].tag = launchTag; vs[2 * tid + 1].tag = launchTag;
+            vs[2 * tid] = pack(o.self); vs[2 * tid + 1] = pack(o.dep);      // consumers first ...
+            F.out[s] = o;                                                   // ... the global copy is for later launches
             unresolved = false; done = true;
         }
     }
