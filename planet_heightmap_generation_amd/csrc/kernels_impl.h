@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
 constexpr int WO_PATCH_THREADS = WO_PATCH;                 // one task per thread
 constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;
 #ifndef WO_PATCH_SLEEP
-#define WO_PATCH_SLEEP 2                                    // x64 clocks between polls
+#define WO_PATCH_SLEEP 1
 #endif               // passes of one wave over its tasks before it gives up for this launch
 // Inside a launch the waves of a patch do not meet at barriers: every task polls its patch-local predecessors in LDS
 // and runs as soon as they are there (value stored before tag, tag read before value; LDS operations of a wave stay
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
     const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
     for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(unresolved); ++spin) {
         // a wave that only waits should not compete for issue slots with the waves that carry a chain
-        if (spin) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
+        if (spin && WO_PATCH_SLEEP) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
         if (!unresolved) continue;
         int32_t open = 0, fail = -1;
         double a = er, b = et, c = et2;
