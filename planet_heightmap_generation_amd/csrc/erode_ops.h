@@ -585,9 +585,18 @@ WO_HD inline bool carve_task(const Fields& F, int32_t r, int32_t round, double g
     if (depCnt >= 0) {
         // listed dependencies: resume at the first one that was still open last time
         const int32_t* deps = F.carveDeps + (size_t)slot * WO_CARVE_DEPS;
-        int32_t i = F.carveDepPos[slot];
-        while (i < depCnt && F.doneAt[deps[i]] < round) ++i;
-        if (i < depCnt) { F.carveDepPos[slot] = i; return false; }
+        // all of them must be looked at before the task may run: issue the loads together instead of one
+        // dependent round trip per entry (this walk is on the critical path of the round)
+        const int32_t pos = F.carveDepPos[slot];
+        int32_t dv[WO_CARVE_DEPS], da[WO_CARVE_DEPS];
+#pragma unroll
+        for (int k = 0; k < WO_CARVE_DEPS; ++k) dv[k] = (k >= pos && k < depCnt) ? deps[k] : -1;
+#pragma unroll
+        for (int k = 0; k < WO_CARVE_DEPS; ++k) da[k] = dv[k] >= 0 ? F.doneAt[dv[k]] : -1;
+        int32_t firstOpen = depCnt;
+#pragma unroll
+        for (int k = WO_CARVE_DEPS - 1; k >= 0; --k) if (dv[k] >= 0 && !(da[k] < round)) firstOpen = k;
+        if (firstOpen < depCnt) { F.carveDepPos[slot] = firstOpen; return false; }
     } else {
         // cheap test first: the cell that blocked us at the last full scan (1-2 loads instead of ~40)
         const int32_t b0 = F.blocker[r];
@@ -610,18 +619,48 @@ WO_HD inline bool carve_task(const Fields& F, int32_t r, int32_t round, double g
     const double deepening = gCarveRate * pow(fl, 0.6) * glacialStrength;
     float er = (float)((double)F.e[r] - deepening);
     F.e[r] = er;
-    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
-        const int32_t nb = F.adj[j];
-        if (F.ocean[nb]) continue;
-        const double d = nd_or_eps(F.dist[j]);
-        const double slope = fabs((double)er - (double)F.e[nb]) / d;
-        double f = 1 - slope;
-        if (!(f > 0)) f = (f != f) ? f : 0;
-        F.e[nb] = (float)((double)F.e[nb] - deepening * 0.4 * f);
+    // A round lasts as long as its slowest task.  The neighbours are distinct cells and none of them is r (checked at
+    // planet creation), so their updates are independent: fetch every neighbour's inputs before the first store — the
+    // compiler cannot prove that the stores do not alias the next iteration's loads and would serialise the round trips.
+    const int32_t jb = F.off[r], deg = F.off[r + 1] - jb;
+    if (deg <= 8) {
+        int32_t nbs[8]; float en[8], dn[8]; uint8_t on[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { nbs[k] = k < deg ? F.adj[jb + k] : r; dn[k] = k < deg ? F.dist[jb + k] : 1.0f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { on[k] = F.ocean[nbs[k]]; en[k] = F.e[nbs[k]]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= deg || on[k]) continue;
+            const double d = nd_or_eps(dn[k]);
+            const double slope = fabs((double)er - (double)en[k]) / d;
+            double f = 1 - slope;
+            if (!(f > 0)) f = (f != f) ? f : 0;
+            F.e[nbs[k]] = (float)((double)en[k] - deepening * 0.4 * f);
+        }
+    } else {
+        for (int32_t j = jb; j < jb + deg; ++j) {
+            const int32_t nb = F.adj[j];
+            if (F.ocean[nb]) continue;
+            const double d = nd_or_eps(F.dist[j]);
+            const double slope = fabs((double)er - (double)F.e[nb]) / d;
+            double f = 1 - slope;
+            if (!(f > 0)) f = (f != f) ? f : 0;
+            F.e[nb] = (float)((double)F.e[nb] - deepening * 0.4 * f);
+        }
     }
     if (F.iceUp[r] >= 2) F.e[r] = (float)((double)F.e[r] - gConvergenceBonus * pow(fl, 0.4));
     F.doneAt[r] = round;
     return true;
+}
+
+// the cell a task that just failed carve_task() is waiting for (device schedule: carried in the pending-list entry)
+WO_HD inline int32_t carve_current_blocker(const Fields& F, int32_t r) {
+    if (F.carveDeps) {
+        const int32_t slot = F.carveSlot[r];
+        if (F.carveDepCnt[slot] >= 0) return F.carveDeps[(size_t)slot * WO_CARVE_DEPS + F.carveDepPos[slot]];
+    }
+    return F.blocker[r];
 }
 
 // moraine (js/terrain-post.js:529-537) gathered per target, then fjord (540-551) and clamp (554-556)

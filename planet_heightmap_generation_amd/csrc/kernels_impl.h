@@ -459,6 +459,41 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_
         block_append(pending, r, out, outCount);
     }
 }
+// Carve rounds on {task, blocker} entries: a round is as long as its longest chain of dependent loads, and a parked task
+// only needs list entry -> doneAt[blocker]; the task's own records are touched when that blocker has finished.
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_pairs_init(const int32_t* list, const int32_t* count, int2* out) {
+    const int32_t n = *count;
+    WO_GRID_STRIDE(i, n) out[i] = make_int2(list[i], -1);
+}
+__device__ inline void block_append2(bool flag, int2 v, int2* out, int32_t* outCount) {
+    __shared__ int32_t s_base2, s_wave2[WO_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_wave2[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < WO_BLOCK / 64; ++w) { const int32_t c = s_wave2[w]; s_wave2[w] = tot; tot += c; }
+        s_base2 = tot ? atomicAdd(outCount, tot) : 0;
+    }
+    __syncthreads();
+    if (flag) out[s_base2 + s_wave2[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    __syncthreads();
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_round_pairs(Fields F, const int2* in, const int32_t* inCount, int2* out, int32_t* outCount,
+                                                                 int32_t* zeroCount, int32_t round, double gCarve, double gConv, double gStrength) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    const int32_t n = *inCount;
+    WO_BLOCK_STRIDE(i, valid, n) {
+        bool pending = false; int2 ent = make_int2(-1, -1);
+        if (valid) {
+            ent = in[i];
+            if (ent.y >= 0 && !(F.doneAt[ent.y] < round)) pending = true;             // still parked on the same blocker
+            else if (!carve_task(F, ent.x, round, gCarve, gConv, gStrength)) { pending = true; ent.y = carve_current_blocker(F, ent.x); }
+        }
+        block_append2(pending, ent, out, outCount);
+    }
+}
 __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDep, double gFjord) {
     WO_XCD_CELLS(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
 }

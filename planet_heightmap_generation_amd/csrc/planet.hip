@@ -378,20 +378,38 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             {   // dependency lists of the active tasks (once per glacial step)
                 const int32_t active = read_count(p, p->d_counters + 3);
                 if ((int64_t)active > p->carveCap) {
-                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos);
+                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]);
                     p->carveCap = (int64_t)active + active / 4 + 1024;
                     p->d_carveDeps = dalloc<int32_t>((size_t)p->carveCap * WO_CARVE_DEPS);
                     p->d_carveDepCnt = dalloc<int32_t>((size_t)p->carveCap); p->d_carveDepPos = dalloc<int32_t>((size_t)p->carveCap);
+                    p->d_carvePairs[0] = dalloc<int2>((size_t)p->carveCap); p->d_carvePairs[1] = dalloc<int2>((size_t)p->carveCap);
                 }
                 F.carveDeps = p->d_carveDeps; F.carveDepCnt = p->d_carveDepCnt; F.carveDepPos = p->d_carveDepPos;
                 if (active > 0)
                     launch(p, FAM_CARVE_SETUP, k_carve_deps, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveSlot);
             }
-            // the activation list was written to listB; rounds alternate A/B starting with out = A
-            carveRounds += run_rounds(p, p->d_listB, 0, true, 16,
-                [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
-                    launch(p, FAM_CARVE_ROUND, k_carve_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k, gCarve, gConv, gStrength);
-                });
+            // rounds over {task, blocker} entries (k_carve_round_pairs); counters as in run_rounds: c[k%3] in, c[(k+1)%3] out
+            {
+                int32_t* c = p->d_counters;
+                WO_HIP(hipMemcpyAsync(c + 1, c + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+                WO_HIP(hipMemsetAsync(c, 0, sizeof(int32_t), s));
+                WO_HIP(hipMemsetAsync(c + 2, 0, sizeof(int32_t), s));
+                int32_t count = read_count(p, c + 1);
+                if (count > 0) launch(p, FAM_CARVE_SETUP, k_carve_pairs_init, blocks_for(count), WO_BLOCK, (const int32_t*)p->d_listB, (const int32_t*)(c + 1), p->d_carvePairs[0]);
+                int64_t k = 1;
+                int cur = 0;
+                while (count > 0) {
+                    const int grid = blocks_for(count, 2048);
+                    for (int b = 0; b < 16; ++b, ++k) {
+                        launch(p, FAM_CARVE_ROUND, k_carve_round_pairs, grid, WO_BLOCK, F, (const int2*)p->d_carvePairs[cur], (const int32_t*)(c + (k % 3)),
+                               p->d_carvePairs[cur ^ 1], c + ((k + 1) % 3), c + ((k + 2) % 3), (int32_t)k, gCarve, gConv, gStrength);
+                        cur ^= 1;
+                    }
+                    count = read_count(p, c + (k % 3));
+                    if (k > 4 * (int64_t)p->N + 1024) throw HipError{"carve rounds do not converge"};
+                }
+                carveRounds += k - 1;
+            }
             launch(p, FAM_MORAINE, k_moraine_fjord, gridN, WO_BLOCK, F, gDep, gFjord);
             clk.end();
         }
@@ -606,7 +624,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);
