@@ -156,6 +156,14 @@ int wo_smooth_field(wo_planet* p, float* field, int32_t passes);
  * planet's stream until wo_planet_sync / wo_planet_download. */
 int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_isOcean);
 int wo_planet_download(wo_planet* p, float* r_elevation);
+/* Band-decomposed Jacobi passes (smoothElevation / applySoilCreep on one index band per GPU, banded.py): the planet is a
+ * band plus its one-ring halo.  set_halo stores the local indices whose values go to / come from the neighbouring
+ * bands; after each *_resident iteration pack gathers the resident r_elevation at the send indices (into hostOut, or
+ * into the device buffer deviceOut that is handed to RCCL) and unpack scatters the received values to the receive
+ * indices.  Exactly one of the host / device pointers is non-NULL. */
+int wo_planet_set_halo(wo_planet* p, const int32_t* sendIdx, int32_t nSend, const int32_t* recvIdx, int32_t nRecv);
+int wo_planet_pack_halo(wo_planet* p, float* hostOut, void* deviceOut);
+int wo_planet_unpack_halo(wo_planet* p, const float* hostIn, const void* deviceIn);
 /* r_isOcean[r] = r_elevation[r] <= 0 on the resident field (js/planet-worker.js:51-54) */
 int wo_planet_ocean_from_elevation(wo_planet* p);
 int wo_planet_download_ocean(wo_planet* p, uint8_t* r_isOcean);

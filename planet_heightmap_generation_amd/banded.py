@@ -121,6 +121,53 @@ def banded_jacobi(part: BandPart, field_local: np.ndarray, iterations: int, step
             exchange_halo(part, field_local, dist, device)
 
 
+class ResidentBand:
+    """A band whose field stays in HBM: after each resident iteration only the halo values move (pack kernel -> send /
+    receive -> unpack kernel).  With `device` the pack / unpack buffers are torch device tensors that go straight to
+    RCCL; without it they are staged through pinned host memory (gloo in the tests)."""
+
+    def __init__(self, part: BandPart, planet):
+        self.part, self.planet = part, planet
+        self.peers = [j for j in range(len(part.send)) if j != part.rank and (part.send[j].size or part.recv[j].size)]
+        self.send_sizes = [int(part.send[j].size) for j in self.peers]
+        self.recv_sizes = [int(part.recv[j].size) for j in self.peers]
+        cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.empty(0, np.int32)
+        planet.set_halo(cat([part.send[j] for j in self.peers]), cat([part.recv[j] for j in self.peers]))
+
+    def exchange(self, dist, device=None) -> None:
+        import torch
+        ns, nr = sum(self.send_sizes), sum(self.recv_sizes)
+        if device is not None:
+            sbuf = torch.empty(max(ns, 1), dtype=torch.float32, device=device)
+            rbuf = torch.empty(max(nr, 1), dtype=torch.float32, device=device)
+            self.planet.pack_halo(device_ptr=sbuf.data_ptr())
+        else:
+            sbuf = torch.from_numpy(self.planet.pack_halo()) if ns else torch.empty(0)
+            rbuf = torch.empty(nr, dtype=torch.float32)
+        ops, so, ro = [], 0, 0
+        for j, a, b in zip(self.peers, self.send_sizes, self.recv_sizes):
+            if a:
+                ops.append(dist.P2POp(dist.isend, sbuf[so:so + a], j)); so += a
+            if b:
+                ops.append(dist.P2POp(dist.irecv, rbuf[ro:ro + b], j)); ro += b
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if nr:
+            if device is not None:
+                torch.cuda.synchronize(device)
+                self.planet.unpack_halo(device_ptr=rbuf.data_ptr())
+            else:
+                self.planet.unpack_halo(rbuf.numpy())
+
+    def jacobi(self, step_resident: Callable[[], None], iterations: int, dist, device=None) -> None:
+        """`step_resident()` advances the resident field by ONE iteration (e.g. ``lambda: planet.apply_soil_creep_resident(1, s)``)."""
+        for _ in range(iterations):
+            step_resident()
+            if dist is not None:
+                self.exchange(dist, device)
+
+
 def gather_owned(plan: BandPlan, rank: int, field_local: np.ndarray, dist) -> np.ndarray | None:
     """Assemble the global field on rank 0 from every rank's owned cells (testing / output)."""
     import torch

@@ -51,6 +51,9 @@ SIGNATURES = {
     "wo_smooth_reconnect_plates": (C.c_int, [_c_i32, _p, _p, _p, _p, _c_i32, _c_i32]),
     "wo_planet_upload": (C.c_int, [_p, _p, _p]),
     "wo_planet_download": (C.c_int, [_p, _p]),
+    "wo_planet_set_halo": (C.c_int, [_p, _p, _c_i32, _p, _c_i32]),
+    "wo_planet_pack_halo": (C.c_int, [_p, _p, _p]),
+    "wo_planet_unpack_halo": (C.c_int, [_p, _p, _p]),
     "wo_planet_ocean_from_elevation": (C.c_int, [_p]),
     "wo_planet_download_ocean": (C.c_int, [_p, _p]),
     "wo_planet_sync": (C.c_int, [_p]),

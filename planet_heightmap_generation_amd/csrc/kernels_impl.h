@@ -116,6 +116,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_warp(Fields F, const uint8_t* tabl
     }
 }
 
+// ---------------------------------------------------------------- halo pack / unpack (banded Jacobi) ----
+__global__ __launch_bounds__(WO_BLOCK) void k_halo_pack(const float* e, const int32_t* idx, int32_t n, float* out) { WO_GRID_STRIDE(i, n) out[i] = e[idx[i]]; }
+__global__ __launch_bounds__(WO_BLOCK) void k_halo_unpack(float* e, const int32_t* idx, int32_t n, const float* in) { WO_GRID_STRIDE(i, n) e[idx[i]] = in[i]; }
+
 // ---------------------------------------------------------------- climate-util smoothField ------
 __global__ __launch_bounds__(WO_BLOCK) void k_smooth_field(Fields F, const float* src, float* dst) {
     WO_XCD_CELLS(r, F.N) dst[r] = smooth_field_cell(F, src, r);

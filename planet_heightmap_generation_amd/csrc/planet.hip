@@ -624,7 +624,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);
@@ -656,6 +656,66 @@ int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_is
     WO_HIP(hipStreamSynchronize(s));
     return 0;
     WO_CATCH("wo_planet_upload")
+}
+
+// ---- halo lists of a band-decomposed Jacobi pass (planet = one band + its one-ring halo, see banded.py) ----
+int wo_planet_set_halo(wo_planet* p, const int32_t* sendIdx, int32_t nSend, const int32_t* recvIdx, int32_t nRecv) {
+    if (!check_planet(p, "wo_planet_set_halo")) return 1;
+    if (nSend < 0 || nRecv < 0 || (nSend && !sendIdx) || (nRecv && !recvIdx)) { set_error("wo_planet_set_halo: bad arguments"); return 1; }
+    for (int32_t i = 0; i < nSend; ++i) if (sendIdx[i] < 0 || sendIdx[i] >= p->N) { set_error("wo_planet_set_halo: send index out of range"); return 1; }
+    for (int32_t i = 0; i < nRecv; ++i) if (recvIdx[i] < 0 || recvIdx[i] >= p->N) { set_error("wo_planet_set_halo: receive index out of range"); return 1; }
+    WO_TRY
+    hipStream_t s = p->ctx->stream;
+    dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf);
+    if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; }
+    p->nHaloSend = nSend; p->nHaloRecv = nRecv;
+    const size_t m = (size_t)std::max(nSend, nRecv);
+    p->d_haloSend = dalloc<int32_t>(nSend); p->d_haloRecv = dalloc<int32_t>(nRecv); p->d_haloBuf = dalloc<float>(m);
+    WO_HIP(hipHostMalloc((void**)&p->h_haloBuf, std::max<size_t>(m * sizeof(float), 64)));
+    if (nSend) WO_HIP(hipMemcpyAsync(p->d_haloSend, sendIdx, (size_t)nSend * 4, hipMemcpyHostToDevice, s));
+    if (nRecv) WO_HIP(hipMemcpyAsync(p->d_haloRecv, recvIdx, (size_t)nRecv * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipStreamSynchronize(s));
+    return 0;
+    WO_CATCH("wo_planet_set_halo")
+}
+int wo_planet_pack_halo(wo_planet* p, float* hostOut, void* deviceOut) {
+    if (!check_planet(p, "wo_planet_pack_halo")) return 1;
+    if ((hostOut == nullptr) == (deviceOut == nullptr)) { set_error("wo_planet_pack_halo: pass exactly one of hostOut / deviceOut"); return 1; }
+    WO_TRY
+    hipStream_t s = p->ctx->stream;
+    const int32_t n = p->nHaloSend;
+    if (n > 0) {
+        float* dst = deviceOut ? (float*)deviceOut : p->d_haloBuf;
+        launch(p, FAM_MISC, k_halo_pack, blocks_for(n), WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_haloSend, n, dst);
+        if (hostOut) {
+            WO_HIP(hipMemcpyAsync(p->h_haloBuf, p->d_haloBuf, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+            WO_HIP(hipStreamSynchronize(s));
+            std::memcpy(hostOut, p->h_haloBuf, (size_t)n * 4);
+            return 0;
+        }
+    }
+    WO_HIP(hipStreamSynchronize(s));           // deviceOut is handed to another stream (RCCL) next
+    return 0;
+    WO_CATCH("wo_planet_pack_halo")
+}
+int wo_planet_unpack_halo(wo_planet* p, const float* hostIn, const void* deviceIn) {
+    if (!check_planet(p, "wo_planet_unpack_halo")) return 1;
+    if ((hostIn == nullptr) == (deviceIn == nullptr)) { set_error("wo_planet_unpack_halo: pass exactly one of hostIn / deviceIn"); return 1; }
+    WO_TRY
+    hipStream_t s = p->ctx->stream;
+    const int32_t n = p->nHaloRecv;
+    if (n > 0) {
+        const float* src = (const float*)deviceIn;
+        if (hostIn) {
+            std::memcpy(p->h_haloBuf, hostIn, (size_t)n * 4);
+            WO_HIP(hipMemcpyAsync(p->d_haloBuf, p->h_haloBuf, (size_t)n * 4, hipMemcpyHostToDevice, s));
+            src = p->d_haloBuf;
+        }
+        launch(p, FAM_MISC, k_halo_unpack, blocks_for(n), WO_BLOCK, p->d_e, (const int32_t*)p->d_haloRecv, n, src);
+        WO_HIP(hipStreamSynchronize(s));       // the caller may reuse its buffer; the next pass reads d_e on this stream anyway
+    }
+    return 0;
+    WO_CATCH("wo_planet_unpack_halo")
 }
 
 int wo_planet_download(wo_planet* p, float* r_elevation) {

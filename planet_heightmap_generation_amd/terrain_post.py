@@ -124,6 +124,29 @@ class Planet:
         capi.check(capi.lib().wo_planet_download(self.handle, capi.ptr(out)), "wo_planet_download")
         return out
 
+    # ---- band-decomposed Jacobi passes (banded.py) ----
+    def set_halo(self, send_idx, recv_idx):
+        s = np.ascontiguousarray(send_idx, np.int32); r = np.ascontiguousarray(recv_idx, np.int32)
+        self._halo = (int(s.size), int(r.size))
+        capi.check(capi.lib().wo_planet_set_halo(self.handle, capi.ptr(s), s.size, capi.ptr(r), r.size), "wo_planet_set_halo")
+
+    def pack_halo(self, device_ptr: int | None = None) -> np.ndarray | None:
+        if device_ptr is not None:
+            capi.check(capi.lib().wo_planet_pack_halo(self.handle, None, device_ptr), "wo_planet_pack_halo")
+            return None
+        out = np.empty(self._halo[0], np.float32)
+        capi.check(capi.lib().wo_planet_pack_halo(self.handle, capi.ptr(out), None), "wo_planet_pack_halo")
+        return out
+
+    def unpack_halo(self, values: np.ndarray | None = None, device_ptr: int | None = None) -> None:
+        if device_ptr is not None:
+            capi.check(capi.lib().wo_planet_unpack_halo(self.handle, None, device_ptr), "wo_planet_unpack_halo")
+            return
+        v = np.ascontiguousarray(values, np.float32)
+        if v.size != self._halo[1]:
+            raise ValueError("halo value count mismatch")
+        capi.check(capi.lib().wo_planet_unpack_halo(self.handle, capi.ptr(v), None), "wo_planet_unpack_halo")
+
     def download_ocean(self) -> np.ndarray:
         out = np.empty(self.numRegions, np.uint8)
         capi.check(capi.lib().wo_planet_download_ocean(self.handle, capi.ptr(out)), "wo_planet_download_ocean")

@@ -37,6 +37,21 @@ def main():
         steps = {"smooth": lambda f, s: pl.smooth_elevation(f, oc, 1, s),
                  "creep": lambda f, s: pl.apply_soil_creep(f, oc, 1, s),
                  "field": lambda f, s: CU.smooth_field(part.mesh, f, 1, planet=pl)}
+    if engine == "resident":
+        # the field stays in HBM; only halo values travel (pack kernel -> gloo -> unpack kernel)
+        band = banded.ResidentBand(part, pl)
+        for name, iters, strength in (("smooth", 4, 0.3), ("creep", 3, 0.1125)):
+            pl.upload(plan.scatter(rank, z["elevation"]), oc)
+            step = (lambda: pl.smooth_elevation_resident(1, strength)) if name == "smooth" else (lambda: pl.apply_soil_creep_resident(1, strength))
+            band.jacobi(step, iters, dist)
+            g = banded.gather_owned(plan, rank, pl.download(), dist)
+            if rank == 0:
+                results[name] = g
+        if rank == 0:
+            np.savez(work / "result.npz", **results)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     for name, iters, strength in (("smooth", 4, 0.3), ("creep", 3, 0.1125), ("field", 5, 0.0)):
         f = plan.scatter(rank, z["elevation"]).copy()
         banded.banded_jacobi(part, f, iters, lambda fl: steps[name](fl, strength), dist)
