@@ -4,6 +4,10 @@ Only plumbing lives here: it loads the in-tree shared library, declares argument
 symbol the header exports and converts a non-zero status into ``WorogenError`` (the reference reports
 failures as JS exceptions, js/planet-worker.js:336-338).  There is no CPU fallback: if the library or a
 HIP device is missing the calls raise.
+
+Load order: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  A process that uses both torch's
+GPU side and this library must `import torch` first (bench.py does); the other way round torch finds the system runtime
+already mapped and reports "No HIP GPUs are available".  This library works with either runtime.
 """
 from __future__ import annotations
 
