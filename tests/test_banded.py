@@ -76,7 +76,7 @@ def test_banded_jacobi_equals_unpartitioned_gpu(tmp_path, oracle):
 @pytest.mark.gpu
 def test_halo_pack_unpack_host_and_device_buffers():
     """wo_planet_pack_halo / unpack_halo with pinned-host staging and with device buffers (torch tensors, as handed to RCCL)."""
-    import torch
+
     from planet_heightmap_generation_amd import sphere_mesh as S, terrain_post as TP
     mesh, xyz, nd = S.build_sphere(20000, 0.75, 1)
     N = mesh.numRegions
@@ -94,16 +94,28 @@ def test_halo_pack_unpack_host_and_device_buffers():
     assert np.array_equal(pl.download(), want)
     with pytest.raises(ValueError):
         pl.unpack_halo(vals[:10])
-    try:                                    # device buffers owned by torch (what RCCL sends / receives)
-        t = torch.empty(700, dtype=torch.float32, device="cuda:0")
-    except RuntimeError as ex:              # torch's own HIP runtime may refuse to initialise next to ours in one process
-        pl.close()
-        pytest.skip(f"torch could not initialise its HIP device in this process: {ex}")
-    pl.pack_halo(device_ptr=t.data_ptr())
-    assert np.array_equal(t.cpu().numpy(), want[send])
-    vals2 = torch.from_numpy(rng.normal(size=500).astype(np.float32)).to("cuda:0")
-    torch.cuda.synchronize()
-    pl.unpack_halo(device_ptr=vals2.data_ptr())
-    want[recv] = vals2.cpu().numpy()
-    assert np.array_equal(pl.download(), want)
     pl.close()
+    # device buffers owned by torch (what RCCL sends / receives): in a fresh interpreter that imports torch first
+    # (torch bundles its own HIP runtime; see capi.py on load order)
+    script = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from planet_heightmap_generation_amd import sphere_mesh as S, terrain_post as TP
+mesh, xyz, nd = S.build_sphere(20000, 0.75, 1)
+N = mesh.numRegions
+pl = TP.Planet(mesh, xyz, nd)
+rng = np.random.default_rng(0)
+e = rng.normal(size=N).astype(np.float32)
+send = rng.choice(N, 700, replace=False).astype(np.int32); recv = rng.choice(N, 500, replace=False).astype(np.int32)
+pl.upload(e, None); pl.set_halo(send, recv)
+t = torch.empty(700, dtype=torch.float32, device="cuda:0")
+pl.pack_halo(device_ptr=t.data_ptr())
+assert np.array_equal(t.cpu().numpy(), e[send])
+v = torch.from_numpy(rng.normal(size=500).astype(np.float32)).to("cuda:0"); torch.cuda.synchronize()
+pl.unpack_halo(device_ptr=v.data_ptr())
+e[recv] = v.cpu().numpy()
+assert np.array_equal(pl.download(), e)
+print("device buffers ok")
+"""
+    r = subprocess.run([sys.executable, "-c", script, str(REPO)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "device buffers ok" in r.stdout, r.stderr[-2000:]
