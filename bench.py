@@ -203,7 +203,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4, help="planets in flight for the supplementary ensemble figure (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=6, help="planets in flight for the supplementary ensemble figure (0 = skip)")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
