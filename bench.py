@@ -287,7 +287,10 @@ def main():
                         traffic=traffic, traffic_note=traffic_note, launches=launches, avg_launch_us=avg_launch_s * 1e6,
                         algorithmic_bytes_per_launch=bytes_per_pass / launches_per_pass,
                         note="the solve kernels (solve_patch / solve_round) walk the drainage DAG level by level: bound by dependency latency, not by HBM (DESIGN.md §5)",
-                        families=fams)
+                        families=fams,
+                        whole_stack=dict(note="SURVEY 8(d): (243 B x land cells + 12 B x cells) per composite iteration over the wall time of a step",
+                                         achieved_GBs=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9,
+                                         frac=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9 / HBM_PEAK_GBS))
     ensemble = None
     if rank == 0 and world == 1 and args.in_flight > 1:
         ensemble = ensemble_in_flight(TP, mesh, xyz, nd, seed, params, args.in_flight, local_rank)
