@@ -26,6 +26,8 @@ class EnsembleRunner:
 
     def map(self, fn: Callable, items: Iterable) -> List:
         items = list(items)
+        if not items:
+            return []
         results = [None] * len(items)
         todo: "queue.Queue[int]" = queue.Queue()
         for i in range(len(items)):

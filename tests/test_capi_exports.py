@@ -60,3 +60,10 @@ def test_host_entry_points_reject_bad_arguments():
     assert L.wo_project_coarse_plates(None, 4, capi.ptr(i32), capi.ptr(i32), capi.ptr(f32), capi.ptr(i32), 1.0, 8, capi.ptr(i32)) != 0
     assert L.wo_erode_composite_resident(None, 1, 3e-4, 0.5, 1.0, 1, 1.16, 0.015, 0, 0.0) != 0
     assert not L.wo_planet_create(None, 4, capi.ptr(i32), capi.ptr(i32), capi.ptr(f32), None)
+
+
+def test_ensemble_runner_argument_checks():
+    from planet_heightmap_generation_amd.ensemble import EnsembleRunner
+    with pytest.raises(ValueError):
+        EnsembleRunner(None, None, in_flight=0)
+    assert EnsembleRunner(None, None, in_flight=2).map(lambda pl, s: s, []) == []        # nothing to do: no device touched
