@@ -143,6 +143,15 @@ __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N
 
 // ---------------------------------------------------------------- hydraulic ---------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_XCD_CELLS(r, F.N) receiver_cell(F, r); }
+// receivers + the start state of the flow accumulation (k_flow_init) in one pass over the cells
+__global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F) {
+    WO_XCD_CELLS(r, F.N) {
+        receiver_cell(F, r);
+        int32_t j = -1; uint32_t a = 0;
+        if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
+        F.accA[r] = a; F.jumpA[r] = j;
+    }
+}
 
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_init(Fields F) {
     WO_XCD_CELLS(r, F.N) {
@@ -401,8 +410,15 @@ __global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const in
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level) {
-    WO_XCD_CELLS(r, F.N) { out[r] = solve_final_cell(F, r); if (!F.ocean[r]) level[r] = F.out[store_index(F, r)].self.tag; }
+// `masked` (may be null): the thermal step's masked elevation of the new field, written in the same pass
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level, float* masked) {
+    WO_XCD_CELLS(r, F.N) {
+        const float v = solve_final_cell(F, r);
+        out[r] = v;
+        const bool oc = F.ocean[r] != 0;
+        if (!oc) level[r] = F.out[store_index(F, r)].self.tag;
+        if (masked) masked[r] = oc ? INFINITY : v;
+    }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 

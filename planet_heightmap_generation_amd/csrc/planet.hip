@@ -418,10 +418,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (gNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             clk.begin("receivers");
-            launch(p, FAM_RECEIVERS, k_receivers, gridN, WO_BLOCK, F);
+            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridN, WO_BLOCK, F);        // + flow accumulation start state
             clk.end();
             clk.begin("flow");
-            launch(p, FAM_FLOW_INIT, k_flow_init, gridN, WO_BLOCK, F);
             flowRounds += run_rounds(p, p->d_landIdx, L, false, 4,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
@@ -439,7 +438,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
             }
-            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2, p->d_level);
+            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
             swap_elev(p);
             clk.end();
         }
@@ -447,7 +446,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         if (iter < tIters) {
             clk.begin("thermal");
             Fields F = p->fields();
-            launch(p, FAM_THERMAL_EXCESS, k_masked_elev, gridN, WO_BLOCK, F);
+            if (!hNow) launch(p, FAM_THERMAL_EXCESS, k_masked_elev, gridN, WO_BLOCK, F);      // else written by k_solve_final
             launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridN, WO_BLOCK, F, talus);
             if (p->maxDeg <= 12)
                 launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<12>, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
