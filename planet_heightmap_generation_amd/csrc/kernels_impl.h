@@ -144,12 +144,72 @@ __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N
 // ---------------------------------------------------------------- hydraulic ---------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_XCD_CELLS(r, F.N) receiver_cell(F, r); }
 // receivers + the start state of the flow accumulation (k_flow_init) in one pass over the cells
-__global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F) {
+__global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int32_t* donorCnt) {
     WO_XCD_CELLS(r, F.N) {
         receiver_cell(F, r);
         int32_t j = -1; uint32_t a = 0;
         if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
         F.accA[r] = a; F.jumpA[r] = j;
+        if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
+    }
+}
+// Flow accumulation, part 1: rake.  Subtree sizes are integers, so any order of the additions is exact.  Most land
+// cells sit on short hillslope branches: a few rounds of "cells whose donors are all in hand their total to their
+// receiver and retire" remove them, and the pointer doubling (part 2) only runs on the river skeleton that is left.
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_rake(Fields F, int32_t* donorCnt, const int32_t* in, const int32_t* inCount, int32_t* out, int32_t* outCount,
+                                                         int32_t* zeroCount, int32_t firstN) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    // first round (inCount == nullptr): `in` is the whole land list and the leaves (no donors, a receiver) pick themselves
+    const int32_t n = inCount ? *inCount : firstN;
+    WO_BLOCK_STRIDE(i, valid, n) {
+        bool ready = false; int32_t j = -1;
+        bool take = valid;
+        int32_t d = -1;
+        // donorCnt: low 16 bits = forward donors (fixed once the receivers pass is over), high bits = donors retired so far;
+        // the leaf test reads only the low half, which no round changes (a plain countdown could reach 0 mid-round and
+        // make a receiver pass for a leaf)
+        if (valid) { d = in[i]; if (!inCount) take = (donorCnt[d] & 0xffff) == 0 && F.jumpA[d] >= 0; }
+        if (take) {
+            j = F.jumpA[d];
+            atomicAdd(&F.accA[j], F.accA[d]);               // d's total is final: all its donors retired in earlier rounds
+            F.jumpA[d] = -2;                                // retired
+            const int32_t old = atomicAdd(&donorCnt[j], 0x10000);
+            ready = ((old >> 16) + 1 == (old & 0xffff)) && F.jumpA[j] >= 0;      // last donor in: j can go next (roots just keep the sum)
+        }
+        block_append(ready, j, out, outCount);
+    }
+}
+// up to four values per thread, one global atomic per workgroup: the list counter is a single address, and at ~10 ns per
+// atomic a 10^4-block append is atomic-bound (it was 130 us for 2.8 M entries with one value per thread)
+__device__ inline void block_append4(int cnt, const int32_t (&vals)[4], int32_t* out, int32_t* outCount) {
+    __shared__ int32_t s_w4[WO_BLOCK / 64];
+    __shared__ int32_t s_b4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) s_w4[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t tot = 0;
+        for (int w = 0; w < WO_BLOCK / 64; ++w) { const int32_t c = s_w4[w]; s_w4[w] = tot; tot += c; }
+        s_b4 = tot ? atomicAdd(outCount, tot) : 0;
+    }
+    __syncthreads();
+    int32_t at = s_b4 + s_w4[wave] + incl - cnt;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (q < cnt) out[at++] = vals[q];
+    __syncthreads();
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount) {
+    const int32_t groups = (L + 3) / 4;
+    WO_BLOCK_STRIDE(g, valid, groups) {
+        int32_t vals[4]; int cnt = 0;
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int32_t i = 4 * g + q; if (i < L) { const int32_t r = land[i]; if (F.jumpA[r] >= 0) vals[cnt++] = r; } }
+        }
+        block_append4(cnt, vals, out, outCount);
     }
 }
 
@@ -190,8 +250,9 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t
         block_append(again, d, out, outCount);
     }
 }
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F) {
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt) {
     WO_XCD_CELLS(c, F.N) {
+        donorCnt[c] = 0;                                    // for the next iteration's receivers pass
         float fl = 0.0f;
         if (!F.ocean[c]) {
             uint32_t f = F.accA[c];

@@ -44,13 +44,15 @@ void profile_resolve(wo_planet* p) {
 template <class T> static T* dalloc(size_t n) { void* q = nullptr; WO_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); return (T*)q; }
 template <class T> static void dfree(T*& q) { if (q) { (void)hipFree(q); q = nullptr; } }
 
+constexpr int WO_FLOW_RAKE_ROUNDS = 8;             // rake rounds before the pointer doubling of the flow accumulation
+
 static void ensure_scratch(wo_planet* p) {
     if (p->scratch) return;
     const size_t N = (size_t)p->N;
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
-    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_tr = dalloc<TargetRank>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
@@ -301,6 +303,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     if (total <= 0) return;
     ensure_scratch(p);
     hipStream_t s = p->ctx->stream;
+    if (hIters > 0) WO_HIP(hipMemsetAsync(p->d_flowCnt, 0, (size_t)p->N * sizeof(int32_t), s));   // k_flow_final keeps it zero between iterations; a call that was cut short may not have
     const int32_t N = p->N;
     const int gridN = xcd_grid(N);
     StageClock clk(p);
@@ -418,16 +421,30 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (gNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             clk.begin("receivers");
-            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridN, WO_BLOCK, F);        // + flow accumulation start state
+            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridN, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();
             clk.begin("flow");
-            flowRounds += run_rounds(p, p->d_landIdx, L, false, 4,
+            {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
+                int32_t* c = p->d_counters;
+                hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
+                const int32_t* in = p->d_landIdx;
+                for (int k = 1; k <= WO_FLOW_RAKE_ROUNDS; ++k) {
+                    int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
+                    launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for(L / (k < 3 ? 1 : 4), 2048), WO_BLOCK, F, p->d_flowCnt, in,
+                           k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
+                    in = out;
+                }
+                WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
+                launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3);
+            }
+            // pointer doubling on what is left (the cells queued for the next rake round included)
+            flowRounds += run_rounds(p, p->d_listB, 0, true, 4,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
                     launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
                            (const int32_t*)p->d_nj, out, outC, zeroC);
                 });
-            launch(p, FAM_FLOW_FINAL, k_flow_final, gridN, WO_BLOCK, F);
+            launch(p, FAM_FLOW_FINAL, k_flow_final, gridN, WO_BLOCK, F, p->d_flowCnt);
             clk.end();
             clk.begin("solve");
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridN, WO_BLOCK, F);
@@ -623,7 +640,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);
