@@ -156,29 +156,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
 // Flow accumulation, part 1: rake.  Subtree sizes are integers, so any order of the additions is exact.  Most land
 // cells sit on short hillslope branches: a few rounds of "cells whose donors are all in hand their total to their
 // receiver and retire" remove them, and the pointer doubling (part 2) only runs on the river skeleton that is left.
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_rake(Fields F, int32_t* donorCnt, const int32_t* in, const int32_t* inCount, int32_t* out, int32_t* outCount,
-                                                         int32_t* zeroCount, int32_t firstN) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    // first round (inCount == nullptr): `in` is the whole land list and the leaves (no donors, a receiver) pick themselves
-    const int32_t n = inCount ? *inCount : firstN;
-    WO_BLOCK_STRIDE(i, valid, n) {
-        bool ready = false; int32_t j = -1;
-        bool take = valid;
-        int32_t d = -1;
-        // donorCnt: low 16 bits = forward donors (fixed once the receivers pass is over), high bits = donors retired so far;
-        // the leaf test reads only the low half, which no round changes (a plain countdown could reach 0 mid-round and
-        // make a receiver pass for a leaf)
-        if (valid) { d = in[i]; if (!inCount) take = (donorCnt[d] & 0xffff) == 0 && F.jumpA[d] >= 0; }
-        if (take) {
-            j = F.jumpA[d];
-            atomicAdd(&F.accA[j], F.accA[d]);               // d's total is final: all its donors retired in earlier rounds
-            F.jumpA[d] = -2;                                // retired
-            const int32_t old = atomicAdd(&donorCnt[j], 0x10000);
-            ready = ((old >> 16) + 1 == (old & 0xffff)) && F.jumpA[j] >= 0;      // last donor in: j can go next (roots just keep the sum)
-        }
-        block_append(ready, j, out, outCount);
-    }
-}
 // up to four values per thread, one global atomic per workgroup: the list counter is a single address, and at ~10 ns per
 // atomic a 10^4-block append is atomic-bound (it was 130 us for 2.8 M entries with one value per thread)
 __device__ inline void block_append4(int cnt, const int32_t (&vals)[4], int32_t* out, int32_t* outCount) {
@@ -200,6 +177,34 @@ __device__ inline void block_append4(int cnt, const int32_t (&vals)[4], int32_t*
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (q < cnt) out[at++] = vals[q];
     __syncthreads();
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_rake(Fields F, int32_t* donorCnt, const int32_t* in, const int32_t* inCount, int32_t* out, int32_t* outCount,
+                                                         int32_t* zeroCount, int32_t firstN) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
+    // first round (inCount == nullptr): `in` is the whole land list and the leaves (no donors, a receiver) pick themselves
+    const int32_t n = inCount ? *inCount : firstN;
+    const int32_t groups = (n + 3) / 4;
+    WO_BLOCK_STRIDE(g, valid, groups) {
+        int32_t vals[4]; int cnt = 0;
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int32_t i = 4 * g + q;
+                if (i >= n) continue;
+                const int32_t d = in[i];
+                // donorCnt: low 16 bits = forward donors (fixed once the receivers pass is over), high bits = donors retired so
+                // far; the leaf test reads only the low half, which no round changes (a plain countdown could reach 0
+                // mid-round and make a receiver pass for a leaf)
+                if (!inCount && !((donorCnt[d] & 0xffff) == 0 && F.jumpA[d] >= 0)) continue;
+                const int32_t j = F.jumpA[d];
+                atomicAdd(&F.accA[j], F.accA[d]);           // d's total is final: all its donors retired in earlier rounds
+                F.jumpA[d] = -2;                            // retired
+                const int32_t old = atomicAdd(&donorCnt[j], 0x10000);
+                if (((old >> 16) + 1 == (old & 0xffff)) && F.jumpA[j] >= 0) vals[cnt++] = j;    // last donor in: j goes next (roots just keep the sum)
+            }
+        }
+        block_append4(cnt, vals, out, outCount);
+    }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount) {
     const int32_t groups = (L + 3) / 4;

@@ -430,7 +430,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int32_t* in = p->d_landIdx;
                 for (int k = 1; k <= WO_FLOW_RAKE_ROUNDS; ++k) {
                     int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
-                    launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for(L / (k < 3 ? 1 : 4), 2048), WO_BLOCK, F, p->d_flowCnt, in,
+                    launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
                            k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
                     in = out;
                 }
