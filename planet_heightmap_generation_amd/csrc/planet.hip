@@ -44,6 +44,7 @@ void profile_resolve(wo_planet* p) {
 template <class T> static T* dalloc(size_t n) { void* q = nullptr; WO_HIP(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T))); return (T*)q; }
 template <class T> static void dfree(T*& q) { if (q) { (void)hipFree(q); q = nullptr; } }
 
+constexpr int WO_PATCH_TOTAL_SLOTS = 4096;         // pending-total slots of the patch solve (one per launch, reused modulo)
 constexpr int WO_FLOW_RAKE_ROUNDS = 8;             // rake rounds before the pointer doubling of the flow accumulation
 
 static void ensure_scratch(wo_planet* p) {
@@ -59,7 +60,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
     p->d_iceUp = dalloc<uint8_t>(N);
     p->d_listA = dalloc<int32_t>(N); p->d_listB = dalloc<int32_t>(N); p->d_counters = dalloc<int32_t>(8);
-    p->d_patchOrder = dalloc<int32_t>(N); p->d_slotOf = dalloc<int32_t>(N); p->d_patchPending = dalloc<int32_t>(N / WO_PATCH + 2); p->d_patchBlk = dalloc<int32_t>(N);
+    p->d_patchOrder = dalloc<int32_t>(N); p->d_slotOf = dalloc<int32_t>(N); p->d_patchPending = dalloc<int32_t>(N / WO_PATCH + 2); p->d_patchTotals = dalloc<int32_t>(WO_PATCH_TOTAL_SLOTS); p->d_patchBlk = dalloc<int32_t>(N);
     p->d_level = dalloc<int32_t>(N); p->d_byLevel = dalloc<int32_t>(N); p->d_levelStart = dalloc<int32_t>(WO_MAX_LEVEL + 2);
     WO_HIP(hipHostMalloc((void**)&p->h_levelStart, (WO_MAX_LEVEL + 2) * sizeof(int32_t)));
     p->sortTempBytes = sort_temp_bytes(p->N);
@@ -226,20 +227,22 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
 // Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
 static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt) {
     hipStream_t s = p->ctx->stream;
-    int32_t* c = p->d_counters;
     const int np = p->numPatches;
     launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, 1, (int32_t)np);
+    // one pending-total slot per launch, cleared once per pass (a memset per launch was 13.6 k fill kernels per step)
+    int32_t* tot = p->d_patchTotals;
+    WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
     int64_t launches = 0;
     for (int32_t tag = 1;; ) {
         // The pending total is read back (one stream sync) after every burst.  The launch count barely changes from one
         // erosion iteration to the next, so the first burst is sized by the previous count; then small bursts to finish.
         const int burst = (tag == 1) ? std::max<int>(1, (int)p->lastPatchLaunches - 1) : 3;
         for (int b = 0; b < burst; ++b, ++tag) {
-            WO_HIP(hipMemsetAsync(c + 6, 0, sizeof(int32_t), s));
-            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, c + 6, K, m, dt);
+            if (tag % WO_PATCH_TOTAL_SLOTS == 0) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: slots are free again (stream order)
+            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt);
             ++launches;
         }
-        if (read_count(p, c + 6) == 0) break;
+        if (read_count(p, tot + ((tag - 1) % WO_PATCH_TOTAL_SLOTS)) == 0) break;
         if (launches > 4 * (int64_t)p->N + 1024) throw HipError{"patch solve does not converge"};
     }
     p->lastPatchLaunches = launches;
@@ -643,7 +646,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
-    dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchBlk);
+    dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);
     dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
     if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);
     if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);
