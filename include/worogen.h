@@ -64,6 +64,11 @@ int wo_triangle_elevations(int32_t numTriangles, const int32_t* triangles, const
 /* ------------------------------------------------ SimplexNoise (js/simplex-noise.js:5-54) ----- */
 /* constructor: perm[512] and permMod12[512] for makeRng(seed) (js/simplex-noise.js:8-14) */
 int wo_noise_tables(double seed, uint8_t* perm512, uint8_t* pm12_512);
+/* one point on the host, for callers that evaluate the noise a point at a time (js/wind.js:394, js/coarse-plates.js:57):
+ * perm512 / pm12_512 are the instance's tables; kind / octaves / p0..p2 as for wo_noise_eval.  Same arithmetic as the
+ * device passes (csrc/noise.h). */
+int wo_noise_point(const uint8_t* perm512, const uint8_t* pm12_512, int32_t kind, int32_t octaves, double p0, double p1, double p2,
+                   double x, double y, double z, double* out);
 /* batch evaluation on the device.  kind: 0 noise3D, 1 fbm(octaves, persistence),
  * 2 ridgedFbm(octaves, lacunarity=p0, gain=p1, offset=p2).  xyz: n interleaved double triples. */
 #define WO_NOISE_3D 0

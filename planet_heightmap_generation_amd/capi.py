@@ -38,6 +38,7 @@ SIGNATURES = {
     "wo_neighbor_dist": (C.c_int, [_c_i32, _p, _p, _p, _p]),
     "wo_triangle_elevations": (C.c_int, [_c_i32, _p, _p, _p]),
     "wo_noise_tables": (C.c_int, [_c_f64, _p, _p]),
+    "wo_noise_point": (C.c_int, [_p, _p, _c_i32, _c_i32, _c_f64, _c_f64, _c_f64, _c_f64, _c_f64, _c_f64, _p]),
     "wo_noise_eval": (C.c_int, [_p, _c_f64, _c_i32, _c_i32, _c_f64, _c_f64, _c_f64, _c_i64, _p, _p]),
     "wo_ctx_create": (_p, [_c_i32]),
     "wo_ctx_destroy": (None, [_p]),

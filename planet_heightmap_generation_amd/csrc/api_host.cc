@@ -68,6 +68,15 @@ int wo_noise_tables(double seed, uint8_t* perm512, uint8_t* pm12_512) {
     return 0;
 }
 
+int wo_noise_point(const uint8_t* perm512, const uint8_t* pm12_512, int32_t kind, int32_t octaves, double p0, double p1, double p2,
+                   double x, double y, double z, double* out) {
+    if (!perm512 || !pm12_512 || !out || kind < 0 || kind > 2) { wo::set_error("wo_noise_point: bad arguments"); return 1; }
+    *out = kind == 0 ? wo::noise3d(perm512, pm12_512, x, y, z)
+         : kind == 1 ? wo::fbm(perm512, pm12_512, x, y, z, octaves, p0)
+                     : wo::ridged_fbm(perm512, pm12_512, x, y, z, octaves, p0, p1, p2);
+    return 0;
+}
+
 int wo_smooth_reconnect_plates(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, int32_t* r_plate,
                                const int32_t* plateSeeds, int32_t numPlateSeeds, int32_t numPasses) {
     if (numRegions < 1 || !adjOffset || !adjList || !r_plate || numPlateSeeds < 0 || (numPlateSeeds > 0 && !plateSeeds)) {

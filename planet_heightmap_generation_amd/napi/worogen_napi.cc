@@ -255,6 +255,17 @@ napi_value LastStageTiming(napi_env env, napi_callback_info info) {
     return arr;
 }
 
+// noisePoint(perm, pm12, kind, octaves, p0, p1, p2, x, y, z) -> number (host)
+napi_value NoisePoint(napi_env env, napi_callback_info info) {
+    Args a(env, info);
+    size_t np_, nm;
+    uint8_t* P = (uint8_t*)a.ta(0, napi_uint8_array, &np_); if (!a.ok) return nullptr;
+    uint8_t* M = (uint8_t*)a.ta(1, napi_uint8_array, &nm); if (!a.ok) return nullptr;
+    if (np_ != 512 || nm != 512) { napi_throw_range_error(env, nullptr, "noise tables must have 512 entries"); return nullptr; }
+    double out = 0;
+    if (wo_noise_point(P, M, a.i32(2), a.i32(3), a.num(4), a.num(5), a.num(6), a.num(7), a.num(8), a.num(9), &out)) return throw_wo(env, "noisePoint");
+    napi_value v; napi_create_double(env, out, &v); return v;
+}
 napi_value NoiseEval(napi_env env, napi_callback_info info) {                  // (ctx, seed, kind, octaves, p0, p1, p2, xyz Float64Array) -> Float64Array
     Args a(env, info); wo_ctx* c = (wo_ctx*)a.ext(0);
     size_t n; double* xyz = (double*)a.ta(7, napi_float64_array, &n); if (!a.ok) return nullptr;
@@ -355,7 +366,7 @@ napi_value SmoothAndReconnectPlates(napi_env env, napi_callback_info info) {
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"fibSpherePoints", FibSpherePoints}, {"sphereDelaunay", SphereDelaunay}, {"meshCsr", MeshCsr}, {"neighborDist", NeighborDist},
-        {"triangleElevations", TriangleElevations}, {"noiseTables", NoiseTables}, {"noiseEval", NoiseEval},
+        {"triangleElevations", TriangleElevations}, {"noiseTables", NoiseTables}, {"noiseEval", NoiseEval}, {"noisePoint", NoisePoint},
         {"deviceCount", DeviceCount}, {"ctxCreate", CtxCreate}, {"planetCreate", PlanetCreate},
         {"warpTerrain", WarpTerrain}, {"smoothElevation", SmoothElevation}, {"erodeComposite", ErodeComposite},
         {"sharpenRidges", SharpenRidges}, {"applySoilCreep", ApplySoilCreep},
