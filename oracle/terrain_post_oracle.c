@@ -78,7 +78,12 @@ static void heap_push(heap_t* h, int32_t cell) {
     while (i > 0) {
         int32_t parent = (i - 1) >> 1;
         int32_t t;
+#ifdef WO_ORACLE_TIE_VARIANT    /* research only: a different (equally arbitrary) order among EQUAL keys, to measure how much the
+                                    result depends on the reference heap's tie mechanics */
+        if (h->key[h->data[i]] > h->key[h->data[parent]]) break;
+#else
         if (h->key[h->data[i]] >= h->key[h->data[parent]]) break;
+#endif
         t = h->data[i]; h->data[i] = h->data[parent]; h->data[parent] = t;
         i = parent;
     }
