@@ -12,6 +12,7 @@
 #include "host_util.h"
 
 #include "erode_ops.h"
+#include "flood_ops.h"
 #include "wo_internal.h"
 
 namespace wo {
@@ -54,7 +55,8 @@ enum Family : int {
     FAM_SORT_KEYS, FAM_SORT_RADIX, FAM_RANK, FAM_RECEIVERS, FAM_FLOW_INIT, FAM_FLOW_SNAP, FAM_FLOW_APPLY, FAM_FLOW_FINAL,
     FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
     FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
-    FAM_LEVEL_SORT, FAM_SOLVE_TAIL, FAM_SOLVE_PATCH, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_PLATE_GRID, FAM_PLATE_PROJECT, FAM_SMOOTH_FIELD, FAM_MISC, FAM_COUNT
+    FAM_LEVEL_SORT, FAM_SOLVE_TAIL, FAM_SOLVE_PATCH, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_PLATE_GRID, FAM_PLATE_PROJECT, FAM_SMOOTH_FIELD,
+    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_MISC, FAM_COUNT
 };
 extern const char* const kFamilyNames[FAM_COUNT];
 
@@ -64,6 +66,20 @@ struct wo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
+};
+
+// device state of the flood's pass 1 (flood_kernels.h); static part per land mask, the rest per call
+struct wo_flood_gpu {
+    int64_t version = -1; int32_t L = 0, cap = 0, nSeeds = 0;
+    int32_t *off = nullptr, *adj = nullptr, *cell = nullptr, *seedIdx = nullptr, *seeds = nullptr; double* nz = nullptr;
+    float* e = nullptr;
+    wo::FlHead *A = nullptr, *P = nullptr, *F = nullptr;
+    unsigned long long *Astk = nullptr, *Pstk = nullptr, *Fstk = nullptr;
+    int32_t *fdEpoch = nullptr, *inDirty = nullptr; uint8_t* isPending = nullptr;
+    int32_t* lists[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // dirty x2, pending x2, changed
+    void* ctrl = nullptr; void* h_ctrl = nullptr;
+    int32_t *jump = nullptr, *outPar = nullptr, *outRoot = nullptr; float* outSurf = nullptr;
+    int32_t *h_par = nullptr, *h_root = nullptr; float* h_surf = nullptr;   // pinned
 };
 
 struct wo_planet {
@@ -77,6 +93,7 @@ struct wo_planet {
     float* h_pinned = nullptr;          // N floats, pinned
     int32_t* h_count = nullptr;         // pinned scalar(s) for round-count read-back
     wo::FloodScratch flood;
+    wo_flood_gpu fgpu;
 
     // resident mesh
     int32_t *d_off = nullptr, *d_adj = nullptr;

@@ -250,31 +250,44 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     ++S.staticVersion;
 }
 
-void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
-                               const uint8_t* ocean, double carveStrength, FloodScratch& S) {
-    const double EPS = 1e-7;
-    const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
-    auto tp = std::chrono::steady_clock::now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
+// cellNoise of every land cell, in the compact (Morton) land order — uploaded once per land mask for the device flood
+void flood_cell_noise(const FloodScratch& S, double* out) {
+    parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) out[i] = cell_noise(S.landCell[i]); });
+}
+
+namespace {
+struct FloodTimer {
+    bool on = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point tp = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
         auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[flood] %-10s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
         tp = now;
-    };
-    if (!S.staticValid || S.staticN != N) flood_build_static(N, off, adj, xyz, ocean, S);
-    lap("static");
+    }
+};
+}  // namespace
+
+// land elevations into the compact arrays + the start state of pass 1 (:107-113)
+void flood_gather(const float* e, FloodScratch& S) {
     const int32_t L = S.L;
-    if (L == 0) return;
+    const int32_t* landCell = S.landCell.data();
+    float* eL = S.eL.data();
+    FloodCell* st = S.state.data();
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
+    });
+}
+
+// pass 1 (:118-147): the serial heap walk — the reference's order including its heap's tie mechanics
+void flood_pass1_host(FloodScratch& S) {
+    const double EPS = 1e-7;
+    FloodTimer T;
     const int32_t* landCell = S.landCell.data();
     const int32_t* offL = S.offL.data();
     const int32_t* adjL = S.adjL.data();
     float* eL = S.eL.data();
     FloodCell* st = S.state.data();
-
-    // --- surface / drainTo / visited (:107-113); keys are formed when a cell is pushed
-    parallel_ranges(L, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
-    });
     if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
     KeyHeap heap(S.heapStore);
     for (size_t s = 0; s < S.seedCell.size(); ++s) {        // :118-128, ascending r
@@ -283,7 +296,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         st[i].root = (int32_t)s;
         heap.push(i, (float)((double)eL[i] + cell_noise(landCell[i])));
     }
-    lap("init+seeds");
+    T.lap("init+seeds");
     // --- pass 1 (:131-147)
     while (heap.n > 0) {
         const int32_t c = heap.pop();
@@ -319,7 +332,32 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
             heap.push(nb, k);
         }
     }
-    lap("pass1");
+    T.lap("pass1");
+}
+
+// results of the device pass 1 (flood_kernels.h) into the host state of passes 2 and 3: parent in land-index space
+// (FL_NONE = -1 unreached, FL_SEED = -2 drains to the open ocean), surface, tree id (position of the tree's seed)
+void flood_import_pass1(const int32_t* par, const float* surface, const int32_t* root, FloodScratch& S) {
+    FloodCell* st = S.state.data();
+    parallel_ranges(S.L, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; ++i) {
+            const int32_t p = par[i];
+            st[i].drain = (p == -2) ? TO_OCEAN : (p == -1 ? UNVISITED : p);
+            st[i].surface = surface[i];
+            st[i].root = (p == -1) ? -1 : root[i];
+        }
+    });
+}
+
+// passes 2 and 3 (:152-214) on the state pass 1 left, then the land elevations back into e
+void flood_pass23_host(float* e, double carveStrength, FloodScratch& S) {
+    const double EPS = 1e-7;
+    FloodTimer T;
+    const bool timing = T.on;
+    const int32_t L = S.L;
+    const int32_t* landCell = S.landCell.data();
+    float* eL = S.eL.data();
+    FloodCell* st = S.state.data();
     // passes 2 and 3 stream over surface / tree id: give them compact arrays again
     float* surface = S.surface.data();
     int32_t* root = S.root.data();
@@ -388,7 +426,7 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         for (int i = 0; i < nt; ++i) th.emplace_back(worker);
         for (auto& t : th) t.join();
     };
-    lap("group2");
+    T.lap("group2");
     std::atomic<int64_t> nDef{0}, totLen{0};
     for_trees(cnt2, [&](int32_t tree) {
         std::vector<int32_t> path;
@@ -456,9 +494,18 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
         }
     });
     if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
-    lap("pass2+3");
+    T.lap("pass2+3");
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
-    lap("writeback");
+    T.lap("writeback");
+}
+
+void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
+                               const uint8_t* ocean, double carveStrength, FloodScratch& S) {
+    if (!S.staticValid || S.staticN != N) flood_build_static(N, off, adj, xyz, ocean, S);
+    if (S.L == 0) return;
+    flood_gather(e, S);
+    flood_pass1_host(S);
+    flood_pass23_host(e, carveStrength, S);
 }
 
 }  // namespace wo

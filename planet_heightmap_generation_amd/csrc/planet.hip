@@ -16,6 +16,7 @@
 #include "elevation_host.h"
 #include "elevation_kernels.h"
 #include "kernels_impl.h"
+#include "flood_kernels.h"
 #include "noise.h"
 
 namespace wo {
@@ -24,7 +25,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -268,8 +269,124 @@ struct StageClock {
     }
 };
 
-// priorityFloodCarve: host stage (flood_host.cc) — one D2H + H2D round trip of the elevation field
-static void flood_stage(wo_planet* p, double carveStrength) {
+// ---------------------------------------------------------------------------------------------------
+// priorityFloodCarve (js/terrain-post.js:59-215).  Pass 1 (the noise-keyed best-first flood) runs on the device as a
+// label-correcting fixed point (flood_ops.h / flood_kernels.h); passes 2 and 3 (sequential carve along the drain
+// paths, ordered fix-up) run per drainage tree on host threads (flood_host.cc) from the downloaded drainTo / surface.
+// WO_FLOOD=host keeps pass 1 on the host too (the reference's heap walk itself).  The device result is the
+// reference's whenever no decision hinged on two EQUAL keys (the heap orders those by its array mechanics); the
+// decisions that did are counted and, unless WO_FLOOD_TIES=id accepts the cell-id order, pass 1 is redone on the host.
+// ---------------------------------------------------------------------------------------------------
+struct FloodRun { double deviceMs = 0; int64_t rounds = 0, epochs = 0, evals = 0, ties = 0; bool usedDevice = false, fellBack = false; };
+
+static void flood_gpu_free(wo_flood_gpu& G) {
+    dfree(G.off); dfree(G.adj); dfree(G.cell); dfree(G.seedIdx); dfree(G.seeds); dfree(G.nz); dfree(G.e);
+    dfree(G.A); dfree(G.P); dfree(G.F); dfree(G.Astk); dfree(G.Pstk); dfree(G.Fstk); dfree(G.fdEpoch); dfree(G.inDirty); dfree(G.isPending);
+    for (auto& l : G.lists) dfree(l);
+    if (G.ctrl) { (void)hipFree(G.ctrl); G.ctrl = nullptr; }
+    if (G.h_ctrl) { (void)hipHostFree(G.h_ctrl); G.h_ctrl = nullptr; }
+    dfree(G.jump); dfree(G.outPar); dfree(G.outRoot); dfree(G.outSurf);
+    if (G.h_par) { (void)hipHostFree(G.h_par); G.h_par = nullptr; }
+    if (G.h_root) { (void)hipHostFree(G.h_root); G.h_root = nullptr; }
+    if (G.h_surf) { (void)hipHostFree(G.h_surf); G.h_surf = nullptr; }
+    G.version = -1; G.cap = 0; G.L = 0;
+}
+
+static void flood_gpu_upload_static(wo_planet* p) {
+    wo_flood_gpu& G = p->fgpu;
+    const FloodScratch& S = p->flood;
+    hipStream_t s = p->ctx->stream;
+    const int32_t L = S.L;
+    if (L > G.cap) {
+        flood_gpu_free(G);
+        G.cap = L + L / 16 + 1024;
+        const size_t C = (size_t)G.cap;
+        G.off = dalloc<int32_t>(C + 1); G.cell = dalloc<int32_t>(C); G.seedIdx = dalloc<int32_t>(C); G.seeds = dalloc<int32_t>(C); G.nz = dalloc<double>(C);
+        G.e = dalloc<float>(C);
+        G.A = dalloc<FlHead>(C); G.P = dalloc<FlHead>(C); G.F = dalloc<FlHead>(C);
+        G.Astk = dalloc<unsigned long long>(C * FL_LD); G.Pstk = dalloc<unsigned long long>(C * FL_LD); G.Fstk = dalloc<unsigned long long>(C * FL_LD);
+        G.fdEpoch = dalloc<int32_t>(C); G.inDirty = dalloc<int32_t>(C); G.isPending = dalloc<uint8_t>(C);
+        for (auto& l : G.lists) l = dalloc<int32_t>(C);
+        WO_HIP(hipMalloc(&G.ctrl, sizeof(FlCtrl)));
+        WO_HIP(hipHostMalloc(&G.h_ctrl, sizeof(FlCtrl)));
+        G.jump = dalloc<int32_t>(C); G.outPar = dalloc<int32_t>(C); G.outRoot = dalloc<int32_t>(C); G.outSurf = dalloc<float>(C);
+        WO_HIP(hipHostMalloc((void**)&G.h_par, C * 4)); WO_HIP(hipHostMalloc((void**)&G.h_root, C * 4)); WO_HIP(hipHostMalloc((void**)&G.h_surf, C * 4));
+    }
+    dfree(G.adj);
+    G.adj = dalloc<int32_t>(S.adjL.size());
+    std::vector<double> nz((size_t)L);
+    flood_cell_noise(S, nz.data());
+    std::vector<int32_t> seedIdx((size_t)L, -1);
+    for (size_t k = 0; k < S.seedCell.size(); ++k) seedIdx[S.seedCell[k]] = (int32_t)k;
+    WO_HIP(hipMemcpyAsync(G.off, S.offL.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(G.adj, S.adjL.data(), S.adjL.size() * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(G.cell, S.landCell.data(), (size_t)L * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(G.seedIdx, seedIdx.data(), (size_t)L * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(G.seeds, S.seedCell.data(), S.seedCell.size() * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(G.nz, nz.data(), (size_t)L * 8, hipMemcpyHostToDevice, s));
+    WO_HIP(hipStreamSynchronize(s));          // the staging vectors go out of scope
+    G.L = L; G.nSeeds = (int32_t)S.seedCell.size(); G.version = S.staticVersion;
+}
+
+// Returns true when the device result (h_par / h_surf / h_root, land-index space) is valid and may be imported.
+static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
+    wo_flood_gpu& G = p->fgpu;
+    hipStream_t s = p->ctx->stream;
+    if (G.version != p->flood.staticVersion) flood_gpu_upload_static(p);
+    const int32_t L = G.L;
+    if (L == 0) return false;
+    FloodDev D{};
+    D.L = L; D.off = G.off; D.adj = G.adj; D.cell = G.cell; D.nz = G.nz; D.seedIdx = G.seedIdx; D.e = G.e;
+    D.A = G.A; D.Astk = G.Astk; D.P = G.P; D.Pstk = G.Pstk; D.F = G.F; D.Fstk = G.Fstk; D.fdEpoch = G.fdEpoch; D.inDirty = G.inDirty; D.isPending = G.isPending;
+    FlLists Ls{{G.lists[0], G.lists[1]}, {G.lists[2], G.lists[3]}, G.lists[4]};
+    FlCtrl* C = (FlCtrl*)G.ctrl; FlCtrl* hC = (FlCtrl*)G.h_ctrl;
+    hipEvent_t e0 = profile_event(p), e1 = profile_event(p);
+    WO_HIP(hipEventRecord(e0, s));
+    launch(p, FAM_FLOOD_MISC, k_fl_init, blocks_for(L, 4096), WO_BLOCK, D, G.e, (const float*)p->d_e, C);
+    launch(p, FAM_FLOOD_MISC, k_fl_seed_dirty, blocks_for(G.nSeeds, 1024), WO_BLOCK, D, (const int32_t*)G.seeds, G.nSeeds, Ls, C);
+    const int grid = blocks_for(L / 4 + 1, 1024);
+    static const int64_t maxRounds = [] { const char* e = std::getenv("WO_FLOOD_MAX_ROUNDS"); const long long v = e ? std::atoll(e) : 0; return v > 0 ? (int64_t)v : (int64_t)200000; }();
+    bool done = false, over = false;
+    int batch = 32;
+    for (int64_t launched = 0; launched < maxRounds && !done;) {
+        for (int b = 0; b < batch; ++b) {
+            launch(p, FAM_FLOOD_EVAL, k_fl_eval, grid, WO_BLOCK, D, Ls, C);
+            launch(p, FAM_FLOOD_APPLY, k_fl_apply, grid, WO_BLOCK, D, Ls, C);
+        }
+        launched += batch;
+        WO_HIP(hipMemcpyAsync(hC, C, sizeof(FlCtrl), hipMemcpyDeviceToHost, s));
+        WO_HIP(hipStreamSynchronize(s));
+        done = hC->done != 0; over = hC->overflow != 0;
+        if (over) break;
+        if (batch < 256) batch *= 2;
+    }
+    bool ok = done && !over;
+    if (ok) {
+        launch(p, FAM_FLOOD_MISC, k_fl_verify, blocks_for(L, 4096), WO_BLOCK, D, C);
+        launch(p, FAM_FLOOD_MISC, k_fl_jump_init, blocks_for(L, 4096), WO_BLOCK, D, G.jump);
+        for (int k = 0; k < 16; ++k) launch(p, FAM_FLOOD_MISC, k_fl_jump, blocks_for(L, 4096), WO_BLOCK, G.jump, L);    // 2^16 hops
+        launch(p, FAM_FLOOD_MISC, k_fl_export, blocks_for(L, 4096), WO_BLOCK, D, (const int32_t*)G.jump, G.outPar, G.outSurf, G.outRoot);
+        WO_HIP(hipMemcpyAsync(G.h_par, G.outPar, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipMemcpyAsync(G.h_surf, G.outSurf, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipMemcpyAsync(G.h_root, G.outRoot, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+        WO_HIP(hipMemcpyAsync(hC, C, sizeof(FlCtrl), hipMemcpyDeviceToHost, s));
+    }
+    WO_HIP(hipEventRecord(e1, s));
+    WO_HIP(hipStreamSynchronize(s));
+    float ms = 0; WO_HIP(hipEventElapsedTime(&ms, e0, e1));
+    p->eventPool.push_back(e0); p->eventPool.push_back(e1);
+    R.deviceMs += ms; R.rounds += hC->rounds; R.epochs += hC->epochs; R.evals += hC->evals; R.usedDevice = true;
+    if (ok && hC->notFixed != 0) ok = false;                // cannot happen at termination; refuse the result if it does
+    if (ok) {
+        R.ties += hC->ties;
+        static const bool acceptIdOrder = [] { const char* e = std::getenv("WO_FLOOD_TIES"); return e && std::string(e) == "id"; }();
+        if (hC->ties > 0 && !acceptIdOrder) ok = false;
+    }
+    if (!ok) R.fellBack = true;
+    return ok;
+}
+
+static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     hipStream_t s = p->ctx->stream;
     const size_t bytes = (size_t)p->N * sizeof(float);
     const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
@@ -277,17 +394,28 @@ static void flood_stage(wo_planet* p, double carveStrength) {
     auto lap = [&](const char* what) {
         if (!timing) return;
         auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[flood stage] %-10s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        std::fprintf(stderr, "[flood stage] %-12s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
         t0 = now;
     };
     if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("drain gpu"); }
     refresh_host_ocean(p);
     lap("ocean mask");
+    FloodScratch& S = p->flood;
+    if (!S.staticValid || S.staticN != p->N)
+        flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S);
+    lap("static");
+    if (S.L == 0) return;
+    static const bool hostOnly = [] { const char* e = std::getenv("WO_FLOOD"); return e && std::string(e) == "host"; }();
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
-    WO_HIP(hipStreamSynchronize(s));
-    lap("D2H");
-    priority_flood_carve_host(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, p->h_ocean.data(), carveStrength, p->flood);
-    lap("host flood");
+    const bool useDevice = !hostOnly && flood_device_pass1(p, R);       // synchronises the stream
+    if (hostOnly) WO_HIP(hipStreamSynchronize(s));
+    lap(hostOnly ? "D2H" : "device pass1");
+    flood_gather(p->h_pinned, S);
+    if (useDevice) flood_import_pass1(p->fgpu.h_par, p->fgpu.h_surf, p->fgpu.h_root, S);
+    else flood_pass1_host(S);
+    lap(useDevice ? "import" : "host pass1");
+    flood_pass23_host(p->h_pinned, carveStrength, S);
+    lap("host pass2+3");
     WO_HIP(hipMemcpyAsync(p->d_e, p->h_pinned, bytes, hipMemcpyHostToDevice, s));
     if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("H2D"); }
 }
@@ -350,10 +478,11 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t L = p->L;
     clk.end();
 
+    FloodRun floodRun;
     auto flood = [&](double cs) {
-        clk.begin("priority_flood(host)");
+        clk.begin("priority_flood");
         auto t0 = std::chrono::steady_clock::now();
-        flood_stage(p, cs);
+        flood_stage(p, cs, floodRun);
         floodHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         clk.end();
     };
@@ -490,7 +619,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
-                     {"carve_rounds_total", (double)carveRounds}, {"flood_host_ms", floodHostMs}};
+                     {"carve_rounds_total", (double)carveRounds}, {"flood_stage_ms", floodHostMs},
+                     {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
+                     {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
+                     {"flood_pass1_on_host", (floodRun.usedDevice && !floodRun.fellBack) ? 0.0 : 1.0}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
@@ -641,6 +773,7 @@ void wo_planet_destroy(wo_planet* p) {
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
+    flood_gpu_free(p->fgpu);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);

@@ -34,6 +34,12 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
 // xyz (3*N floats) orders the compact land arrays spatially; may be nullptr (index order)
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);
+// the pieces of the call above, used by the device flood (pass 1 on the GPU, passes 2/3 per drainage tree on the host)
+void flood_cell_noise(const FloodScratch& S, double* out);            // cellNoise per land cell, compact order
+void flood_gather(const float* e, FloodScratch& S);                   // land elevations -> compact arrays, pass-1 start state
+void flood_pass1_host(FloodScratch& S);                               // serial heap walk (reference order incl. heap tie mechanics)
+void flood_import_pass1(const int32_t* par, const float* surface, const int32_t* root, FloodScratch& S);
+void flood_pass23_host(float* e, double carveStrength, FloodScratch& S);
 
 // plates_host.cc — js/plates.js:241-348 (r_plate rewritten in place; plateSeeds in the Set's iteration order)
 void smooth_reconnect_plates_host(int32_t N, const int32_t* off, const int32_t* adj, int32_t* r_plate, int32_t numSeeds,

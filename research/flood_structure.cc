@@ -264,7 +264,7 @@ extern "C" int flood_bf(int32_t N, const int32_t* off, const int32_t* adj, const
         }
         dirty.swap(next);
         if (verbose && rounds % 100 == 0) fprintf(stderr, "round %lld dirty %zu pending %zu changes %lld\n", (long long)rounds, dirty.size(), pending.size(), (long long)changes);
-        if (rounds > 6000) break;
+        if (rounds > 60000) break;
     }
     out[15] = (double)resets; out[16] = (double)pendingTotal;
     int64_t mismatchParent = 0, mismatchS = 0, mismatchK = 0;

@@ -19,10 +19,10 @@ def run(mesh, e, oc, deltas):
     N = mesh.numRegions
     T = np.empty(N, np.int32); par = np.empty(N, np.int32); Sx = np.empty(N, np.float32); Kx = np.empty(N, np.float32)
     lib.flood_structure(N, a(mesh.adjOffset), a(mesh.adjList), a(e), a(oc), d.size, a(d), a(out), a(T), a(par), a(Sx), a(Kx))
-    for MODE in (0, 1):
+    for MODE in (1,):
         bf = np.zeros(32)
         t0 = time.time()
-        lib.flood_bf(N, a(mesh.adjOffset), a(mesh.adjList), a(e), a(oc), a(par), a(Sx), a(Kx), a(bf), 0.0, MODE, 0)
+        lib.flood_bf(N, a(mesh.adjOffset), a(mesh.adjList), a(e), a(oc), a(par), a(Sx), a(Kx), a(bf), 0.0, MODE, 1)
         bfn = ["rounds", "evals", "changes", "maxDirty", "mismatchParent", "mismatchS", "mismatchK", "tieCompares", "deepCompares", "maxStackDepth", "overflow", "walks", "walkSteps", "walkReject", "maxWalk", "resets", "pendingTotal"]
         print("BF mode", MODE, {n: int(bf[i]) for i, n in enumerate(bfn) if n not in ("walks", "walkSteps", "walkReject", "maxWalk")}, "sec %.2f" % (time.time() - t0), flush=True)
     names = ["L", "seeds", "popped", "maxHeap", "maxDepth", "units", "maxUnit", "units>8", "units>64", "units>1k", "units>16k", "cellsInUnits>64",

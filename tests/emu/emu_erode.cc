@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../planet_heightmap_generation_amd/csrc/erode_ops.h"
+#include "../../planet_heightmap_generation_amd/csrc/flood_ops.h"
 #include "../../planet_heightmap_generation_amd/csrc/plates_ops.h"
 #include "../../planet_heightmap_generation_amd/csrc/wo_internal.h"
 
@@ -285,6 +286,85 @@ extern "C" void emu_warp(int32_t N, const int32_t* off, const int32_t* adj, floa
 extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, float* e, const uint8_t* ocean, double cs) {
     FloodScratch fs;
     priority_flood_carve_host(N, off, adj, nullptr, e, ocean, cs, fs);
+}
+
+
+// Device flood (flood_ops.h): the same bodies and the same round / epoch control as k_fl_eval / k_fl_apply
+// (flood_kernels.h), one "thread" at a time.  Jacobi: every evaluation of a round sees the labels of the previous
+// round.  stats: [rounds, epochs, evaluations, changes, equal-key decisions, not-fixed cells, overflow, max stack depth]
+extern "C" int emu_flood_device(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, const uint8_t* ocean, double cs,
+                                int32_t acceptIdOrder, double* stats) {
+    FloodScratch S;
+    flood_build_static(N, off, adj, xyz, ocean, S);
+    const int32_t L = S.L;
+    if (L == 0) return 0;
+    std::vector<double> nz(L); flood_cell_noise(S, nz.data());
+    std::vector<int32_t> seedIdx(L, -1);
+    for (size_t k = 0; k < S.seedCell.size(); ++k) seedIdx[S.seedCell[k]] = (int32_t)k;
+    std::vector<float> eL(L);
+    std::vector<FlHead> A(L), P(L), Fd(L);
+    std::vector<unsigned long long> As((size_t)L * FL_LD), Ps((size_t)L * FL_LD), Fs((size_t)L * FL_LD);
+    std::vector<int32_t> fdEpoch(L, 0), inDirty(L, 0); std::vector<uint8_t> isPending(L, 0);
+    FloodDev D{};
+    D.L = L; D.off = S.offL.data(); D.adj = S.adjL.data(); D.cell = S.landCell.data(); D.nz = nz.data(); D.seedIdx = seedIdx.data(); D.e = eL.data();
+    D.A = A.data(); D.Astk = As.data(); D.P = P.data(); D.Pstk = Ps.data(); D.F = Fd.data(); D.Fstk = Fs.data(); D.fdEpoch = fdEpoch.data();
+    D.inDirty = inDirty.data(); D.isPending = isPending.data();
+    for (int32_t i = 0; i < L; ++i) {                                          // k_fl_init
+        const float v = e[D.cell[i]]; eL[i] = v;
+        FlHead h; h.par = FL_NONE; h.S = v; h.K = 0; h.dep = 0; h.top = 0; h.spare = 0;
+        if (seedIdx[i] >= 0) { h.par = FL_SEED; h.K = (float)((double)v + nz[i]); h.dep = 1; h.top = fl_pack(h.K, D.cell[i]); As[(size_t)i * FL_LD] = h.top; }
+        A[i] = h;
+    }
+    std::vector<int32_t> dirty, next, changed, pend[2];
+    for (int32_t c : S.seedCell)                                               // k_fl_seed_dirty
+        for (int32_t j = D.off[c]; j < D.off[c + 1]; ++j) { const int32_t y = D.adj[j]; if (seedIdx[y] < 0 && !inDirty[y]) { inDirty[y] = 1; dirty.push_back(y); } }
+    int64_t rounds = 0, epochs = 0, evals = 0, changes = 0; int32_t epoch = 1, pcur = 0, relIdx = 0; bool release = false, over = false, done = false;
+    int32_t maxDep = 0;
+    while (!done) {
+        const std::vector<int32_t>& list = release ? pend[relIdx] : dirty;
+        changed.clear();
+        for (int32_t x : list) {                                               // k_fl_eval
+            inDirty[x] = 0;
+            bool pendNew = false, o = false;
+            const bool ch = flood_eval_cell(D, x, epoch, release, &pendNew, &o);
+            if (o) over = true;
+            if (ch) changed.push_back(x);
+            if (pendNew) pend[pcur].push_back(x);
+        }
+        evals += (int64_t)list.size();
+        next.clear();
+        for (int32_t x : changed) {                                            // k_fl_apply
+            flood_apply_cell(D, x, epoch);
+            if (A[x].dep > maxDep) maxDep = A[x].dep;
+            for (int32_t j = D.off[x]; j < D.off[x + 1]; ++j) { const int32_t y = D.adj[j]; if (seedIdx[y] < 0 && !inDirty[y]) { inDirty[y] = 1; next.push_back(y); } }
+        }
+        changes += (int64_t)changed.size();
+        dirty.swap(next); ++rounds;
+        if (release) { pend[relIdx].clear(); release = false; }
+        if (dirty.empty()) {
+            if (!pend[pcur].empty()) { ++epoch; ++epochs; release = true; relIdx = pcur; pcur ^= 1; }
+            else done = true;
+        }
+        if (over || rounds > 4000000) break;
+    }
+    int64_t notFixed = 0, ties = 0;
+    for (int32_t i = 0; i < L; ++i) { bool nf = false, tie = false; flood_verify_cell(D, i, &nf, &tie); notFixed += nf; ties += tie; }
+    if (stats) { stats[0] = (double)rounds; stats[1] = (double)epochs; stats[2] = (double)evals; stats[3] = (double)changes; stats[4] = (double)ties;
+                 stats[5] = (double)notFixed; stats[6] = over ? 1 : 0; stats[7] = (double)maxDep; }
+    const bool ok = done && !over && notFixed == 0 && (ties == 0 || acceptIdOrder);
+    flood_gather(e, S);
+    if (ok) {
+        std::vector<int32_t> par(L), root(L, -1); std::vector<float> surf(L);
+        for (int32_t i = 0; i < L; ++i) { par[i] = A[i].par; surf[i] = A[i].S; }
+        for (int32_t i = 0; i < L; ++i) {                                      // k_fl_jump / k_fl_export
+            if (par[i] == FL_NONE) continue;
+            int32_t c = i; while (par[c] >= 0) c = par[c];
+            root[i] = seedIdx[c];
+        }
+        flood_import_pass1(par.data(), surf.data(), root.data(), S);
+    } else flood_pass1_host(S);
+    flood_pass23_host(e, cs, S);
+    return ok ? 0 : 1;
 }
 
 // plate projection: the kernel bodies of csrc/plates_ops.h, bucket grid included, one "thread" per cell
