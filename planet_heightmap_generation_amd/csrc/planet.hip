@@ -273,9 +273,11 @@ struct StageClock {
 // priorityFloodCarve (js/terrain-post.js:59-215).  Pass 1 (the noise-keyed best-first flood) runs on the device as a
 // label-correcting fixed point (flood_ops.h / flood_kernels.h); passes 2 and 3 (sequential carve along the drain
 // paths, ordered fix-up) run per drainage tree on host threads (flood_host.cc) from the downloaded drainTo / surface.
-// WO_FLOOD=host keeps pass 1 on the host too (the reference's heap walk itself).  The device result is the
-// reference's whenever no decision hinged on two EQUAL keys (the heap orders those by its array mechanics); the
-// decisions that did are counted and, unless WO_FLOOD_TIES=id accepts the cell-id order, pass 1 is redone on the host.
+// Which pass 1 runs is read from the environment at every call: WO_FLOOD=device selects the device formulation; the
+// default is the host heap walk (the reference's own order, and at 10^7 cells still the faster of the two: see
+// DESIGN.md).  The device result is the reference's whenever no decision hinged on two EQUAL keys (the heap orders
+// those by its array mechanics); the decisions that did are counted and, unless WO_FLOOD_TIES=id accepts the cell-id
+// order, pass 1 is redone on the host.
 // ---------------------------------------------------------------------------------------------------
 struct FloodRun { double deviceMs = 0; int64_t rounds = 0, epochs = 0, evals = 0, ties = 0; bool usedDevice = false, fellBack = false; };
 
@@ -379,7 +381,8 @@ static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
     if (ok && hC->notFixed != 0) ok = false;                // cannot happen at termination; refuse the result if it does
     if (ok) {
         R.ties += hC->ties;
-        static const bool acceptIdOrder = [] { const char* e = std::getenv("WO_FLOOD_TIES"); return e && std::string(e) == "id"; }();
+        const char* te = std::getenv("WO_FLOOD_TIES");
+        const bool acceptIdOrder = te && std::string(te) == "id";
         if (hC->ties > 0 && !acceptIdOrder) ok = false;
     }
     if (!ok) R.fellBack = true;
@@ -405,7 +408,8 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
         flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S);
     lap("static");
     if (S.L == 0) return;
-    static const bool hostOnly = [] { const char* e = std::getenv("WO_FLOOD"); return e && std::string(e) == "host"; }();
+    const char* fe = std::getenv("WO_FLOOD");
+    const bool hostOnly = !(fe && std::string(fe) == "device");
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     const bool useDevice = !hostOnly && flood_device_pass1(p, R);       // synchronises the stream
     if (hostOnly) WO_HIP(hipStreamSynchronize(s));

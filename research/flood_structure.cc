@@ -211,7 +211,25 @@ extern "C" int flood_bf(int32_t N, const int32_t* off, const int32_t* adj, const
     for (int32_t r = 0; r < N; ++r) if (isSeed[r]) for (int32_t i = off[r]; i < off[r + 1]; ++i) { const int32_t nb = adj[i]; if (!ocean[nb] && !isSeed[nb] && !inDirty[nb]) { inDirty[nb] = 1; dirty.push_back(nb); } }
     std::vector<std::pair<int32_t, Lab>> props;
     int64_t rounds = 0, evals = 0, changes = 0, maxDirty = 0, overflow = 0, resets = 0, pendingTotal = 0; int32_t maxDep = 0;
+    const bool throttle = DELTA > 0 && DELTA < 5;
+    std::vector<int32_t> waiting, waiting2; std::vector<uint8_t> inWait(N, 0);
+    double Chor = throttle ? -1e30 : 1e30, lastMin = 1e30;
+    if (throttle) { for (int32_t r = 0; r < N; ++r) if (isSeed[r]) { waiting.push_back(r); inWait[r] = 1; } dirty.clear(); std::fill(inDirty.begin(), inDirty.end(), 0); }
     for (;;) {
+        if (throttle) {
+            // horizon: lowest tau still moving (changed last round / pending / waiting) + DELTA; never decreases
+            double m = lastMin;
+            for (int32_t w : waiting) if (A[w].par != -1) m = std::min(m, (double)A[w].k[0]);
+            if (m < 1e29) Chor = std::max(Chor, m + DELTA);
+            waiting2.clear();
+            for (int32_t w : waiting) {
+                if (A[w].par == -1) { inWait[w] = 0; continue; }
+                if ((double)A[w].k[0] < Chor) { inWait[w] = 0; for (int32_t i = off[w]; i < off[w + 1]; ++i) { const int32_t nb = adj[i]; if (!ocean[nb] && !isSeed[nb] && !inDirty[nb]) { inDirty[nb] = 1; dirty.push_back(nb); } } }
+                else waiting2.push_back(w);
+            }
+            waiting.swap(waiting2);
+        }
+        if (dirty.empty() && pending.empty() && !waiting.empty()) { lastMin = 1e30; ++rounds; if (rounds > 60000) break; continue; }
         if (dirty.empty()) {
             if (pending.empty()) break;
             // global quiescence: every label is consistent with its parent's; pending switches are safe now
@@ -230,6 +248,7 @@ extern "C" int flood_bf(int32_t N, const int32_t* off, const int32_t* adj, const
                 const int32_t y = adj[i];
                 if (ocean[y] || A[y].par == -1) continue;
                 if (A[y].par == x) continue;            // x's child cannot be its parent
+                if (!((double)A[y].k[0] < Chor)) continue;   // beyond the horizon: not yet a parent
                 if (best < 0 || labcmp(A[y], A[best]) < 0) best = y;
             }
             Lab P; P.par = -1; P.dep = 0; P.S = e[x]; P.K = 0;
@@ -254,9 +273,13 @@ extern "C" int flood_bf(int32_t N, const int32_t* off, const int32_t* adj, const
                 fprintf(stderr, "  x %d: par %d->%d S %.9g->%.9g K %.9g->%.9g dep %d->%d top (%.9g,%d)->(%.9g,%d) pend %d\n", pr.first, o.par, n.par, o.S, n.S, o.K, n.K, o.dep, n.dep,
                         o.dep ? o.k[0] : 0.f, o.dep ? o.c[0] : -1, n.dep ? n.k[0] : 0.f, n.dep ? n.c[0] : -1, (int)isPending[pr.first]); }
         }
+        lastMin = 1e30;
         for (auto& pr : props) {
             ++changes;
             const int32_t x = pr.first;
+            if (A[x].par != -1) lastMin = std::min(lastMin, (double)A[x].k[0]);
+            if (pr.second.par != -1) lastMin = std::min(lastMin, (double)pr.second.k[0]);
+            if (throttle && pr.second.par != -1 && !((double)pr.second.k[0] < Chor) && !inWait[x]) { inWait[x] = 1; waiting.push_back(x); }
             A[x] = pr.second;
             if (pr.second.par >= 0 && (!hasFD[x] || labcmp(pr.second, FD[x]) < 0)) { FD[x] = pr.second; hasFD[x] = 1; }
             maxDep = std::max(maxDep, pr.second.dep);

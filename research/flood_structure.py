@@ -19,12 +19,12 @@ def run(mesh, e, oc, deltas):
     N = mesh.numRegions
     T = np.empty(N, np.int32); par = np.empty(N, np.int32); Sx = np.empty(N, np.float32); Kx = np.empty(N, np.float32)
     lib.flood_structure(N, a(mesh.adjOffset), a(mesh.adjList), a(e), a(oc), d.size, a(d), a(out), a(T), a(par), a(Sx), a(Kx))
-    for MODE in (1,):
+    for DELTA in (0.002, 0.01, 0.05, 10.0):
         bf = np.zeros(32)
         t0 = time.time()
-        lib.flood_bf(N, a(mesh.adjOffset), a(mesh.adjList), a(e), a(oc), a(par), a(Sx), a(Kx), a(bf), 0.0, MODE, 1)
+        lib.flood_bf(N, a(mesh.adjOffset), a(mesh.adjList), a(e), a(oc), a(par), a(Sx), a(Kx), a(bf), DELTA, 1, 0)
         bfn = ["rounds", "evals", "changes", "maxDirty", "mismatchParent", "mismatchS", "mismatchK", "tieCompares", "deepCompares", "maxStackDepth", "overflow", "walks", "walkSteps", "walkReject", "maxWalk", "resets", "pendingTotal"]
-        print("BF mode", MODE, {n: int(bf[i]) for i, n in enumerate(bfn) if n not in ("walks", "walkSteps", "walkReject", "maxWalk")}, "sec %.2f" % (time.time() - t0), flush=True)
+        print("BF delta", DELTA, {n: int(bf[i]) for i, n in enumerate(bfn) if n not in ("walks", "walkSteps", "walkReject", "maxWalk")}, "sec %.2f" % (time.time() - t0), flush=True)
     names = ["L", "seeds", "popped", "maxHeap", "maxDepth", "units", "maxUnit", "units>8", "units>64", "units>1k", "units>16k", "cellsInUnits>64",
              "tauViolations", "consecutiveEqualKeyPops", "equalKeyPairsWithin2hops", "flooded", "maxHopInUnit", "tauMin", "tauMax"]
     res = {n: out[i] for i, n in enumerate(names)}
