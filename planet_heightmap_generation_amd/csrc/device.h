@@ -153,11 +153,13 @@ inline void launch(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, in
         hipEvent_t a = profile_event(p), b = profile_event(p);
         WO_HIP(hipEventRecord(a, s));
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, args...);
+        WO_HIP(hipGetLastError());                 // a launch that cannot be configured would otherwise be a silent no-op
         WO_HIP(hipEventRecord(b, s));
         p->pending.push_back({fam, a, b});
         if (p->pending.size() >= 4096) profile_resolve(p);
     } else {
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, args...);
+        WO_HIP(hipGetLastError());
     }
 }
 
@@ -166,7 +168,9 @@ inline void launch_shmem(wo_planet* p, int fam, void (*kernel)(KArgs...), int gr
     hipStream_t s = p->ctx->stream;
     hipEvent_t a = nullptr, b = nullptr;
     if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+    if (shmem > (size_t)(64 << 10)) WO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, s, args...);
+    WO_HIP(hipGetLastError());
     if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({fam, a, b}); if (p->pending.size() >= 4096) profile_resolve(p); }
 }
 

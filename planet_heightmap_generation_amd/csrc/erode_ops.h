@@ -73,6 +73,8 @@ struct Fields {
     // erodeComposite scratch
     int32_t L;                 // land cells
     int32_t* land;             // landCells in current order [L]
+    const int32_t* landIdx;    // land cells in ascending id (the order of the index-order passes over land) [L]
+    int32_t xcdTileL;          // blocks per XCD tile for passes over the land list
     int32_t* rank;             // rank[c] = index of c in land, -1 for ocean [N]
     int32_t* target;           // drainTarget [N]
     TargetRank* tr;            // {target, rank} written by the receivers pass [N] (ocean: {-1, -1})
@@ -102,6 +104,20 @@ struct Fields {
 };
 
 WO_HD inline double nd_or_eps(float d) { return (d == 0.0f || d != d) ? 1e-6 : (double)d; }   // `x || 1e-6`
+
+// Neighbour rows are read in one batch: the index-order passes are bound by the latency of dependent loads (offset ->
+// neighbour id -> neighbour state, once per neighbour when written as a plain loop), not by bytes, so a thread first
+// issues the loads of the whole row, then the gathers of every neighbour's state, and only then computes.  Rows longer
+// than WO_ROW (0.1 % of the cells of a jittered Fibonacci sphere) take the plain loops.  Slots past the degree hold the
+// cell itself: a valid index whose value is never used.
+constexpr int WO_ROW = 8;
+WO_HD inline int load_row(const Fields& F, int32_t r, int32_t& b, int32_t (&nb)[WO_ROW]) {
+    b = F.off[r];
+    const int deg = F.off[r + 1] - b;
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) nb[k] = (k < deg) ? F.adj[b + k] : r;
+    return deg;
+}
 
 // js/climate-util.js:13-21 smoothField: (self + neighbours) / (1 + degree), double sum in adjacency order, f32 store
 WO_HD inline float smooth_field_cell(const Fields& F, const float* src, int32_t r) {
@@ -239,28 +255,50 @@ WO_HD inline float warp_blend(float origF, float warpedF, double warpBias, bool 
 // ------------------------------------------------------------------------------------------------
 // Hydraulic: receivers (js/terrain-post.js:566-601)
 // ------------------------------------------------------------------------------------------------
-WO_HD inline void receiver_cell(const Fields& F, int32_t r) {
-    if (F.ocean[r]) { F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z; return; }
+WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) {
+    if (F.ocean[r]) { F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z; return -1; }
     const double h = F.e[r];
     int32_t bestNb = -1, bestJ = -1;
     double bestDrop = -INFINITY;
-    const int32_t b = F.off[r], en = F.off[r + 1];
-    for (int32_t j = b; j < en; ++j) {
-        const int32_t nb = F.adj[j];
-        const double drop = h - (double)F.e[nb];
-        if (drop > bestDrop) { bestDrop = drop; bestNb = nb; bestJ = j; }
-    }
-    if (bestDrop <= 0) {
-        double minAscent = INFINITY;
+    int32_t b, nbs[WO_ROW];
+    const int deg = load_row(F, r, b, nbs);
+    const int32_t en = b + deg;
+    if (deg <= WO_ROW) {
+        float eh[WO_ROW];
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) eh[k] = F.e[nbs[k]];
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) {
+            const double drop = h - (double)eh[k];
+            if (k < deg && drop > bestDrop) { bestDrop = drop; bestNb = nbs[k]; bestJ = b + k; }
+        }
+        if (bestDrop <= 0) {
+            double minAscent = INFINITY;
+#pragma unroll
+            for (int k = 0; k < WO_ROW; ++k) {
+                const double ascent = (double)eh[k] - h;
+                if (k < deg && ascent < minAscent) { minAscent = ascent; bestNb = nbs[k]; bestJ = b + k; }
+            }
+        }
+    } else {
         for (int32_t j = b; j < en; ++j) {
             const int32_t nb = F.adj[j];
-            const double ascent = (double)F.e[nb] - h;
-            if (ascent < minAscent) { minAscent = ascent; bestNb = nb; bestJ = j; }
+            const double drop = h - (double)F.e[nb];
+            if (drop > bestDrop) { bestDrop = drop; bestNb = nb; bestJ = j; }
+        }
+        if (bestDrop <= 0) {
+            double minAscent = INFINITY;
+            for (int32_t j = b; j < en; ++j) {
+                const int32_t nb = F.adj[j];
+                const double ascent = (double)F.e[nb] - h;
+                if (ascent < minAscent) { minAscent = ascent; bestNb = nb; bestJ = j; }
+            }
         }
     }
     F.target[r] = bestNb;
     { TargetRank v; v.target = bestNb; v.rank = F.rank[r]; F.tr[r] = v; }
     if (bestNb >= 0) { const float d = F.dist[bestJ]; F.cellDist[r] = (d == 0.0f || d != d) ? (float)1e-6 : d; }
+    return bestNb;
 }
 
 // Flow (js/terrain-post.js:604-611).  fwd edge: receiver is land and ranked after the donor.
@@ -291,11 +329,78 @@ WO_HD inline int32_t latest_event_before(const Fields& F, int32_t x, int32_t r) 
     return best;
 }
 
+// the same with x's row and the {target, rank} of its neighbours already loaded (trx = tr[x])
+WO_HD inline int32_t latest_event_before_row(int32_t x, int32_t r, int32_t rr, TargetRank trx, const int32_t (&nb)[WO_ROW], const TargetRank (&trn)[WO_ROW], int deg) {
+    int32_t best = -1, bestRank = -1;
+    if (x != r && trx.target >= 0 && trx.rank > rr) { best = x; bestRank = trx.rank; }
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) {
+        const TargetRank v = trn[k];
+        if (k < deg && nb[k] != r && v.target == x && v.rank > rr && (best < 0 || v.rank < bestRank)) { best = nb[k]; bestRank = v.rank; }
+    }
+    return best;
+}
+
 WO_HD inline int32_t store_index(const Fields& F, int32_t cell) { return F.slotOf ? F.slotOf[cell] : cell; }
 // granule index of the event task p leaves on location x (p == x: own turn, else deposit)
 WO_HD inline int32_t granule_index(const Fields& F, int32_t x, int32_t p) { return p < 0 ? -1 : 2 * store_index(F, p) + (p == x ? 0 : 1); }
 
+WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r);
 WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
+    if (F.ocean[r]) return;
+    // batched form: rows of r, of its receiver t and of t's receiver t2 first, then every neighbour's {target, rank}
+    const TargetRank trr = F.tr[r];
+    const int32_t t = trr.target, rr = trr.rank;
+    int32_t bR, nbR[WO_ROW], bT = 0, nbT[WO_ROW], bT2 = 0, nbT2[WO_ROW];
+    const int degR = load_row(F, r, bR, nbR);
+    TargetRank trt; trt.target = -1; trt.rank = -1;
+    int degT = 0, degT2 = 0;
+    if (t >= 0) { trt = F.tr[t]; degT = load_row(F, t, bT, nbT); }
+    const bool tLand = t >= 0 && trt.rank >= 0;                     // ocean cells carry rank -1
+    const float cdT = tLand ? F.cellDist[t] : 0.0f;
+    const int32_t t2 = (tLand && trt.target >= 0 && cdT > 0) ? trt.target : -1;
+    TargetRank trt2; trt2.target = -1; trt2.rank = -1;
+    if (t2 >= 0) { trt2 = F.tr[t2]; degT2 = load_row(F, t2, bT2, nbT2); }
+    if (degR > WO_ROW || degT > WO_ROW || degT2 > WO_ROW) { solve_setup_cell_plain(F, r); return; }
+    TargetRank qR[WO_ROW], qT[WO_ROW], qT2[WO_ROW];
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) qR[k] = F.tr[nbR[k]];
+    if (tLand) {
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) qT[k] = F.tr[nbT[k]];
+    }
+    const bool t2Land = t2 >= 0 && trt2.rank >= 0;
+    if (t2Land) {
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) qT2[k] = F.tr[nbT2[k]];
+    }
+    SolveTask T;
+    T.predSelf = granule_index(F, r, latest_event_before_row(r, r, rr, trr, nbR, qR, degR));
+    T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
+    T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
+    T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
+    if (t >= 0) {
+        T.flags |= 4u;
+        T.e0t = F.e[t];
+        if (!tLand) T.flags |= 1u;
+        else {
+            T.predT = granule_index(F, t, latest_event_before_row(t, r, rr, trt, nbT, qT, degT));
+            T.cellDistT = cdT;
+            if (t2 >= 0) {
+                T.flags |= 8u;
+                T.e0t2 = F.e[t2];
+                if (!t2Land) T.flags |= 2u;
+                else T.predT2 = granule_index(F, t2, latest_event_before_row(t2, r, rr, trt2, nbT2, qT2, degT2));
+            }
+        }
+    }
+    const int32_t si = store_index(F, r);
+    F.task[si] = T;
+    SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
+    F.out[si] = z;
+    if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+}
+WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     if (F.ocean[r]) return;
     SolveTask T;
     const int32_t t = F.target[r];
@@ -379,11 +484,21 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
     if (F.ocean[x]) return F.e[x];
     int32_t best = -1, bestRank = 0x7fffffff;      // latest == smallest rank
     { const TargetRank v = F.tr[x]; if (v.target >= 0) { best = x; bestRank = v.rank; } }
-    for (int32_t j = F.off[x]; j < F.off[x + 1]; ++j) {
-        const int32_t n = F.adj[j];
-        const TargetRank v = F.tr[n];              // ocean cells carry target -1, never == x
-        if (v.target != x) continue;
-        if (v.rank < bestRank) { best = n; bestRank = v.rank; }
+    int32_t b, nbs[WO_ROW];
+    const int deg = load_row(F, x, b, nbs);
+    if (deg <= WO_ROW) {
+        TargetRank q[WO_ROW];
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) q[k] = F.tr[nbs[k]];
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) if (k < deg && q[k].target == x && q[k].rank < bestRank) { best = nbs[k]; bestRank = q[k].rank; }
+    } else {
+        for (int32_t j = b; j < b + deg; ++j) {
+            const int32_t n = F.adj[j];
+            const TargetRank v = F.tr[n];              // ocean cells carry target -1, never == x
+            if (v.target != x) continue;
+            if (v.rank < bestRank) { best = n; bestRank = v.rank; }
+        }
     }
     if (best < 0) return F.e[x];
     return (best == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, best)].dep.v;
@@ -400,12 +515,28 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
     double total = 0;
     if (!F.ocean[r]) {
         const double h = F.e[r];
-        for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
-            const double nh = F.me[F.adj[j]];
-            if (nh >= h) continue;
-            const double d = nd_or_eps(F.dist[j]);
-            const double slope = (h - nh) / d;
-            if (slope > talus) total += (slope - talus) * d;
+        int32_t b, nbs[WO_ROW];
+        const int deg = load_row(F, r, b, nbs);
+        if (deg <= WO_ROW) {
+            float mh[WO_ROW], dd[WO_ROW];
+#pragma unroll
+            for (int k = 0; k < WO_ROW; ++k) { mh[k] = F.me[nbs[k]]; dd[k] = (k < deg) ? F.dist[b + k] : 1.0f; }
+#pragma unroll
+            for (int k = 0; k < WO_ROW; ++k) {
+                const double nh = mh[k];
+                if (k >= deg || nh >= h) continue;
+                const double d = nd_or_eps(dd[k]);
+                const double slope = (h - nh) / d;
+                if (slope > talus) total += (slope - talus) * d;
+            }
+        } else {
+            for (int32_t j = b; j < b + deg; ++j) {
+                const double nh = F.me[F.adj[j]];
+                if (nh >= h) continue;
+                const double d = nd_or_eps(F.dist[j]);
+                const double slope = (h - nh) / d;
+                if (slope > talus) total += (slope - talus) * d;
+            }
         }
     }
     F.totalExcess[r] = total;
@@ -422,25 +553,65 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
     const double myTotal = F.totalExcess[c];
     const double myTransfer = kThermal * myTotal * 0.5;
     int nIn = 0, nOut = 0; bool hasOut = false;
-    for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
-        const int32_t nb = F.adj[j];
-        const double nh = F.me[nb];         // +inf for ocean neighbours: falls into the branch below and finds totalExcess 0
-        const double d = nd_or_eps(F.dist[j]);
-        if (nh < h) {                       // c sends to nb on c's own turn
-            const double slope = (h - nh) / d;
-            if (slope > talus && myTotal > 0) {
-                hasOut = true;
-                if (outShare) { const float excess = (float)((slope - talus) * d); outShare[nOut++ * stride] = ((double)excess / myTotal) * myTransfer; }
-            }
-        } else if (nh > h) {                // nb may send to c on nb's turn
-            const double slope = (nh - h) / d;
-            if (slope > talus) {
-                const double tot = F.totalExcess[nb];
+    int32_t b, nbs[WO_ROW];
+    const int deg = load_row(F, c, b, nbs);
+    const bool batched = deg <= WO_ROW;
+    float mh[WO_ROW], dd[WO_ROW];
+    if (batched) {
+        // one batch for the row's heights and distances, a second one for the senders' totals and ranks
+        double tx[WO_ROW]; int32_t rk[WO_ROW]; bool snd[WO_ROW];
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) { mh[k] = F.me[nbs[k]]; dd[k] = (k < deg) ? F.dist[b + k] : 1.0f; }
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) {
+            const double nh = mh[k], d = nd_or_eps(dd[k]);
+            snd[k] = k < deg && nh > h && ((nh - h) / d > talus);
+            tx[k] = snd[k] ? F.totalExcess[nbs[k]] : 0.0;
+            rk[k] = snd[k] ? F.rank[nbs[k]] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) {
+            if (k >= deg) continue;
+            const double nh = mh[k];         // +inf for ocean neighbours: falls into the sender branch and finds totalExcess 0
+            const double d = nd_or_eps(dd[k]);
+            if (nh < h) {                       // c sends to nb on c's own turn
+                const double slope = (h - nh) / d;
+                if (slope > talus && myTotal > 0) {
+                    hasOut = true;
+                    if (outShare) { const float excess = (float)((slope - talus) * d); outShare[nOut++ * stride] = ((double)excess / myTotal) * myTransfer; }
+                }
+            } else if (snd[k]) {                // nb sends to c on nb's turn
+                const double slope = (nh - h) / d;
+                const double tot = tx[k];
                 if (tot > 0) {
                     const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
                     inShare[nIn * stride] = ((double)excess / tot) * (kThermal * tot * 0.5);
-                    inRank[nIn * stride] = F.rank[nb];
+                    inRank[nIn * stride] = rk[k];
                     ++nIn;
+                }
+            }
+        }
+    } else {
+        for (int32_t j = b; j < b + deg; ++j) {
+            const int32_t nb = F.adj[j];
+            const double nh = F.me[nb];         // +inf for ocean neighbours: falls into the branch below and finds totalExcess 0
+            const double d = nd_or_eps(F.dist[j]);
+            if (nh < h) {                       // c sends to nb on c's own turn
+                const double slope = (h - nh) / d;
+                if (slope > talus && myTotal > 0) {
+                    hasOut = true;
+                    if (outShare) { const float excess = (float)((slope - talus) * d); outShare[nOut++ * stride] = ((double)excess / myTotal) * myTransfer; }
+                }
+            } else if (nh > h) {                // nb may send to c on nb's turn
+                const double slope = (nh - h) / d;
+                if (slope > talus) {
+                    const double tot = F.totalExcess[nb];
+                    if (tot > 0) {
+                        const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
+                        inShare[nIn * stride] = ((double)excess / tot) * (kThermal * tot * 0.5);
+                        inRank[nIn * stride] = F.rank[nb];
+                        ++nIn;
+                    }
                 }
             }
         }
@@ -460,10 +631,10 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
         if (phase == 0 && hasOut && outShare) {      // c's own turn: its sends, in adjacency order (js/terrain-post.js:676-680)
             for (int k = 0; k < nOut; ++k) delta = (float)((double)delta - outShare[k * stride]);
         } else if (phase == 0 && hasOut) {
-            for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
-                const double nh = F.me[F.adj[j]];
+            for (int32_t j = b; j < b + deg; ++j) {
+                const double nh = batched ? (double)mh[j - b] : (double)F.me[F.adj[j]];
                 if (!(nh < h)) continue;
-                const double d = nd_or_eps(F.dist[j]);
+                const double d = nd_or_eps(batched ? dd[j - b] : F.dist[j]);
                 const double slope = (h - nh) / d;
                 if (slope > talus) {
                     const float excess = (float)((slope - talus) * d);

@@ -26,6 +26,16 @@ namespace wo {
                  once_ = 1;                                                                                          \
          once_ && r < (n); once_ = 0)
 
+// The same over the ascending land list: i = position in F.landIdx, r = the cell.  The erosion passes touch land cells
+// only (28 % of a synthetic planet); the per-ocean-cell constants they used to rewrite every iteration are set once per
+// erodeComposite by k_erode_ocean_init.
+#define WO_XCD_LAND(i, r)                                                                                            \
+    for (int32_t xi_ = (int32_t)(blockIdx.x >> 3), xt_ = F.xcdTileL,                                                 \
+                 i = (int32_t)((((xi_ / xt_) * 8 + (int32_t)(blockIdx.x & 7u)) * xt_ + (xi_ % xt_)) * (int32_t)blockDim.x + (int32_t)threadIdx.x), \
+                 once_ = 1;                                                                                          \
+         once_ && i < F.L; once_ = 0)                                                                                \
+        for (int32_t r = F.landIdx[i], once2_ = 1; once2_; once2_ = 0)
+
 // Block-uniform strided loop: every thread of the workgroup runs the same number of trips (needed around
 // block_append's barriers); `valid` tells whether index i is in range.
 #define WO_BLOCK_STRIDE(i, valid, n)                                                              \
@@ -144,11 +154,19 @@ __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N
 // ---------------------------------------------------------------- hydraulic ---------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_XCD_CELLS(r, F.N) receiver_cell(F, r); }
 // receivers + the start state of the flow accumulation (k_flow_init) in one pass over the cells
+// per-ocean-cell constants of the hydraulic and thermal passes (the ocean mask is fixed during an erodeComposite)
+__global__ __launch_bounds__(WO_BLOCK) void k_erode_ocean_init(Fields F) {
+    WO_GRID_STRIDE(r, F.N) {
+        if (!F.ocean[r]) continue;
+        F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z;
+        F.accA[r] = 0; F.jumpA[r] = -1; F.flow[r] = 0.0f; F.totalExcess[r] = 0.0; F.me[r] = INFINITY;
+    }
+}
 __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int32_t* donorCnt) {
-    WO_XCD_CELLS(r, F.N) {
-        receiver_cell(F, r);
-        int32_t j = -1; uint32_t a = 0;
-        if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
+    WO_XCD_LAND(i, r) {
+        const int32_t t = receiver_cell(F, r);
+        int32_t j = -1; const uint32_t a = 1;
+        if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
         F.accA[r] = a; F.jumpA[r] = j;
         if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
     }
@@ -256,15 +274,25 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt) {
-    WO_XCD_CELLS(c, F.N) {
-        donorCnt[c] = 0;                                    // for the next iteration's receivers pass
+    WO_XCD_LAND(i, c) {
+        donorCnt[c] = 0;                                    // for the next iteration's receivers pass (only land cells are counted into)
         float fl = 0.0f;
-        if (!F.ocean[c]) {
+        {
             uint32_t f = F.accA[c];
             const int32_t rc = F.rank[c];
-            for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
-                const int32_t n = F.adj[j];
-                if (!F.ocean[n] && F.target[n] == c && F.rank[n] > rc) f += F.accA[n];   // late donors, un-forwarded
+            int32_t b, nbs[WO_ROW];
+            const int deg = load_row(F, c, b, nbs);
+            if (deg <= WO_ROW) {
+                TargetRank q[WO_ROW];
+#pragma unroll
+                for (int k = 0; k < WO_ROW; ++k) q[k] = F.tr[nbs[k]];                        // ocean cells carry target -1
+#pragma unroll
+                for (int k = 0; k < WO_ROW; ++k) if (k < deg && q[k].target == c && q[k].rank > rc) f += F.accA[nbs[k]];   // late donors, un-forwarded
+            } else {
+                for (int32_t j = b; j < b + deg; ++j) {
+                    const int32_t n = F.adj[j];
+                    if (!F.ocean[n] && F.target[n] == c && F.rank[n] > rc) f += F.accA[n];
+                }
             }
             fl = (float)f;
         }
@@ -272,7 +300,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* dono
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_XCD_CELLS(r, F.N) solve_setup_cell(F, r); }
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_XCD_LAND(i, r) solve_setup_cell(F, r); }
 
 // One synchronous round of the solve dataflow.  Tasks come from two places: the leftovers of earlier rounds
 // and the bucket of tasks whose level in the previous erosion iteration was exactly this round (levels barely
@@ -478,25 +506,24 @@ __global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const in
 
 // `masked` (may be null): the thermal step's masked elevation of the new field, written in the same pass
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level, float* masked) {
-    WO_XCD_CELLS(r, F.N) {
+    WO_XCD_LAND(i, r) {
         const float v = solve_final_cell(F, r);
         out[r] = v;
-        const bool oc = F.ocean[r] != 0;
-        if (!oc) level[r] = F.out[store_index(F, r)].self.tag;
-        if (masked) masked[r] = oc ? INFINITY : v;
+        level[r] = F.out[store_index(F, r)].self.tag;
+        if (masked) masked[r] = v;
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, int32_t n) { WO_GRID_STRIDE(i, n) a[i] = v; }
 
 // ---------------------------------------------------------------- thermal -----------------------
-__global__ __launch_bounds__(WO_BLOCK) void k_masked_elev(Fields F) { WO_XCD_CELLS(r, F.N) F.me[r] = masked_elev_cell(F, r); }
-__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_XCD_CELLS(r, F.N) thermal_excess_cell(F, r, talus); }
+__global__ __launch_bounds__(WO_BLOCK) void k_masked_elev(Fields F) { WO_XCD_LAND(i, r) F.me[r] = F.e[r]; }
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_XCD_LAND(i, r) thermal_excess_cell(F, r, talus); }
 // meshes whose largest degree is <= 16 (jittered Fibonacci spheres: 10-11 at 10^4..10^6 cells, 13 at 10^7) keep the event
 // lists in registers (12- or 16-entry private arrays are promoted to VGPRs: 103 / 115 VGPRs, no scratch); larger degrees
 // use the LDS form
 template <int MAXIN>
 __global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply_reg(Fields F, float* out, double talus, double kThermal) {
-    WO_XCD_CELLS(r, F.N) {
+    WO_XCD_LAND(i, r) {
         double inShare[MAXIN], outShare[MAXIN]; int32_t inRank[MAXIN];
         out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, 1, outShare);
     }
@@ -505,7 +532,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out
     extern __shared__ __attribute__((aligned(16))) char smem[];          // [maxDeg][256] doubles, then [maxDeg][256] ints
     double* inShare = reinterpret_cast<double*>(smem) + threadIdx.x;
     int32_t* inRank = reinterpret_cast<int32_t*>(smem + (size_t)maxDeg * WO_BLOCK * sizeof(double)) + threadIdx.x;
-    WO_XCD_CELLS(r, F.N) out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, WO_BLOCK);
+    WO_XCD_LAND(i, r) out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, WO_BLOCK);
 }
 
 // ---------------------------------------------------------------- glacial -----------------------

@@ -376,6 +376,18 @@ static inline int next_side(int s) { return (s % 3 == 2) ? s - 2 : s + 1; }
 
 int mesh_csr(int V, int numSides, const int* triangles, const int* halfedges,
              int* adjOffset /*V+1*/, int* adjList /*numSides*/, int* adjTri /*numSides or null*/, std::string& err) {
+    if (V < 0 || numSides < 0 || numSides % 3 != 0) { err = "mesh_csr: bad sizes"; return 3; }
+    {   // the walks below index r_s[] with triangle corners and follow half-edges: refuse anything out of range first
+        std::atomic<int> oob{0};
+        parallel_ranges(numSides, [&](int64_t b, int64_t e, int) {
+            for (int64_t s = b; s < e; ++s) {
+                if (triangles[s] < 0 || triangles[s] >= V) { oob = 1; break; }
+                if (halfedges[s] < -1 || halfedges[s] >= numSides) { oob = 2; break; }
+            }
+        });
+        if (oob == 1) { err = "mesh_csr: triangle corner out of range"; return 3; }
+        if (oob == 2) { err = "mesh_csr: half-edge index out of range"; return 3; }
+    }
     std::vector<int> r_s(V, -1);
     for (int s = numSides - 1; s >= 0; --s) r_s[triangles[s]] = s;   // lowest side wins
     adjOffset[0] = 0;

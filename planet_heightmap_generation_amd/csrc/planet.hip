@@ -75,7 +75,7 @@ static void ensure_scratch(wo_planet* p) {
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -480,6 +480,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         }
     }
     const int32_t L = p->L;
+    const int gridL = xcd_grid(L);              // index-order passes over the ascending land list
+    if (hIters > 0 || tIters > 0) {
+        // ocean cells keep these values through the whole call: both elevation buffers hold them, and the per-ocean-cell
+        // constants of the land passes are written once
+        WO_HIP(hipMemcpyAsync(p->d_e2, p->d_e, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        launch(p, FAM_MISC, k_erode_ocean_init, blocks_for(N, 4096), WO_BLOCK, p->fields());
+    }
     clk.end();
 
     FloodRun floodRun;
@@ -557,7 +564,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (gNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             clk.begin("receivers");
-            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridN, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
+            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();
             clk.begin("flow");
             {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
@@ -580,10 +587,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
                            (const int32_t*)p->d_nj, out, outC, zeroC);
                 });
-            launch(p, FAM_FLOW_FINAL, k_flow_final, gridN, WO_BLOCK, F, p->d_flowCnt);
+            launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, F, p->d_flowCnt);
             clk.end();
             clk.begin("solve");
-            launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridN, WO_BLOCK, F);
+            launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
                 const int64_t r = run_solve_patches(p, F, K, m, dt);
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
@@ -591,7 +598,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
             }
-            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridN, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
+            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridL, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
             swap_elev(p);
             clk.end();
         }
@@ -599,14 +606,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         if (iter < tIters) {
             clk.begin("thermal");
             Fields F = p->fields();
-            if (!hNow) launch(p, FAM_THERMAL_EXCESS, k_masked_elev, gridN, WO_BLOCK, F);      // else written by k_solve_final
-            launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridN, WO_BLOCK, F, talus);
+            if (!hNow) launch(p, FAM_THERMAL_EXCESS, k_masked_elev, gridL, WO_BLOCK, F);      // else written by k_solve_final
+            launch(p, FAM_THERMAL_EXCESS, k_thermal_excess, gridL, WO_BLOCK, F, talus);
             if (p->maxDeg <= 12)
-                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<12>, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<12>, gridL, WO_BLOCK, F, p->d_e2, talus, kThermal);
             else if (p->maxDeg <= 16)
-                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<16>, gridN, WO_BLOCK, F, p->d_e2, talus, kThermal);
+                launch(p, FAM_THERMAL_APPLY, k_thermal_apply_reg<16>, gridL, WO_BLOCK, F, p->d_e2, talus, kThermal);
             else
-                launch_shmem(p, FAM_THERMAL_APPLY, k_thermal_apply, gridN, WO_BLOCK, (size_t)p->maxDeg * WO_BLOCK * 12, F, p->d_e2, talus, kThermal,
+                launch_shmem(p, FAM_THERMAL_APPLY, k_thermal_apply, gridL, WO_BLOCK, (size_t)p->maxDeg * WO_BLOCK * 12, F, p->d_e2, talus, kThermal,
                              (int32_t)p->maxDeg);
             swap_elev(p);
             clk.end();
@@ -1057,6 +1064,14 @@ int wo_project_coarse_plates(wo_planet* p, int32_t coarseRegions, const int32_t*
     if (coarseRegions < 1 || !coarseAdjOffset || !coarseAdjList || !coarse_xyz || !coarse_r_plate || !r_plate) {
         set_error("wo_project_coarse_plates: bad arguments"); return 1;
     }
+    {   // the kernel walks this CSR on the device: validate it the way wo_planet_create validates the planet's
+        if (coarseAdjOffset[0] != 0) { set_error("wo_project_coarse_plates: coarseAdjOffset[0] != 0"); return 1; }
+        for (int32_t r = 0; r < coarseRegions; ++r)
+            if (coarseAdjOffset[r + 1] < coarseAdjOffset[r]) { set_error("wo_project_coarse_plates: coarseAdjOffset is not monotone"); return 1; }
+        const int32_t Ec = coarseAdjOffset[coarseRegions];
+        for (int32_t i = 0; i < Ec; ++i)
+            if (coarseAdjList[i] < 0 || coarseAdjList[i] >= coarseRegions) { set_error("wo_project_coarse_plates: coarseAdjList entry out of range"); return 1; }
+    }
     int32_t *d_off = nullptr, *d_adj = nullptr, *d_plate = nullptr, *d_grid = nullptr, *d_out = nullptr; float* d_cxyz = nullptr;
     WO_TRY
     hipStream_t s = p->ctx->stream;
@@ -1111,6 +1126,7 @@ int wo_noise_eval(wo_ctx* ctx, double seed, int32_t kind, int32_t octaves, doubl
         dfree(d_in); dfree(d_out); dfree(d_t);
         return 0;
     } catch (const HipError& e) { dfree(d_in); dfree(d_out); dfree(d_t); set_error(std::string("wo_noise_eval: ") + e.msg); return 2; }
+      catch (const std::exception& e) { dfree(d_in); dfree(d_out); dfree(d_t); set_error(std::string("wo_noise_eval: ") + e.what()); return 3; }
 }
 
 // ---- measurement ----

@@ -22,15 +22,22 @@ export function defaultContext(device = 0) {
 }
 
 // One device-resident planet per mesh object (the worker keeps one mesh in W, js/planet-worker.js:277-292).
+// The planet is rebuilt when a later call brings a different r_xyz / neighborDist array for the same mesh object (or
+// the mesh's own arrays were replaced): the device copy must never silently disagree with what the caller passes.
 const planets = new WeakMap();
 export function planetFor(mesh, r_xyz, neighborDist) {
-    let p = planets.get(mesh);
-    if (!p) {
-        if (!r_xyz) throw new Error('orogen-hip: first call for this mesh needs r_xyz (call bindMesh(mesh, r_xyz, neighborDist))');
-        p = addon.planetCreate(defaultContext(), mesh.numRegions, mesh.adjOffset, mesh.adjList, r_xyz, neighborDist || null);
-        planets.set(mesh, p);
+    let ent = planets.get(mesh);
+    const stale = ent && ((r_xyz && ent.r_xyz !== r_xyz) || (neighborDist && ent.neighborDist && ent.neighborDist !== neighborDist) ||
+                          (neighborDist && !ent.neighborDist) || ent.adjList !== mesh.adjList || ent.numRegions !== mesh.numRegions);
+    if (!ent || stale) {
+        const xyz = r_xyz || (ent && ent.r_xyz);
+        if (!xyz) throw new Error('orogen-hip: first call for this mesh needs r_xyz (call bindMesh(mesh, r_xyz, neighborDist))');
+        const nd = neighborDist || (ent && ent.neighborDist) || null;
+        const p = addon.planetCreate(defaultContext(), mesh.numRegions, mesh.adjOffset, mesh.adjList, xyz, nd);
+        ent = { p, r_xyz: xyz, neighborDist: nd, adjList: mesh.adjList, numRegions: mesh.numRegions };
+        planets.set(mesh, ent);
     }
-    return p;
+    return ent.p;
 }
 export function bindMesh(mesh, r_xyz, neighborDist) { return planetFor(mesh, r_xyz, neighborDist); }
 

@@ -82,6 +82,7 @@ napi_value MeshCsr(napi_env env, napi_callback_info info) {                    /
     const int32_t V = a.i32(0);
     size_t ns, nh; int32_t* tri = (int32_t*)a.ta(1, napi_int32_array, &ns); int32_t* he = (int32_t*)a.ta(2, napi_int32_array, &nh);
     if (!a.ok) return nullptr;
+    if (ns != nh || V < 0) { napi_throw_range_error(env, nullptr, "meshCsr: triangles and halfedges must have the same length"); return nullptr; }
     void *o1, *o2, *o3;
     napi_value off = make_ta(env, napi_int32_array, (size_t)V + 1, 4, &o1);
     std::vector<int32_t> adj(ns), adjt(ns);
@@ -122,7 +123,13 @@ napi_value NoiseTables(napi_env env, napi_callback_info info) {                /
 
 // ---- handles ---------------------------------------------------------------------------------------
 void FinalizeCtx(napi_env, void* data, void*) { wo_ctx_destroy((wo_ctx*)data); }
-void FinalizePlanet(napi_env, void* data, void*) { wo_planet_destroy((wo_planet*)data); }
+// wo_planet_destroy uses the planet's context (device, stream), and the order in which the garbage collector finalizes
+// two externals is unspecified: the planet holds a strong reference to its context value and drops it only after the
+// planet itself is gone.
+void FinalizePlanet(napi_env env, void* data, void* hint) {
+    wo_planet_destroy((wo_planet*)data);
+    if (hint) napi_delete_reference(env, (napi_ref)hint);
+}
 
 napi_value DeviceCount(napi_env env, napi_callback_info) { napi_value v; napi_create_int32(env, wo_device_count(), &v); return v; }
 
@@ -143,20 +150,42 @@ napi_value PlanetCreate(napi_env env, napi_callback_info info) {               /
     float* xyz = (float*)a.ta(4, napi_float32_array, &nx); if (!a.ok) return nullptr;
     float* dist = a.has(5) ? (float*)a.ta(5, napi_float32_array, &nd) : nullptr; if (!a.ok) return nullptr;
     if (no != (size_t)V + 1 || nx != 3 * (size_t)V || (dist && nd != na)) { napi_throw_range_error(env, nullptr, "planetCreate: array sizes do not match numRegions"); return nullptr; }
+    if (!c) { napi_throw_type_error(env, nullptr, "planetCreate: expected a context handle"); return nullptr; }
     wo_planet* p = wo_planet_create(c, V, off, adj, xyz, dist);
     if (!p) return throw_wo(env, "planetCreate");
-    napi_value v; NAPI_OK(napi_create_external(env, p, FinalizePlanet, nullptr, &v));
+    napi_ref ctxRef = nullptr;
+    if (napi_create_reference(env, a.argv[0], 1, &ctxRef) != napi_ok) { wo_planet_destroy(p); napi_throw_error(env, nullptr, "planetCreate: cannot reference the context"); return nullptr; }
+    napi_value v;
+    if (napi_create_external(env, p, FinalizePlanet, ctxRef, &v) != napi_ok) { wo_planet_destroy(p); napi_delete_reference(env, ctxRef); napi_throw_error(env, nullptr, "planetCreate: cannot wrap the planet"); return nullptr; }
     return v;
+}
+
+// A planet argument must be a live handle, and every per-region array handed over with it must have exactly
+// mesh.numRegions entries: the C ABI copies numRegions elements in and out of the pointer it is given (the reference
+// would merely index `undefined`; here a short array would be an out-of-bounds read and write in the V8 heap).
+bool planet_ok(napi_env env, wo_planet* p) {
+    if (p) return true;
+    napi_throw_type_error(env, nullptr, "expected a planet handle");
+    return false;
+}
+bool regions_ok(napi_env env, wo_planet* p, size_t len, const char* what) {
+    if ((int64_t)len == (int64_t)wo_planet_num_regions(p)) return true;
+    std::string msg = std::string(what) + " length must equal mesh.numRegions";
+    napi_throw_range_error(env, nullptr, msg.c_str());
+    return false;
 }
 
 // ---- terrain-post, JS call surface (arrays mutated in place, return undefined) --------------------------
 #define PLANET_AND_ELEV()                                                                        \
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);                                      \
-    size_t ne; float* e = (float*)a.ta(1, napi_float32_array, &ne); if (!a.ok) return nullptr;
+    if (!planet_ok(env, p)) return nullptr;                                                      \
+    size_t ne; float* e = (float*)a.ta(1, napi_float32_array, &ne); if (!a.ok) return nullptr;   \
+    if (!regions_ok(env, p, ne, "r_elevation")) return nullptr;
 
 napi_value WarpTerrain(napi_env env, napi_callback_info info) {                // (planet, elev, seed, strength, hotspot|null)
     PLANET_AND_ELEV();
-    size_t nh; float* hot = a.has(4) ? (float*)a.ta(4, napi_float32_array, &nh) : nullptr; if (!a.ok) return nullptr;
+    size_t nh = 0; float* hot = a.has(4) ? (float*)a.ta(4, napi_float32_array, &nh) : nullptr; if (!a.ok) return nullptr;
+    if (hot && !regions_ok(env, p, nh, "r_hotspot")) return nullptr;
     if (wo_warp_terrain(p, e, a.num(2), a.num(3), hot)) return throw_wo(env, "warpTerrain");
     return nullptr;
 }
@@ -193,9 +222,11 @@ napi_value ErodeComposite(napi_env env, napi_callback_info info) {             /
 // ---- resident variants ("reapply": the field stays in HBM) ---------------------------------------------
 napi_value PlanetUpload(napi_env env, napi_callback_info info) {               // (planet, elev|null, isOcean|null)
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
-    size_t n1, n2;
+    if (!planet_ok(env, p)) return nullptr;
+    size_t n1 = 0, n2 = 0;
     float* e = a.has(1) ? (float*)a.ta(1, napi_float32_array, &n1) : nullptr; if (!a.ok) return nullptr;
     uint8_t* oc = a.has(2) ? (uint8_t*)a.ta(2, napi_uint8_array, &n2) : nullptr; if (!a.ok) return nullptr;
+    if ((e && !regions_ok(env, p, n1, "r_elevation")) || (oc && !regions_ok(env, p, n2, "r_isOcean"))) return nullptr;
     if (wo_planet_upload(p, e, oc)) return throw_wo(env, "planetUpload");
     return nullptr;
 }
@@ -206,7 +237,9 @@ napi_value PlanetDownload(napi_env env, napi_callback_info info) {             /
 }
 napi_value PlanetDownloadOcean(napi_env env, napi_callback_info info) {        // (planet, isOceanOut)
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
     size_t n; uint8_t* oc = (uint8_t*)a.ta(1, napi_uint8_array, &n); if (!a.ok) return nullptr;
+    if (!regions_ok(env, p, n, "r_isOcean")) return nullptr;
     if (wo_planet_download_ocean(p, oc)) return throw_wo(env, "planetDownloadOcean");
     return nullptr;
 }
@@ -217,7 +250,8 @@ napi_value PlanetUploadHotspot(napi_env env, napi_callback_info info) {
 }
 #define SIMPLE_PLANET_CALL(NAME, EXPR)                                                     \
     napi_value NAME(napi_env env, napi_callback_info info) {                               \
-        Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0); (void)p;                   \
+        Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);                            \
+        if (!planet_ok(env, p)) return nullptr;                                            \
         if (EXPR) return throw_wo(env, #NAME);                                             \
         return nullptr;                                                                    \
     }
@@ -235,6 +269,7 @@ SIMPLE_PLANET_CALL(TimerStart, wo_timer_start(p))
 
 napi_value TimerStopMs(napi_env env, napi_callback_info info) {
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
     double ms = 0;
     if (wo_timer_stop_ms(p, &ms)) return throw_wo(env, "timerStopMs");
     napi_value v; napi_create_double(env, ms, &v); return v;
@@ -243,6 +278,7 @@ napi_value TimerStopMs(napi_env env, napi_callback_info info) {
 // [{stage, ms}] of the last erodeComposite — same shape as the reference's _postTiming entries
 napi_value LastStageTiming(napi_env env, napi_callback_info info) {
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
     const char* names[64]; double ms[64]; int32_t n = 0;
     if (wo_last_stage_timing(p, 64, names, ms, &n)) return throw_wo(env, "lastStageTiming");
     napi_value arr; napi_create_array_with_length(env, n, &arr);
@@ -300,8 +336,10 @@ bool read_table(Args& a, napi_value obj, wo_plate_table* t) {
 
 napi_value AssignElevation(napi_env env, napi_callback_info info) {
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
     size_t n, ns, nsup = 0, np_, nm;
     int32_t* r_plate = (int32_t*)a.ta(1, napi_int32_array, &n); if (!a.ok) return nullptr;
+    if (!regions_ok(env, p, n, "r_plate")) return nullptr;
     wo_plate_table T{}, TS{};
     if (!read_table(a, a.argv[2], &T)) return nullptr;
     int32_t* seeds = (int32_t*)a.ta(3, napi_int32_array, &ns); if (!a.ok) return nullptr;
@@ -330,13 +368,13 @@ napi_value AssignElevation(napi_env env, napi_callback_info info) {
 // smoothField(planet, field Float32Array (in place), passes)
 napi_value SmoothField(napi_env env, napi_callback_info info) {
     PLANET_AND_ELEV();
-    if ((int32_t)ne != wo_planet_num_regions(p)) { napi_throw_range_error(env, nullptr, "field length must equal mesh.numRegions"); return nullptr; }
     if (wo_smooth_field(p, e, a.i32(2))) return throw_wo(env, "smoothField");
     return nullptr;
 }
 // projectCoarsePlates(planet, coarseAdjOffset, coarseAdjList, coarse_xyz, coarse_r_plate, seed, numPlates|null) -> Int32Array
 napi_value ProjectCoarsePlates(napi_env env, napi_callback_info info) {
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
     size_t no, na, nx, np_;
     int32_t* off = (int32_t*)a.ta(1, napi_int32_array, &no); if (!a.ok) return nullptr;
     int32_t* adj = (int32_t*)a.ta(2, napi_int32_array, &na); if (!a.ok) return nullptr;

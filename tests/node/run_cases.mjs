@@ -133,6 +133,9 @@ async function main() {
             try { TP.erodeComposite(mesh, e, xyz, oc, 1, 3e-4, 0.5, 1, 0, 1.16, 0.015, 0, 0); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
             try { TP.smoothElevation(mesh, new Float64Array(e.length), oc, 1, 0.5); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
             try { TP.smoothElevation(mesh, e, oc.subarray(1), 1, 0.5); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
+            // a field from another (smaller) mesh: must be refused, not read and written out of bounds
+            try { TP.applySoilCreep(mesh, e.subarray(1), oc.subarray(1), 1, 0.1); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
+            try { TP.warpTerrain(mesh, e, xyz, 1, 0.5, e.subarray(2)); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
             result.errors = errs;
             break;
         }
