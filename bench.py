@@ -10,8 +10,11 @@ priority-flood calls per step run on the host by design and are insi
 
   value = numRegions * 200 iterations * steps * n_gpus / wall / 1e6          [Mcells·iter/s, whole job]
 
-N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and the max-over-ranks timing),
-one independent planet per rank with seed = 1 + rank (BASELINE config 5, ensemble; no data-path collective)
+N > 1, default (--mode decomposed): one process per GPU, ONE planet (seed 1) eroded by all of them — landmass
+decomposition (planet_heightmap_generation_amd/decomposed.py: every rank erodes the full mesh with the other ranks'
+landmasses masked as ocean; one all-gather of the land elevations per step over RCCL; bit-identical to the
+unpartitioned run) -> value = cells x 200 x steps / wall of that one planet, "scaling": "strong".
+--mode ensemble: one independent planet per rank with seed = 1 + rank (BASELINE config 5; no data-path collective)
 -> "scaling": "weak".
 
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel family, HIP-event timed) and
@@ -142,6 +145,51 @@ def one_step(pl, seed, params, iters_scale=None):
     pl.apply_soil_creep_resident(*CREEP)
 
 
+class Decomposition:
+    """Per-rank state of the landmass decomposition: the plan is a function of the ocean mask (recomputed when it changes)."""
+
+    def __init__(self, mesh, pl, rank, world, dist, device):
+        self.mesh, self.pl, self.rank, self.world, self.dist, self.device = mesh, pl, rank, world, dist, device
+        self.plan, self.mask, self.true_oc, self.link, self.exchange_ms, self.plan_ms = None, None, None, None, 0.0, 0.0
+
+    def apply_mask(self):
+        from planet_heightmap_generation_amd import decomposed as D
+        oc = self.pl.download_ocean()
+        if self.true_oc is None or not np.array_equal(oc, self.true_oc):
+            t0 = time.perf_counter()
+            self.plan = D.plan_landmasses(self.mesh, oc, self.world)
+            self.mask = self.plan.rank_mask(self.rank, oc)
+            self.true_oc = oc
+            self.link = D.ResidentLandmass(self.plan, self.rank, self.pl)
+            self.plan_ms = (time.perf_counter() - t0) * 1e3
+        self.pl.upload(None, self.mask)
+
+    def merge(self):
+        t0 = time.perf_counter()
+        self.link.exchange(self.dist, self.device)
+        self.pl.sync()
+        self.exchange_ms = (time.perf_counter() - t0) * 1e3
+
+    def summary(self):
+        L = max(1, int(self.plan.load.sum()))
+        return dict(landmasses=self.plan.num_landmasses, largest_landmass_fraction=round(self.plan.largest / L, 4),
+                    land_cells_per_rank=[int(v) for v in self.plan.load], speedup_bound_by_cell_count=round(L / max(1, int(self.plan.load.max())), 2),
+                    plan_ms_when_mask_changes=round(self.plan_ms, 1), exchange_ms_last_step=round(self.exchange_ms, 2),
+                    exchange="all-gather of 4 B per land cell per step (RCCL); no exchange inside the iteration loop")
+
+
+def one_step_decomposed(pl, seed, params, dec: Decomposition):
+    p = dict(params)
+    pl.restore_state()
+    pl.warp_terrain_resident(seed, WARP)
+    pl.ocean_from_elevation()
+    dec.apply_mask()
+    pl.erode_composite_resident(p["hIters"], p["K"], p["m"], p["dt"], p["tIters"], p["talusSlope"], p["kThermal"], p["gIters"],
+                                p["glacialStrength"])
+    pl.apply_soil_creep_resident(*CREEP)
+    dec.merge()
+
+
 def ensemble_in_flight(TP, mesh, xyz, nd, seed, params, B: int, device: int):
     """Supplementary figure, NOT `value`: B independent planets in flight on one GPU (one host thread, context and
     stream per planet; BASELINE config 5 runs 8 planets per GPU).  The dependency-bound kernels of one planet leave
@@ -254,6 +302,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--in-flight", type=int, default=6, help="planets in flight for the supplementary ensemble figure (0 = skip)")
+    ap.add_argument("--mode", choices=("auto", "decomposed", "ensemble"), default="auto",
+                    help="N > 1: 'decomposed' = one planet over all GPUs by landmass (strong scaling, default), 'ensemble' = one planet per GPU (weak)")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -268,7 +318,8 @@ def main():
     params = dict(PARAMS)
     if args.iters != 200:
         params.update(hIters=args.iters, tIters=args.iters, gIters=min(10, max(1, args.iters // 20)))
-    seed = seed_for_rank(rank)
+    decomposed_mode = world > 1 and args.mode in ("auto", "decomposed")
+    seed = 1 if decomposed_mode else seed_for_rank(rank)
     mesh, xyz, nd, t_mesh = build_inputs(args.cells, seed)
     pl = TP.Planet(mesh, xyz, nd, device=local_rank)
     pl.synthetic_terrain(seed)
@@ -282,10 +333,12 @@ def main():
         torch.cuda.synchronize()
         pl.sync()
 
+    dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}") if decomposed_mode else None
+    step = (lambda: one_step_decomposed(pl, seed, params, dec)) if decomposed_mode else (lambda: one_step(pl, seed, params))
     cold_ms = None
     for w in range(args.warmup):
         tc = time.perf_counter()
-        one_step(pl, seed, params)
+        step()
         if w == 0:
             pl.sync()
             cold_ms = (time.perf_counter() - tc) * 1e3       # first step: mask-dependent tables, scratch allocation, launch-count prediction
@@ -293,7 +346,7 @@ def main():
     t0 = time.perf_counter()
     pl.timer_start()
     for _ in range(args.steps):
-        one_step(pl, seed, params)
+        step()
     ev_ms = pl.timer_stop_ms()
     barrier()
     wall = time.perf_counter() - t0
@@ -305,7 +358,7 @@ def main():
     iters = max(params["hIters"], params["tIters"], params["gIters"])
 
     roofline = None
-    if rank == 0 and not args.no_profile:
+    if rank == 0 and not args.no_profile and not decomposed_mode:
         # separate pass with every launch bracketed by HIP events on the planet's stream
         pl.profile_reset()
         pl.profile_enable(True)
@@ -356,15 +409,18 @@ def main():
         cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters, iters)
 
     if rank == 0:
-        value = whole_job_value(N, iters, args.steps, world, wall)
+        value = whole_job_value(N, iters, args.steps, 1 if decomposed_mode else world, wall)
         out = {
             "metric": "Mcells·iter/s, terrain-post erosion stack", "value": value, "unit": "Mcells·iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if decomposed_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 3: {N} cells (Fibonacci sphere {args.cells}+pole, jitter 0.75, seed 1+rank), "
                                    f"warp 0.75 + erodeComposite(h={params['hIters']},t={params['tIters']},g={params['gIters']}) + creep x3, "
-                                   f"one planet per GPU", "cells": N, "land_cells": L, "iterations": iters,
-                       "parallelism": f"ensemble x{world} (no collective on the data path)"},
+                                   + ("ONE planet over all GPUs" if decomposed_mode else "one planet per GPU"), "cells": N, "land_cells": L, "iterations": iters,
+                       "parallelism": (f"landmass decomposition x{world}: every rank erodes its share of the planet's landmasses, one all-gather of the land "
+                                       f"elevations per step over RCCL (bit-identical to the unpartitioned run)") if decomposed_mode
+                                      else f"ensemble x{world} (no collective on the data path)"},
+            "decomposition": dec.summary() if dec else None,
             "roofline": roofline, "cpu_baseline": cpu, "ensemble_in_flight": ensemble,
             "parity": crc, "cold_first_step_ms": cold_ms, "host_threads": host_thread_usage(),
             "hbm_d2d_copy_GBs_measured": round(d2d_bandwidth_GBs(local_rank), 1),

@@ -88,4 +88,17 @@ int wo_smooth_reconnect_plates(int32_t numRegions, const int32_t* adjOffset, con
     return 0;
 }
 
+int wo_land_components(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, const uint8_t* r_isOcean,
+                       int32_t* label) {
+    if (numRegions < 1 || !adjOffset || !adjList || !r_isOcean || !label) { wo::set_error("wo_land_components: bad arguments"); return 1; }
+    if (adjOffset[0] != 0) { wo::set_error("wo_land_components: adjOffset[0] != 0"); return 1; }
+    for (int32_t r = 0; r < numRegions; ++r) if (adjOffset[r + 1] < adjOffset[r]) { wo::set_error("wo_land_components: adjOffset is not monotone"); return 1; }
+    for (int32_t i = 0; i < adjOffset[numRegions]; ++i) if (adjList[i] < 0 || adjList[i] >= numRegions) { wo::set_error("wo_land_components: adjList entry out of range"); return 1; }
+    try {
+        wo::mesh_components(numRegions, adjOffset, adjList, [&](int32_t r) { return r_isOcean[r] == 0; }, [](int32_t, int32_t) { return true; }, label);
+        wo::parallel_ranges(numRegions, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) if (r_isOcean[r]) label[r] = -1; });
+    } catch (const std::exception& e) { wo::set_error(std::string("wo_land_components: ") + e.what()); return 3; }
+    return 0;
+}
+
 }  // extern "C"

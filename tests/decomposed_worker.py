@@ -1,0 +1,49 @@
+"""Worker for tests/test_decomposed.py: every rank erodes the planet with the other ranks' landmasses masked as ocean,
+then the land elevations are merged over gloo.  Engine 'oracle' (CPU tests: the oracle is the checker's engine here,
+never the product's) or 'planet' (the HIP path through the C ABI, resident field, on the GPU box)."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch.distributed as dist  # noqa: E402
+
+from planet_heightmap_generation_amd import decomposed  # noqa: E402
+
+
+def main():
+    work, engine = Path(sys.argv[1]), sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    z = np.load(work / "case.npz")
+    h, t, g = (int(v) for v in z["iters"])
+
+    class M:
+        adjOffset, adjList, numRegions = z["adjOffset"], z["adjList"], z["adjOffset"].size - 1
+    e, oc, xyz, nd = z["elevation"].copy(), z["isOcean"], z["xyz"], z["neighborDist"]
+    plan = decomposed.plan_landmasses(M, oc, world)
+    mask = plan.rank_mask(rank, oc)
+    if engine == "oracle":
+        from oracle import pyoracle as O
+        om = O.Mesh(M.adjOffset, M.adjList)
+        e = O.erode_composite(om, e, xyz, mask, h, 3e-4, 0.5, 1.0, t, 1.16, 0.015, g, 0.5, nd)
+        e = O.soil_creep(om, e, mask, 3, 0.1125)
+        decomposed.merge_land(plan, rank, e, dist)
+    else:
+        from planet_heightmap_generation_amd import terrain_post as TP
+        pl = TP.Planet(M, xyz, nd)
+        pl.upload(e, mask)
+        pl.erode_composite_resident(h, 3e-4, 0.5, 1.0, t, 1.16, 0.015, g, 0.5)
+        pl.apply_soil_creep_resident(3, 0.1125)
+        decomposed.ResidentLandmass(plan, rank, pl).exchange(dist)
+        e = pl.download()
+        pl.close()
+    np.save(work / f"result_{rank}.npy", e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

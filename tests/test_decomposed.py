@@ -1,0 +1,64 @@
+"""Landmass decomposition (planet_heightmap_generation_amd/decomposed.py): the erosion stack of ONE planet spread over
+several ranks equals the unpartitioned stack bit for bit.  Here on CPU with gloo and the oracle as every rank's engine
+(which checks the decomposition against the reference's semantics themselves); tests/test_gpu_parity.py repeats it with
+the HIP path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def make_case(oracle, cells, seed):
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(cells, 0.75, seed)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    e = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, seed), xyz, seed, 0.75)
+    return mesh, xyz, nd, e, (e <= 0).astype(np.uint8)
+
+
+def run_ranks(tmp_path, world, engine, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", WO_HOST_THREADS="2")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), str(REPO / "tests" / "decomposed_worker.py"), str(tmp_path), engine],
+                   check=True, env=env, timeout=900)
+    return [np.load(tmp_path / f"result_{r}.npy") for r in range(world)]
+
+
+def test_plan_is_a_partition_of_the_land(oracle):
+    from planet_heightmap_generation_amd import decomposed as D
+    mesh, xyz, nd, e, oc = make_case(oracle, 30000, 2)
+    label = D.land_components(mesh, oc)
+    assert ((label >= 0) == (oc == 0)).all()
+    rows = np.repeat(np.arange(mesh.numRegions), np.diff(mesh.adjOffset))
+    both = (oc[rows] == 0) & (oc[mesh.adjList] == 0)
+    assert (label[rows[both]] == label[mesh.adjList[both]]).all()             # an edge between land cells never leaves a landmass
+    assert (label[label >= 0] <= np.flatnonzero(label >= 0)).all()            # the label is the smallest id of the landmass
+    for world in (1, 2, 3, 8):
+        plan = D.plan_landmasses(mesh, oc, world)
+        assert (plan.owner[oc == 1] == -1).all() and (plan.owner[oc == 0] >= 0).all()
+        assert sum(c.size for c in plan.cells) == int((oc == 0).sum())
+        assert len(np.unique(np.concatenate(plan.cells))) == int((oc == 0).sum())
+        for k in range(world):                                               # a landmass is never split
+            assert len(np.intersect1d(label[plan.cells[k]], np.concatenate([label[plan.cells[j]] for j in range(world) if j != k] or [np.empty(0, np.int32)]))) == 0
+            m = plan.rank_mask(k, oc)
+            assert (m[plan.cells[k]] == 0).all() and int((m == 0).sum()) == plan.cells[k].size
+        assert plan.load.max() >= plan.largest
+
+
+@pytest.mark.parametrize("world,cells,seed,iters", [(2, 20000, 1, (8, 8, 3)), (3, 40000, 4, (12, 6, 0))])
+def test_partitioned_equals_unpartitioned_with_the_oracle(oracle, tmp_path, world, cells, seed, iters):
+    mesh, xyz, nd, e, oc = make_case(oracle, cells, seed)
+    np.savez(tmp_path / "case.npz", adjOffset=mesh.adjOffset, adjList=mesh.adjList, xyz=xyz, neighborDist=nd, elevation=e, isOcean=oc,
+             iters=np.array(iters))
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    h, t, g = iters
+    ref = oracle.erode_composite(om, e, xyz, oc, h, 3e-4, 0.5, 1.0, t, 1.16, 0.015, g, 0.5, nd)     # two floods: start and at 75 %
+    ref = oracle.soil_creep(om, ref, oc, 3, 0.1125)
+    outs = run_ranks(tmp_path, world, "oracle", 29600 + world)
+    for r, out in enumerate(outs):
+        assert np.array_equal(out, ref), (r, int((out != ref).sum()))
+    assert not np.array_equal(ref, e)

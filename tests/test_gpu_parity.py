@@ -406,3 +406,34 @@ def test_config3_checksum_of_the_benched_field(TP):
     assert abs(float(out.astype(np.float64).sum()) - gold["sum"]) < 1e-5 * out.size      # RMS-scale guard before the exact check
     assert int(zlib.crc32(out.tobytes())) == gold["crc32"], "field differs from the oracle's"
     pl.close()
+
+
+@pytest.mark.parametrize("world,cells,iters", [(3, 200000, (8, 8, 3)), (2, 1000000, (6, 6, 2))])
+def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells, iters):
+    """One planet eroded by `world` ranks (processes sharing this box's GPU, gloo for the merge): every rank runs the HIP
+    stack with the other ranks' landmasses masked as ocean, the land elevations are merged through the C ABI's pack /
+    unpack kernels.  Partitioned == unpartitioned, bit for bit, on every rank."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(cells, 0.75, 2)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    e = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, 2), xyz, 2, 0.75)
+    oc = (e <= 0).astype(np.uint8)
+    np.savez(tmp_path / "case.npz", adjOffset=mesh.adjOffset, adjList=mesh.adjList, xyz=xyz, neighborDist=nd, elevation=e, isOcean=oc, iters=np.array(iters))
+    h, t, g = iters
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.upload(e, oc)
+    pl.erode_composite_resident(h, 3e-4, 0.5, 1.0, t, 1.16, 0.015, g, 0.5)
+    pl.apply_soil_creep_resident(3, 0.1125)
+    ref = pl.download()
+    pl.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(29700 + world), str(REPO / "tests" / "decomposed_worker.py"), str(tmp_path), "planet"],
+                   check=True, env=env, timeout=1200)
+    for r in range(world):
+        out = np.load(tmp_path / f"result_{r}.npy")
+        assert np.array_equal(out, ref), (r, int((out != ref).sum()))
