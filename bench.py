@@ -302,6 +302,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--in-flight", type=int, default=6, help="planets in flight for the supplementary ensemble figure (0 = skip)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo + --share-gpu: rehearse the multi-rank path on a one-GPU box (not a measurement)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0")
     ap.add_argument("--mode", choices=("auto", "decomposed", "ensemble"), default="auto",
                     help="N > 1: 'decomposed' = one planet over all GPUs by landmass (strong scaling, default), 'ensemble' = one planet per GPU (weak)")
     args = ap.parse_args()
@@ -310,7 +312,9 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path)")
-    dist = dist_init(world, local_rank, "nccl")
+    if args.share_gpu:
+        local_rank = 0
+    dist = dist_init(world, local_rank, args.backend)
     torch.cuda.set_device(local_rank)
     numa_node = bind_to_gpu_numa_node(local_rank)
 
@@ -333,7 +337,7 @@ def main():
         torch.cuda.synchronize()
         pl.sync()
 
-    dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}") if decomposed_mode else None
+    dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}" if args.backend == "nccl" else None) if decomposed_mode else None
     step = (lambda: one_step_decomposed(pl, seed, params, dec)) if decomposed_mode else (lambda: one_step(pl, seed, params))
     cold_ms = None
     for w in range(args.warmup):
@@ -350,7 +354,7 @@ def main():
     ev_ms = pl.timer_stop_ms()
     barrier()
     wall = time.perf_counter() - t0
-    wall = dist_max(dist, wall, "cuda")
+    wall = dist_max(dist, wall, "cuda" if args.backend == "nccl" else "cpu")
     stats = pl.last_erode_stats()
     stages = pl.last_stage_timing()
     crc = parity_crc(pl, args.cells, max(params["hIters"], params["tIters"], params["gIters"])) if (rank == 0 and seed == 1) else None

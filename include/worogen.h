@@ -148,6 +148,23 @@ int wo_project_coarse_plates(wo_planet* p, int32_t coarseRegions, const int32_t*
 int wo_smooth_reconnect_plates(int32_t numRegions, const int32_t* adjOffset, const int32_t* adjList, int32_t* r_plate,
                                const int32_t* plateSeeds, int32_t numPlateSeeds, int32_t numPasses);
 
+/* diffuseOceanWarmth(mesh, r_oceanWarmth, r_isLand, r_plateContinentality, passes)   js/temperature.js:19-66
+ * Seeds the ocean cells with their warmth, then `passes` Jacobi sweeps of (self + neighbours) / (1 + degree); cells
+ * with plate continentality >= 0.95 keep their value.  r_oceanWarmth / r_plateContinentality may be NULL (the reference
+ * accepts null for both).  `out` (numRegions floats) receives the Float32Array the reference returns. */
+int wo_diffuse_ocean_warmth(wo_planet* planet, const float* r_oceanWarmth, const uint8_t* r_isLand, const float* r_plateContinentality,
+                            int32_t passes, float* out);
+/* computeWindConvergence(mesh, r_xyz, r_wind3dX, r_wind3dY, r_wind3dZ)               js/precipitation.js:18-52
+ * r_xyz is the planet's resident position array. */
+int wo_wind_convergence(wo_planet* planet, const float* r_wind3dX, const float* r_wind3dY, const float* r_wind3dZ, float* out);
+/* advectMoisture(mesh, r_xyz, r_heightKm, r_isLand, r_windE, r_windN, r_wind3dX, r_wind3dY, r_wind3dZ, r_oceanWarmth,
+ *                r_coastDistLand, maxHops, avgEdgeKm)                                js/precipitation.js:59-195
+ * Start moisture per cell, then maxHops upwind-gather sweeps (ping-pong buffers); avgEdgeKm is not read by the
+ * reference's body and is not part of this entry point.  r_oceanWarmth may be NULL. */
+int wo_advect_moisture(wo_planet* planet, const float* r_heightKm, const uint8_t* r_isLand, const float* r_windE, const float* r_windN,
+                       const float* r_wind3dX, const float* r_wind3dY, const float* r_wind3dZ, const float* r_oceanWarmth,
+                       const int32_t* r_coastDistLand, int32_t maxHops, float* out);
+
 /* ------------------------------------------------ landmass decomposition --------- */
 /* Connected components of the land cells (cells with r_isOcean == 0, joined along mesh edges).  label[r] = smallest
  * region id of r's landmass, -1 for ocean cells.  Every order-defined pass of erodeComposite (js/terrain-post.js:369-707:

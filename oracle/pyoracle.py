@@ -41,6 +41,9 @@ def lib() -> C.CDLL:
         L.wo_or_priority_flood_carve.argtypes = [_i32, _p, _p, _p, _p, _f64]
         L.wo_or_erode_composite.argtypes = [_i32, _p, _p, _p, _p, _p, _i32, _f64, _f64, _f64, _i32, _f64, _f64, _i32, _f64, _p]
         L.wo_or_smooth_field.argtypes = [_i32, _p, _p, _p, _i32]
+        L.wo_or_diffuse_ocean_warmth.argtypes = [_i32, _p, _p, _p, _p, _p, _i32, _p]
+        L.wo_or_wind_convergence.argtypes = [_i32, _p, _p, _p, _p, _p, _p, _p]
+        L.wo_or_advect_moisture.argtypes = [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p]
         L.wo_or_project_coarse_plates.argtypes = [_i32, _p, _i32, _p, _p, _p, _p, _f64, _i32, _p]
         L.wo_or_smooth_reconnect_plates.argtypes = [_i32, _p, _p, _p, _i32, _p, _i32]
         _lib = L
@@ -157,3 +160,31 @@ def smooth_field(mesh, field, passes) -> np.ndarray:
     f = _c(field, np.float32).copy()
     lib().wo_or_smooth_field(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(f), int(passes))
     return f
+
+
+def diffuse_ocean_warmth(mesh, r_oceanWarmth, r_isLand, r_plateContinentality, passes) -> np.ndarray:
+    """js/temperature.js:19 diffuseOceanWarmth -> Float32Array."""
+    out = np.empty(mesh.numRegions, np.float32)
+    w = None if r_oceanWarmth is None else _c(r_oceanWarmth, np.float32)
+    c = None if r_plateContinentality is None else _c(r_plateContinentality, np.float32)
+    lib().wo_or_diffuse_ocean_warmth(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(w), _ptr(_c(r_isLand, np.uint8)), _ptr(c), int(passes), _ptr(out))
+    return out
+
+
+def wind_convergence(mesh, r_xyz, wx, wy, wz) -> np.ndarray:
+    """js/precipitation.js:18 computeWindConvergence -> Float32Array."""
+    out = np.empty(mesh.numRegions, np.float32)
+    lib().wo_or_wind_convergence(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), _ptr(_c(r_xyz, np.float32)), _ptr(_c(wx, np.float32)),
+                                 _ptr(_c(wy, np.float32)), _ptr(_c(wz, np.float32)), _ptr(out))
+    return out
+
+
+def advect_moisture(mesh, r_xyz, r_heightKm, r_isLand, r_windE, r_windN, wx, wy, wz, r_oceanWarmth, r_coastDistLand, maxHops) -> np.ndarray:
+    """js/precipitation.js:59 advectMoisture -> Float32Array."""
+    out = np.empty(mesh.numRegions, np.float32)
+    w = None if r_oceanWarmth is None else _c(r_oceanWarmth, np.float32)
+    a = [_c(r_xyz, np.float32), _c(r_heightKm, np.float32), _c(r_isLand, np.uint8), _c(r_windE, np.float32), _c(r_windN, np.float32),
+         _c(wx, np.float32), _c(wy, np.float32), _c(wz, np.float32)]
+    cd = _c(r_coastDistLand, np.int32)
+    lib().wo_or_advect_moisture(mesh.numRegions, _ptr(mesh.adjOffset), _ptr(mesh.adjList), *[_ptr(x) for x in a], _ptr(w), _ptr(cd), int(maxHops), _ptr(out))
+    return out

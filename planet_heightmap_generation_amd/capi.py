@@ -55,6 +55,9 @@ SIGNATURES = {
     "wo_project_coarse_plates": (C.c_int, [_p, _c_i32, _p, _p, _p, _p, _c_f64, _c_i32, _p]),
     "wo_smooth_reconnect_plates": (C.c_int, [_c_i32, _p, _p, _p, _p, _c_i32, _c_i32]),
     "wo_land_components": (C.c_int, [_c_i32, _p, _p, _p, _p]),
+    "wo_diffuse_ocean_warmth": (C.c_int, [_p, _p, _p, _p, _c_i32, _p]),
+    "wo_wind_convergence": (C.c_int, [_p, _p, _p, _p, _p]),
+    "wo_advect_moisture": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _c_i32, _p]),
     "wo_planet_upload": (C.c_int, [_p, _p, _p]),
     "wo_planet_download": (C.c_int, [_p, _p]),
     "wo_planet_set_halo": (C.c_int, [_p, _p, _c_i32, _p, _c_i32]),

@@ -9,6 +9,7 @@
 
 #include "device.h"
 #include "plates_ops.h"
+#include "climate_ops.h"
 
 namespace wo {
 
@@ -133,6 +134,26 @@ __global__ __launch_bounds__(WO_BLOCK) void k_halo_unpack(float* e, const int32_
 // ---------------------------------------------------------------- climate-util smoothField ------
 __global__ __launch_bounds__(WO_BLOCK) void k_smooth_field(Fields F, const float* src, float* dst) {
     WO_XCD_CELLS(r, F.N) dst[r] = smooth_field_cell(F, src, r);
+}
+
+// ---------------------------------------------------------------- climate sweeps (js/temperature.js, js/precipitation.js) ----
+__global__ __launch_bounds__(WO_BLOCK) void k_warmth_seed(const float* warmth, const uint8_t* isLand, float* out, int32_t N) {
+    WO_GRID_STRIDE(r, N) out[r] = warmth_seed_cell(warmth, isLand, r);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_warmth_diffuse(Fields F, ClimateMesh M, const float* src, const float* cont, float* dst) {
+    WO_XCD_CELLS(r, F.N) dst[r] = warmth_diffuse_cell(M, src, cont, r);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_wind_convergence(Fields F, ClimateMesh M, const float* wx, const float* wy, const float* wz, float* out) {
+    WO_XCD_CELLS(r, F.N) out[r] = wind_convergence_cell(M, wx, wy, wz, r);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_moisture_seed(Fields F, ClimateMesh M, const uint8_t* isLand, const float* wx, const float* wy, const float* wz,
+                                                             const float* warmth, const int32_t* coastDist, float* out) {
+    WO_XCD_CELLS(r, F.N) out[r] = moisture_seed_cell(M, isLand, wx, wy, wz, warmth, coastDist, r);
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_moisture_advect(Fields F, ClimateMesh M, const float* src, const float* heightKm, const uint8_t* isLand,
+                                                               const float* windE, const float* windN, const float* wx, const float* wy, const float* wz,
+                                                               int32_t maxHops, double depletionBase, float* dst) {
+    WO_XCD_CELLS(r, F.N) dst[r] = moisture_advect_cell(M, src, heightKm, isLand, windE, windN, wx, wy, wz, maxHops, depletionBase, r);
 }
 
 // ---------------------------------------------------------------- plate projection --------------

@@ -25,7 +25,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -669,6 +669,23 @@ static void warp(wo_planet* p, double seed, double strength, bool useHot) {
 
 }  // namespace wo
 
+namespace wo {
+// device copies of per-region host arrays, freed on scope exit (also when a HIP call throws)
+struct DevBufs {
+    std::vector<void*> bufs;
+    ~DevBufs() { for (void* b : bufs) (void)hipFree(b); }
+    template <class T> T* up(const T* host, size_t n, hipStream_t s) {
+        if (!host) return nullptr;
+        void* d = nullptr; WO_HIP(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T))); bufs.push_back(d);
+        WO_HIP(hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+        return (T*)d;
+    }
+    template <class T> T* alloc(size_t n) { void* d = nullptr; WO_HIP(hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T))); bufs.push_back(d); return (T*)d; }
+};
+ClimateMesh climate_mesh(const wo_planet* p) { ClimateMesh M; M.N = p->N; M.off = p->d_off; M.adj = p->d_adj; M.xyz = p->d_xyz; return M; }
+}  // namespace wo
+
+
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -1053,6 +1070,66 @@ int wo_smooth_field(wo_planet* p, float* field, int32_t passes) {
         return 0;
     } catch (const HipError& e) { dfree(a); dfree(b); set_error(std::string("wo_smooth_field: ") + e.msg); return 2; }
       catch (const std::exception& e) { dfree(a); dfree(b); set_error(std::string("wo_smooth_field: ") + e.what()); return 3; }
+}
+
+// ---- climate sweeps on caller-owned fields (js/temperature.js:19-66, js/precipitation.js:18-52, :59-195) ----
+int wo_diffuse_ocean_warmth(wo_planet* p, const float* r_oceanWarmth, const uint8_t* r_isLand, const float* r_plateContinentality,
+                            int32_t passes, float* out) {
+    if (!check_planet(p, "wo_diffuse_ocean_warmth")) return 1;
+    if (!r_isLand || !out) { set_error("wo_diffuse_ocean_warmth: null pointer"); return 1; }
+    WO_TRY
+    hipStream_t s = p->ctx->stream; const size_t N = (size_t)p->N;
+    DevBufs B;
+    const float* w = B.up(r_oceanWarmth, N, s); const uint8_t* land = B.up(r_isLand, N, s); const float* cont = B.up(r_plateContinentality, N, s);
+    float* a = B.alloc<float>(N); float* b = B.alloc<float>(N);
+    launch(p, FAM_CLIMATE, k_warmth_seed, blocks_for(p->N, 4096), WO_BLOCK, w, land, a, p->N);
+    const Fields F = p->fields(); const ClimateMesh M = climate_mesh(p);
+    for (int32_t pass = 0; pass < passes; ++pass) { launch(p, FAM_CLIMATE, k_warmth_diffuse, xcd_grid(p->N), WO_BLOCK, F, M, (const float*)a, cont, b); std::swap(a, b); }
+    WO_HIP(hipMemcpyAsync(out, a, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    return 0;
+    WO_CATCH("wo_diffuse_ocean_warmth")
+}
+
+int wo_wind_convergence(wo_planet* p, const float* r_wind3dX, const float* r_wind3dY, const float* r_wind3dZ, float* out) {
+    if (!check_planet(p, "wo_wind_convergence")) return 1;
+    if (!r_wind3dX || !r_wind3dY || !r_wind3dZ || !out) { set_error("wo_wind_convergence: null pointer"); return 1; }
+    WO_TRY
+    hipStream_t s = p->ctx->stream; const size_t N = (size_t)p->N;
+    DevBufs B;
+    const float* wx = B.up(r_wind3dX, N, s); const float* wy = B.up(r_wind3dY, N, s); const float* wz = B.up(r_wind3dZ, N, s);
+    float* o = B.alloc<float>(N);
+    launch(p, FAM_CLIMATE, k_wind_convergence, xcd_grid(p->N), WO_BLOCK, p->fields(), climate_mesh(p), wx, wy, wz, o);
+    WO_HIP(hipMemcpyAsync(out, o, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    return 0;
+    WO_CATCH("wo_wind_convergence")
+}
+
+int wo_advect_moisture(wo_planet* p, const float* r_heightKm, const uint8_t* r_isLand, const float* r_windE, const float* r_windN,
+                       const float* r_wind3dX, const float* r_wind3dY, const float* r_wind3dZ, const float* r_oceanWarmth,
+                       const int32_t* r_coastDistLand, int32_t maxHops, float* out) {
+    if (!check_planet(p, "wo_advect_moisture")) return 1;
+    if (!r_heightKm || !r_isLand || !r_windE || !r_windN || !r_wind3dX || !r_wind3dY || !r_wind3dZ || !r_coastDistLand || !out) { set_error("wo_advect_moisture: null pointer"); return 1; }
+    if (maxHops < 1) { set_error("wo_advect_moisture: maxHops must be >= 1"); return 1; }
+    WO_TRY
+    hipStream_t s = p->ctx->stream; const size_t N = (size_t)p->N;
+    DevBufs B;
+    const float* hk = B.up(r_heightKm, N, s); const uint8_t* land = B.up(r_isLand, N, s); const float* we = B.up(r_windE, N, s); const float* wn = B.up(r_windN, N, s);
+    const float* wx = B.up(r_wind3dX, N, s); const float* wy = B.up(r_wind3dY, N, s); const float* wz = B.up(r_wind3dZ, N, s);
+    const float* w = B.up(r_oceanWarmth, N, s); const int32_t* cd = B.up(r_coastDistLand, N, s);
+    float* a = B.alloc<float>(N); float* b = B.alloc<float>(N);
+    const Fields F = p->fields(); const ClimateMesh M = climate_mesh(p);
+    const double depletionBase = 1 - std::pow(0.78, 1.0 / maxHops);                  // js/precipitation.js:123
+    launch(p, FAM_CLIMATE, k_moisture_seed, xcd_grid(p->N), WO_BLOCK, F, M, land, wx, wy, wz, w, cd, a);
+    for (int32_t it = 0; it < maxHops; ++it) {
+        launch(p, FAM_CLIMATE, k_moisture_advect, xcd_grid(p->N), WO_BLOCK, F, M, (const float*)a, hk, land, we, wn, wx, wy, wz, maxHops, depletionBase, b);
+        std::swap(a, b);
+    }
+    WO_HIP(hipMemcpyAsync(out, a, N * sizeof(float), hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    return 0;
+    WO_CATCH("wo_advect_moisture")
 }
 
 int32_t wo_planet_num_regions(const wo_planet* p) { return p ? p->N : 0; }

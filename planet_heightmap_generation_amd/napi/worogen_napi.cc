@@ -371,6 +371,65 @@ napi_value SmoothField(napi_env env, napi_callback_info info) {
     if (wo_smooth_field(p, e, a.i32(2))) return throw_wo(env, "smoothField");
     return nullptr;
 }
+// optional Float32Array / Uint8Array / Int32Array of numRegions entries (null / undefined -> nullptr)
+static void* opt_regions(Args& a, size_t i, napi_typedarray_type t, wo_planet* p, const char* what, bool required) {
+    if (!a.has(i)) { if (required) { napi_throw_type_error(a.env, nullptr, what); a.ok = false; } return nullptr; }
+    size_t n; void* d = a.ta(i, t, &n); if (!a.ok) return nullptr;
+    if (!regions_ok(a.env, p, n, what)) { a.ok = false; return nullptr; }
+    return d;
+}
+// diffuseOceanWarmth(planet, r_oceanWarmth|null, r_isLand, r_plateContinentality|null, passes) -> Float32Array
+napi_value DiffuseOceanWarmth(napi_env env, napi_callback_info info) {
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
+    float* w = (float*)opt_regions(a, 1, napi_float32_array, p, "r_oceanWarmth", false); if (!a.ok) return nullptr;
+    uint8_t* land = (uint8_t*)opt_regions(a, 2, napi_uint8_array, p, "r_isLand", true); if (!a.ok) return nullptr;
+    float* c = (float*)opt_regions(a, 3, napi_float32_array, p, "r_plateContinentality", false); if (!a.ok) return nullptr;
+    void* d; napi_value out = make_ta(env, napi_float32_array, (size_t)wo_planet_num_regions(p), 4, &d);
+    if (wo_diffuse_ocean_warmth(p, w, land, c, a.i32(4), (float*)d)) return throw_wo(env, "diffuseOceanWarmth");
+    return out;
+}
+// computeWindConvergence(planet, r_wind3dX, r_wind3dY, r_wind3dZ) -> Float32Array
+napi_value WindConvergence(napi_env env, napi_callback_info info) {
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
+    float* x = (float*)opt_regions(a, 1, napi_float32_array, p, "r_wind3dX", true); if (!a.ok) return nullptr;
+    float* y = (float*)opt_regions(a, 2, napi_float32_array, p, "r_wind3dY", true); if (!a.ok) return nullptr;
+    float* z = (float*)opt_regions(a, 3, napi_float32_array, p, "r_wind3dZ", true); if (!a.ok) return nullptr;
+    void* d; napi_value out = make_ta(env, napi_float32_array, (size_t)wo_planet_num_regions(p), 4, &d);
+    if (wo_wind_convergence(p, x, y, z, (float*)d)) return throw_wo(env, "computeWindConvergence");
+    return out;
+}
+// advectMoisture(planet, r_heightKm, r_isLand, r_windE, r_windN, r_wind3dX, r_wind3dY, r_wind3dZ, r_oceanWarmth|null, r_coastDistLand, maxHops) -> Float32Array
+napi_value AdvectMoisture(napi_env env, napi_callback_info info) {
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
+    float* hk = (float*)opt_regions(a, 1, napi_float32_array, p, "r_heightKm", true); if (!a.ok) return nullptr;
+    uint8_t* land = (uint8_t*)opt_regions(a, 2, napi_uint8_array, p, "r_isLand", true); if (!a.ok) return nullptr;
+    float* we = (float*)opt_regions(a, 3, napi_float32_array, p, "r_windE", true); if (!a.ok) return nullptr;
+    float* wn = (float*)opt_regions(a, 4, napi_float32_array, p, "r_windN", true); if (!a.ok) return nullptr;
+    float* x = (float*)opt_regions(a, 5, napi_float32_array, p, "r_wind3dX", true); if (!a.ok) return nullptr;
+    float* y = (float*)opt_regions(a, 6, napi_float32_array, p, "r_wind3dY", true); if (!a.ok) return nullptr;
+    float* z = (float*)opt_regions(a, 7, napi_float32_array, p, "r_wind3dZ", true); if (!a.ok) return nullptr;
+    float* w = (float*)opt_regions(a, 8, napi_float32_array, p, "r_oceanWarmth", false); if (!a.ok) return nullptr;
+    int32_t* cd = (int32_t*)opt_regions(a, 9, napi_int32_array, p, "r_coastDistLand", true); if (!a.ok) return nullptr;
+    void* d; napi_value out = make_ta(env, napi_float32_array, (size_t)wo_planet_num_regions(p), 4, &d);
+    if (wo_advect_moisture(p, hk, land, we, wn, x, y, z, w, cd, a.i32(10), (float*)d)) return throw_wo(env, "advectMoisture");
+    return out;
+}
+// landComponents(numRegions, adjOffset, adjList, r_isOcean) -> Int32Array (label = smallest id of the landmass, -1 for ocean)
+napi_value LandComponents(napi_env env, napi_callback_info info) {
+    Args a(env, info);
+    size_t no, na, nc;
+    int32_t* off = (int32_t*)a.ta(1, napi_int32_array, &no); if (!a.ok) return nullptr;
+    int32_t* adj = (int32_t*)a.ta(2, napi_int32_array, &na); if (!a.ok) return nullptr;
+    uint8_t* oc = (uint8_t*)a.ta(3, napi_uint8_array, &nc); if (!a.ok) return nullptr;
+    const int32_t n = a.i32(0);
+    if (n < 1 || (size_t)n + 1 != no || (size_t)n != nc) { napi_throw_range_error(env, nullptr, "mesh / r_isOcean length mismatch"); return nullptr; }
+    void* d; napi_value out = make_ta(env, napi_int32_array, (size_t)n, 4, &d);
+    if (wo_land_components(n, off, adj, oc, (int32_t*)d)) return throw_wo(env, "landComponents");
+    return out;
+}
 // projectCoarsePlates(planet, coarseAdjOffset, coarseAdjList, coarse_xyz, coarse_r_plate, seed, numPlates|null) -> Int32Array
 napi_value ProjectCoarsePlates(napi_env env, napi_callback_info info) {
     Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
@@ -416,6 +475,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"applySoilCreepResident", ApplySoilCreepResident}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
         {"lastStageTiming", LastStageTiming}, {"assignElevation", AssignElevation},
         {"projectCoarsePlates", ProjectCoarsePlates}, {"smoothField", SmoothField}, {"smoothAndReconnectPlates", SmoothAndReconnectPlates},
+        {"diffuseOceanWarmth", DiffuseOceanWarmth}, {"computeWindConvergence", WindConvergence}, {"advectMoisture", AdvectMoisture},
+        {"landComponents", LandComponents},
     };
     for (auto& f : fns) {
         napi_value v;

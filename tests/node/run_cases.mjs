@@ -127,6 +127,21 @@ async function main() {
             writeArr(j.out, fld);
             break;
         }
+        case 'climate_sweeps': {
+            const CS = await imp('climate-sweeps.js');
+            const rd = (k, T) => readArr(j.in[k], T);
+            const land = rd('isLand', Uint8Array), warmth = rd('oceanWarmth', Float32Array), cont = rd('plateContinentality', Float32Array);
+            const wx = rd('wind3dX', Float32Array), wy = rd('wind3dY', Float32Array), wz = rd('wind3dZ', Float32Array);
+            writeArr(j.out.diffuse, CS.diffuseOceanWarmth(mesh, warmth, land, cont, j.passes));
+            writeArr(j.out.diffuseNulls, CS.diffuseOceanWarmth(mesh, null, land, null, j.passesNulls));
+            writeArr(j.out.convergence, CS.computeWindConvergence(mesh, xyz, wx, wy, wz));
+            writeArr(j.out.advect, CS.advectMoisture(mesh, xyz, rd('heightKm', Float32Array), land, rd('windE', Float32Array), rd('windN', Float32Array),
+                wx, wy, wz, warmth, rd('coastDistLand', Int32Array), j.maxHops, 123.0));
+            const errs = [];
+            try { CS.computeWindConvergence(mesh, xyz, wx.subarray(1), wy, wz); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
+            result.climateErrors = errs;
+            break;
+        }
         case 'error_paths': {
             const errs = [];
             const e = readArr(j.elevation, Float32Array), oc = readArr(j.isOcean, Uint8Array);

@@ -67,6 +67,12 @@ def test_js_drop_in_matches_goldens(tmp_path):
     jobs.append({"op": "pipeline", "elevation": "e0.bin", "hotspot": "hot.bin", "params": params, "seed": 1, "out": "pipe.bin"})
     jobs.append({"op": "error_paths", "elevation": "e0.bin", "isOcean": "oc.bin"})
     jobs.append({"op": "smooth_field", "field": "e0.bin", "passes": 4, "out": "sf4.bin"})
+    from climate_common import SWEEP_CASES, sweep_inputs
+    I = sweep_inputs(g["adjOffset"], g["adjList"], g["xyz"], g["elevation0"])
+    for k, v in I.items():
+        v.tofile(tmp_path / f"cs_{k}.bin")
+    jobs.append({"op": "climate_sweeps", "in": {k: f"cs_{k}.bin" for k in I}, "passes": SWEEP_CASES["diffuse_passes"][-1], "passesNulls": SWEEP_CASES["diffuse_no_cont_passes"],
+                 "maxHops": SWEEP_CASES["advect_hops"][-1], "out": {"diffuse": "cs_d.bin", "diffuseNulls": "cs_dn.bin", "convergence": "cs_c.bin", "advect": "cs_a.bin"}})
     pts = load_golden("noise_seed78")["points"]
     pts.tofile(tmp_path / "pts.bin")
     jobs.append({"op": "noise_batch", "seed": 78, "kind": "ridgedFbm", "points": "pts.bin", "octaves": 3, "p0": 0.5, "p1": 0.5, "p2": 1.0, "out": "nb.bin"})
@@ -81,6 +87,11 @@ def test_js_drop_in_matches_goldens(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "nb.bin", np.float64), load_golden("noise_seed78")["ref_ridged3h"])
     assert res["errors"] == ["TypeError", "TypeError", "RangeError", "RangeError", "RangeError"]
     assert np.array_equal(np.fromfile(tmp_path / "sf4.bin", np.float32), load_golden("climate_N10000_s1")["ref_smoothField_4"])
+    cs = load_golden("climate_sweeps_N10000_s1")
+    for f, k in (("cs_d.bin", f"ref_diffuse_{SWEEP_CASES['diffuse_passes'][-1]}"), ("cs_dn.bin", "ref_diffuse_nulls"), ("cs_c.bin", "ref_convergence"),
+                 ("cs_a.bin", f"ref_advect_{SWEEP_CASES['advect_hops'][-1]}")):
+        assert np.array_equal(np.fromfile(tmp_path / f, np.float32), cs[k]), k
+    assert res["climateErrors"] == ["RangeError"]
     assert res["postTiming"][0].startswith("Terrain warp") and res["postTiming"][-1] == "Soil creep (3 iters)"
     # pipeline == the Python mirror's pipeline (same C ABI underneath)
     from planet_heightmap_generation_amd import terrain_post as TP
