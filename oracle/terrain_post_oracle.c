@@ -71,6 +71,9 @@ uint32_t wo_or_cell_noise_hash(int32_t r) {
  * MinHeap (js/terrain-post.js:12-47)
  * ---------------------------------------------------------------------------------------------- */
 typedef struct { int32_t* data; int32_t size; const float* key; } heap_t;
+#ifdef WO_ORACLE_TIE_BY_ID   /* research only: equal keys ordered by cell id (what the device flood's label order does) */
+#define HEAP_LT(h, a, b) ((h)->key[a] < (h)->key[b] || ((h)->key[a] == (h)->key[b] && (a) < (b)))
+#endif
 
 static void heap_push(heap_t* h, int32_t cell) {
     int32_t i = h->size++;
@@ -78,7 +81,9 @@ static void heap_push(heap_t* h, int32_t cell) {
     while (i > 0) {
         int32_t parent = (i - 1) >> 1;
         int32_t t;
-#ifdef WO_ORACLE_TIE_VARIANT    /* research only: a different (equally arbitrary) order among EQUAL keys, to measure how much the
+#ifdef WO_ORACLE_TIE_BY_ID
+        if (!HEAP_LT(h, h->data[i], h->data[parent])) break;
+#elif defined(WO_ORACLE_TIE_VARIANT)    /* research only: a different (equally arbitrary) order among EQUAL keys, to measure how much the
                                     result depends on the reference heap's tie mechanics */
         if (h->key[h->data[i]] > h->key[h->data[parent]]) break;
 #else
@@ -99,8 +104,13 @@ static int32_t heap_pop(heap_t* h) {
         for (;;) {
             int32_t smallest = i, t;
             const int32_t l = 2 * i + 1, r = 2 * i + 2;
+#ifdef WO_ORACLE_TIE_BY_ID
+            if (l < n && HEAP_LT(h, h->data[l], h->data[smallest])) smallest = l;
+            if (r < n && HEAP_LT(h, h->data[r], h->data[smallest])) smallest = r;
+#else
             if (l < n && h->key[h->data[l]] < h->key[h->data[smallest]]) smallest = l;
             if (r < n && h->key[h->data[r]] < h->key[h->data[smallest]]) smallest = r;
+#endif
             if (smallest == i) break;
             t = h->data[i]; h->data[i] = h->data[smallest]; h->data[smallest] = t;
             i = smallest;
