@@ -195,7 +195,8 @@ void blend_collision_layers(int32_t N, const CollisionHost& S, const CollisionHo
 
 // Everything between the collision kernels and the uplift kernel (js/elevation.js:249-631, 1059-1086, 1116-1261).
 void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const CollisionHost& S, const CollisionHost* P,
-                          ElevHostState& H, ElevParams& Q, std::vector<Dome>& domes) {
+                          ElevHostState& H, ElevParams& Q, std::vector<Dome>& domes,
+                          const std::function<void(const ElevParams&, int32_t, double)>& bfsOnDevice) {
     const int32_t N = M.N;
     const bool hasSuper = P != nullptr;
     const double SMALL_W = 0.05, SUPER_W = 0.95;
@@ -275,18 +276,6 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     for (int32_t r : ocean.items) stopAll[r] = 1;
 
     lap("reps+seeds");
-    // ---- five distance fields (:392-426), independent -> one host thread each ----
-    H.distMountain.resize(N); H.distOcean.resize(N); H.distCoastline.resize(N); H.distCoast.resize(N); H.distCoastLand.resize(N);
-    {
-        std::thread a([&]() { distance_field(M, stressMountain, ocean.in.data(), I.seed + 1, H.distMountain.data()); });
-        std::thread b([&]() { distance_field(M, ocean.items, coastline.in.data(), I.seed + 2, H.distOcean.data()); });
-        std::thread c([&]() { distance_field(M, coastline.items, stopAll.data(), I.seed + 3, H.distCoastline.data()); });
-        std::thread d([&]() { distance_field(M, coastSeeds.items, nullptr, I.seed + 4, H.distCoast.data()); });
-        distance_field(M, landCoastSeeds, H.isOcean.data(), I.seed + 5, H.distCoastLand.data());
-        a.join(); b.join(); c.join(); d.join();
-    }
-
-    lap("distance fields");
     // ---- scalars (:431-460) ----
     auto rnd = [](double x) { return std::floor(x + 0.5); };
     Q.N = N; Q.scaleFactor = scaleFactor; Q.noiseMag = I.noiseMag;
@@ -322,6 +311,22 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     const double maxStress = Q.maxStress;
 
     lap("scalars+pctl");
+    // the FIFO BFS fields do not depend on the distance fields: the product starts them on the device now and they run
+    // while the serial RNG-ordered walks below occupy the host threads
+    if (bfsOnDevice) bfsOnDevice(Q, maxCD, maxStress);
+    // ---- five distance fields (:392-426), independent -> one host thread each ----
+    H.distMountain.resize(N); H.distOcean.resize(N); H.distCoastline.resize(N); H.distCoast.resize(N); H.distCoastLand.resize(N);
+    {
+        std::thread a([&]() { distance_field(M, stressMountain, ocean.in.data(), I.seed + 1, H.distMountain.data()); });
+        std::thread b([&]() { distance_field(M, ocean.items, coastline.in.data(), I.seed + 2, H.distOcean.data()); });
+        std::thread c([&]() { distance_field(M, coastline.items, stopAll.data(), I.seed + 3, H.distCoastline.data()); });
+        std::thread d([&]() { distance_field(M, coastSeeds.items, nullptr, I.seed + 4, H.distCoast.data()); });
+        distance_field(M, landCoastSeeds, H.isOcean.data(), I.seed + 5, H.distCoastLand.data());
+        a.join(); b.join(); c.join(); d.join();
+    }
+
+    lap("distance fields");
+    if (!bfsOnDevice) {
     // ---- BFS fields (independent of each other) ----
     H.dBdry.assign(N, (float)(maxCD + 1)); H.coastStressMax.assign(N, 0.f); H.coastSubductMax.assign(N, 0.f); H.coastConvergent.assign(N, 0);
     H.riftDist.assign(N, INFINITY); H.ridgeDist.assign(N, INFINITY); H.fractureDist.assign(N, INFINITY);
@@ -398,6 +403,7 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
         std::thread a(coast_bfs), b(rift_bfs), c(ridge_bfs), d(fracture_bfs), e(backarc_bfs);
         arc_bfs();
         a.join(); b.join(); c.join(); d.join(); e.join();
+    }
     }
 
     lap("bfs fields");

@@ -17,6 +17,7 @@
 #include "elevation_kernels.h"
 #include "kernels_impl.h"
 #include "flood_kernels.h"
+#include "elevation_bfs.h"
 #include "noise.h"
 
 namespace wo {
@@ -1357,19 +1358,92 @@ static void assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plat
     I.superPlate = hasSuper ? r_superPlate : nullptr; if (hasSuper) I.superPlates = host_table(*superPlates);
     I.seed = seed; I.spread = spread; I.noiseMag = noiseMag; I.hsNoise3 = NoiseTab{hs3.data(), hs3.data() + 512};
     ElevHostState H; ElevParams Q{}; std::vector<Dome> domes;
-    elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
-    lap("Stress, sets, distance fields, BFS fields (host)");
-
-    // per-cell pass
+    // The FIFO BFS fields (js/elevation.js:464-631, 1059-1086) run on the device (elevation_bfs.h), started from inside the
+    // host stage as soon as their inputs exist and overlapped with the serial RNG-ordered distance fields on the host.
     ElevFields F{};
     F.xyz = p->d_xyz; F.plate = d_plate;
     std::vector<void*> tmp;
     auto up = [&](auto& v) { auto* d = upload_vec(v, s); tmp.push_back((void*)d); return d; };
-    F.isOcean = up(H.isOcean); F.stress = up(H.stress); F.subduct = up(H.subduct); F.btype = up(H.btype);
+    auto dev = [&](auto* proto, size_t n) { using T = std::remove_pointer_t<decltype(proto)>; T* d = dalloc<T>(n); tmp.push_back((void*)d); return d; };
+    float *b_dBdry = nullptr, *b_csm = nullptr, *b_cssm = nullptr, *b_rift = nullptr, *b_ridge = nullptr, *b_frac = nullptr, *b_ba = nullptr, *b_bas = nullptr, *b_arc = nullptr, *b_arcs = nullptr;
+    uint8_t* b_conv = nullptr;
+    std::vector<std::vector<int32_t>> bfsSeeds;             // host seed lists stay alive until the stream has consumed them
+    bfsSeeds.reserve(8);
+    auto bfs_on_device = [&](const ElevParams& Qs, int32_t maxCD, double maxStress) {
+        const size_t n = (size_t)N;
+        F.isOcean = up(H.isOcean); F.stress = up(H.stress); F.subduct = up(H.subduct); F.btype = up(H.btype);
+        const uint8_t* d_both = up(H.bothOcean); const uint8_t* d_has = up(H.hasOcean); (void)d_both; (void)d_has;
+        b_dBdry = dev((float*)nullptr, n); b_csm = dev((float*)nullptr, n); b_cssm = dev((float*)nullptr, n); b_conv = dev((uint8_t*)nullptr, n);
+        b_rift = dev((float*)nullptr, n); b_ridge = dev((float*)nullptr, n); b_frac = dev((float*)nullptr, n);
+        b_ba = dev((float*)nullptr, n); b_bas = dev((float*)nullptr, n); b_arc = dev((float*)nullptr, n); b_arcs = dev((float*)nullptr, n);
+        int32_t* listA = dev((int32_t*)nullptr, n); int32_t* listB = dev((int32_t*)nullptr, n);
+        int32_t* cnt = dev((int32_t*)nullptr, n); int32_t* base = dev((int32_t*)nullptr, n); int32_t* pushPos = dev((int32_t*)nullptr, n);
+        unsigned long long* attrKey = dev((unsigned long long*)nullptr, n);
+        int32_t* counters = dev((int32_t*)nullptr, 4);
+        BfsCtx B{N, p->d_off, p->d_adj, F.isOcean, d_plate};
+        // seed lists in ascending id (the reference's scan order), built on the host from the arrays the host stage holds
+        auto seeds_of = [&](auto pred) {
+            std::vector<std::vector<int32_t>> part(host_threads() + 1);
+            parallel_ranges(N, [&](int64_t b, int64_t e, int t) { for (int64_t r = b; r < e; ++r) if (pred((int32_t)r)) part[t].push_back((int32_t)r); });
+            std::vector<int32_t> q; for (auto& v : part) q.insert(q.end(), v.begin(), v.end());
+            return q;
+        };
+        const int grid = 512;
+        auto run_field = [&](int32_t mode, std::vector<int32_t>&& seedList, float* dist, float init, float* a0, float* a1, uint8_t* a2, int32_t maxDist) {
+            bfsSeeds.push_back(std::move(seedList));
+            const std::vector<int32_t>& seeds = bfsSeeds.back();
+            const bool carry = a0 != nullptr;
+            launch(p, FAM_ELEV_COLLISION, k_bfs_init, blocks_for(N, 4096), WO_BLOCK, dist, init, a0, a1, a2, carry ? pushPos : (int32_t*)nullptr,
+                   mode == BFS_COAST ? attrKey : (unsigned long long*)nullptr, N);
+            const int32_t ns = (int32_t)seeds.size();
+            if (ns == 0) return;
+            WO_HIP(hipMemcpyAsync(listA, seeds.data(), (size_t)ns * 4, hipMemcpyHostToDevice, s));       // no host wait: the device keeps running the previous field
+            hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, counters, ns, 0, 0, 0);
+            launch(p, FAM_ELEV_COLLISION, k_bfs_seed, blocks_for(ns, 1024), WO_BLOCK, mode, (const int32_t*)listA, ns, dist, a0, a1, a2,
+                   (const float*)F.stress, (const float*)F.subduct, (const int8_t*)F.btype, maxStress);
+            int32_t* cur = listA; int32_t* nxt = listB;
+            for (int32_t level = 1; level <= maxDist; ++level) {
+                int32_t* cc = counters + ((level - 1) % 3); int32_t* nc = counters + (level % 3); int32_t* zc = counters + ((level + 1) % 3);
+                if (!carry) {
+                    launch(p, FAM_ELEV_COLLISION, k_bfs_plain, grid, WO_BLOCK, B, mode, dist, (const int32_t*)cur, (const int32_t*)cc, nxt, nc, zc, level);
+                } else {
+                    launch(p, FAM_ELEV_COLLISION, k_bfs_push, grid, WO_BLOCK, B, mode, (const float*)dist, (const int32_t*)cur, (const int32_t*)cc, pushPos,
+                           mode == BFS_COAST ? attrKey : (unsigned long long*)nullptr, (const float*)a0, level);
+                    launch(p, FAM_ELEV_COLLISION, k_bfs_count, grid, WO_BLOCK, B, (const float*)dist, (const int32_t*)cur, (const int32_t*)cc, (const int32_t*)pushPos, cnt, level);
+                    launch(p, FAM_ELEV_COLLISION, k_bfs_scan, 1, 1024, (const int32_t*)cnt, (const int32_t*)cc, base, nc);
+                    launch(p, FAM_ELEV_COLLISION, k_bfs_assign, grid, WO_BLOCK, B, mode, dist, (const int32_t*)cur, (const int32_t*)cc, (const int32_t*)pushPos,
+                           (const unsigned long long*)(mode == BFS_COAST ? attrKey : nullptr), (const int32_t*)base, nxt, a0, a1, a2, level);
+                }
+                std::swap(cur, nxt);
+            }
+        };
+        const uint8_t* oc = H.isOcean.data(); const int8_t* bt = H.btype.data(); const uint8_t* both = H.bothOcean.data(); const uint8_t* has = H.hasOcean.data();
+        const float* sub = H.subduct.data();
+        run_field(BFS_COAST, seeds_of([&](int32_t r) { const uint8_t o = oc[r]; for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni) if (oc[M.adj[ni]] != o) return true; return false; }),
+                  b_dBdry, (float)(maxCD + 1), b_csm, b_cssm, b_conv, maxCD);
+        run_field(BFS_RIFT, seeds_of([&](int32_t r) { return bt[r] == 2 && !has[r]; }), b_rift, INFINITY, nullptr, nullptr, nullptr, Qs.riftHalfWidth);
+        run_field(BFS_RIDGE, seeds_of([&](int32_t r) { return bt[r] == 2 && both[r]; }), b_ridge, INFINITY, nullptr, nullptr, nullptr, Qs.ridgeHalfWidth);
+        run_field(BFS_FRACTURE, seeds_of([&](int32_t r) { return bt[r] == 3 && both[r]; }), b_frac, INFINITY, nullptr, nullptr, nullptr, Qs.fractureHalfWidth);
+        run_field(BFS_BACKARC, seeds_of([&](int32_t r) { return bt[r] == 1 && has[r] && (double)sub[r] < 0.50; }), b_ba, INFINITY, b_bas, nullptr, nullptr, Qs.baEnd);
+        run_field(BFS_ARC, seeds_of([&](int32_t r) { return bt[r] == 1 && both[r] && (double)sub[r] < 0.45; }), b_arc, (float)(Qs.maxArcDist + 1), b_arcs, nullptr, nullptr, Qs.maxArcDist);
+    };
+    static const bool bfsHost = std::getenv("WO_ELEV_BFS_HOST") != nullptr;      // the host walks instead (reference for the device version)
+    if (bfsHost) elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
+    else elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes, bfs_on_device);
+    lap(bfsHost ? "Stress, sets, distance fields, BFS fields (host)" : "Stress, sets, distance fields (host) || BFS fields (device)");
+
+    // per-cell pass
+    if (bfsHost) {
+        F.isOcean = up(H.isOcean); F.stress = up(H.stress); F.subduct = up(H.subduct); F.btype = up(H.btype);
+        F.dBdry = up(H.dBdry); F.coastStressMax = up(H.coastStressMax); F.coastSubductMax = up(H.coastSubductMax);
+        F.coastConvergent = up(H.coastConvergent); F.riftDist = up(H.riftDist); F.ridgeDist = up(H.ridgeDist); F.fractureDist = up(H.fractureDist);
+        F.backArcDist = up(H.backArcDist); F.backArcStress = up(H.backArcStress); F.arcDist = up(H.arcDist); F.arcStress = up(H.arcStress);
+    } else {
+        F.dBdry = b_dBdry; F.coastStressMax = b_csm; F.coastSubductMax = b_cssm; F.coastConvergent = b_conv; F.riftDist = b_rift; F.ridgeDist = b_ridge;
+        F.fractureDist = b_frac; F.backArcDist = b_ba; F.backArcStress = b_bas; F.arcDist = b_arc; F.arcStress = b_arcs;
+    }
     F.distMountain = up(H.distMountain); F.distOcean = up(H.distOcean); F.distCoastline = up(H.distCoastline); F.distCoast = up(H.distCoast);
-    F.distCoastLand = up(H.distCoastLand); F.dBdry = up(H.dBdry); F.coastStressMax = up(H.coastStressMax); F.coastSubductMax = up(H.coastSubductMax);
-    F.coastConvergent = up(H.coastConvergent); F.riftDist = up(H.riftDist); F.ridgeDist = up(H.ridgeDist); F.fractureDist = up(H.fractureDist);
-    F.backArcDist = up(H.backArcDist); F.backArcStress = up(H.backArcStress); F.arcDist = up(H.arcDist); F.arcStress = up(H.arcStress);
+    F.distCoastLand = up(H.distCoastLand);
     F.elev = p->d_e;
     float* d_dl = nullptr;
     if (debugLayers) { d_dl = dalloc<float>((size_t)DL_COUNT * N); WO_HIP(hipMemsetAsync(d_dl, 0, (size_t)DL_COUNT * N * 4, s)); }

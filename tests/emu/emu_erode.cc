@@ -388,6 +388,96 @@ extern "C" void emu_set_lookahead(int v) { LOOKAHEAD = v; }
 
 // ---- assignElevation: the same host stage as the product plus the per-cell bodies driven on the CPU ----
 #include "../../planet_heightmap_generation_amd/csrc/elevation_host.h"
+#include "../../planet_heightmap_generation_amd/csrc/elevation_bfs.h"
+
+// The device formulation of the FIFO BFS fields (elevation_bfs.h), kernel by kernel with the atomics executed one
+// "thread" at a time: level-synchronous claims for the fields without attributes; push / count / scan / assign per level
+// for the fields that carry the attributes of the first (coast: the strongest) parent in queue order.
+static int g_bfsDevice = 0;
+extern "C" void emu_set_bfs_device(int v) { g_bfsDevice = v; }
+namespace {
+void emu_bfs_fields(const ElevMesh& M, const ElevInputs& I, ElevHostState& H, const ElevParams& Q, int32_t maxCD, double maxStress) {
+    const int32_t N = M.N;
+    BfsCtx B{N, M.off, M.adj, H.isOcean.data(), I.plate};
+    std::vector<int32_t> cur, nxt, pushPos(N), cnt, base;
+    std::vector<unsigned long long> attrKey(N);
+    auto run = [&](int32_t mode, std::vector<int32_t> seeds, float* dist, float init, float* a0, float* a1, uint8_t* a2, int32_t maxDist) {
+        const bool carry = a0 != nullptr;
+        for (int32_t r = 0; r < N; ++r) { dist[r] = init; if (a0) a0[r] = 0; if (a1) a1[r] = 0; if (a2) a2[r] = 0; pushPos[r] = 0x7fffffff; attrKey[r] = 0; }    // k_bfs_init
+        for (int32_t r : seeds) {                                                                                              // k_bfs_seed
+            dist[r] = 0.0f;
+            if (mode == BFS_COAST || mode == BFS_BACKARC || mode == BFS_ARC) { const double v = (double)H.stress[r] / maxStress; a0[r] = (float)(v < 1.0 ? v : 1.0); }
+            if (mode == BFS_COAST) { a1[r] = H.subduct[r]; a2[r] = H.btype[r] == 1 ? 1 : 0; }
+        }
+        cur = seeds;
+        for (int32_t level = 1; level <= maxDist; ++level) {
+            const float nd = (float)level;
+            nxt.clear();
+            if (!carry) {                                                                                                      // k_bfs_plain
+                const uint32_t ndBits = bfs_f32_bits(nd);
+                for (size_t i = cur.size(); i-- > 0;) {              // any order: take the reverse of the queue on purpose
+                    const int32_t r = cur[i];
+                    for (int32_t j = M.off[r]; j < M.off[r + 1]; ++j) {
+                        const int32_t nr = M.adj[j];
+                        if (nd < dist[nr] && bfs_admit(B, mode, nr, r)) {
+                            const uint32_t old = bfs_f32_bits(dist[nr]);
+                            if (old > ndBits) { dist[nr] = nd; nxt.push_back(nr); }
+                        }
+                    }
+                }
+            } else {
+                const int32_t n = (int32_t)cur.size();
+                for (int32_t i = n - 1; i >= 0; --i) {                                                                         // k_bfs_push (reverse order: atomics commute)
+                    const int32_t r = cur[i];
+                    for (int32_t j = M.off[r]; j < M.off[r + 1]; ++j) {
+                        const int32_t nr = M.adj[j];
+                        if (!(nd <= dist[nr])) continue;
+                        if (!bfs_admit(B, mode, nr, r)) continue;
+                        if (nd < dist[nr] && i < pushPos[nr]) pushPos[nr] = i;
+                        if (mode == BFS_COAST) { const unsigned long long k = bfs_attr_key(a0[r], i); if (k > attrKey[nr]) attrKey[nr] = k; }
+                    }
+                }
+                cnt.assign(n, 0); base.assign(n, 0);
+                for (int32_t i = 0; i < n; ++i) {                                                                              // k_bfs_count
+                    const int32_t r = cur[i];
+                    for (int32_t j = M.off[r]; j < M.off[r + 1]; ++j) { const int32_t nr = M.adj[j]; if (pushPos[nr] == i && nd < dist[nr]) ++cnt[i]; }
+                }
+                int32_t run = 0; for (int32_t i = 0; i < n; ++i) { base[i] = run; run += cnt[i]; }                             // k_bfs_scan
+                nxt.assign(run, -1);
+                for (int32_t i = n - 1; i >= 0; --i) {                                                                         // k_bfs_assign
+                    const int32_t r = cur[i];
+                    int32_t k = base[i];
+                    for (int32_t j = M.off[r]; j < M.off[r + 1]; ++j) {
+                        const int32_t nr = M.adj[j];
+                        if (!(pushPos[nr] == i && nd < dist[nr])) continue;
+                        nxt[k++] = nr;
+                        int32_t src = r;
+                        if (mode == BFS_COAST) src = cur[bfs_attr_pos(attrKey[nr])];
+                        if (a0) a0[nr] = a0[src];
+                        if (a1) a1[nr] = a1[src];
+                        if (a2) a2[nr] = a2[src];
+                        dist[nr] = nd;
+                    }
+                }
+            }
+            cur.swap(nxt);
+        }
+    };
+    auto seeds_of = [&](auto pred) { std::vector<int32_t> q; for (int32_t r = 0; r < N; ++r) if (pred(r)) q.push_back(r); return q; };
+    H.dBdry.resize(N); H.coastStressMax.resize(N); H.coastSubductMax.resize(N); H.coastConvergent.resize(N);
+    H.riftDist.resize(N); H.ridgeDist.resize(N); H.fractureDist.resize(N); H.backArcDist.resize(N); H.backArcStress.resize(N); H.arcDist.resize(N); H.arcStress.resize(N);
+    const uint8_t* oc = H.isOcean.data();
+    run(BFS_COAST, seeds_of([&](int32_t r) { for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni) if (oc[M.adj[ni]] != oc[r]) return true; return false; }),
+        H.dBdry.data(), (float)(maxCD + 1), H.coastStressMax.data(), H.coastSubductMax.data(), H.coastConvergent.data(), maxCD);
+    run(BFS_RIFT, seeds_of([&](int32_t r) { return H.btype[r] == 2 && !H.hasOcean[r]; }), H.riftDist.data(), INFINITY, nullptr, nullptr, nullptr, Q.riftHalfWidth);
+    run(BFS_RIDGE, seeds_of([&](int32_t r) { return H.btype[r] == 2 && H.bothOcean[r]; }), H.ridgeDist.data(), INFINITY, nullptr, nullptr, nullptr, Q.ridgeHalfWidth);
+    run(BFS_FRACTURE, seeds_of([&](int32_t r) { return H.btype[r] == 3 && H.bothOcean[r]; }), H.fractureDist.data(), INFINITY, nullptr, nullptr, nullptr, Q.fractureHalfWidth);
+    run(BFS_BACKARC, seeds_of([&](int32_t r) { return H.btype[r] == 1 && H.hasOcean[r] && (double)H.subduct[r] < 0.50; }), H.backArcDist.data(), INFINITY,
+        H.backArcStress.data(), nullptr, nullptr, Q.baEnd);
+    run(BFS_ARC, seeds_of([&](int32_t r) { return H.btype[r] == 1 && H.bothOcean[r] && (double)H.subduct[r] < 0.45; }), H.arcDist.data(), (float)(Q.maxArcDist + 1),
+        H.arcStress.data(), nullptr, nullptr, Q.maxArcDist);
+}
+}  // namespace
 
 extern "C" int emu_assign_elevation(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const int32_t* r_plate,
                                     int32_t numIds, const uint8_t* hasVec, const double* pole, const double* omega, const uint8_t* isOcean,
@@ -418,7 +508,10 @@ extern "C" int emu_assign_elevation(int32_t N, const int32_t* off, const int32_t
     I.plate = r_plate; I.plates = T; I.plateSeeds = plateSeeds; I.numPlateSeeds = nSeeds; I.superPlate = r_super; I.superPlates = TS;
     I.seed = seed; I.spread = spread; I.noiseMag = noiseMag; I.hsNoise3 = NoiseTab{hs3.data(), hs3.data() + 512};
     ElevHostState H; ElevParams Q{}; std::vector<Dome> domes;
-    elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
+    if (g_bfsDevice)
+        elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes,
+                             [&](const ElevParams& Qs, int32_t maxCD, double maxStress) { emu_bfs_fields(M, I, H, Qs, maxCD, maxStress); });
+    else elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
     ElevFields F{};
     F.xyz = xyz; F.plate = r_plate; F.isOcean = H.isOcean.data(); F.stress = H.stress.data(); F.subduct = H.subduct.data(); F.btype = H.btype.data();
     F.distMountain = H.distMountain.data(); F.distOcean = H.distOcean.data(); F.distCoastline = H.distCoastline.data(); F.distCoast = H.distCoast.data();

@@ -21,6 +21,7 @@ def emu():
     L = C.CDLL(str(EMU_DIR / "_build" / "libemu.so"))
     p, i32, f64 = C.c_void_p, C.c_int32, C.c_double
     L.emu_assign_elevation.argtypes = [i32, p, p, p, p, i32, p, p, p, p, p, p, i32, p, i32, p, p, p, p, p, p, p, f64, f64, f64, p, p, p, p, p, p, p]
+    L.emu_set_bfs_device.argtypes = [i32]
     L.emu_pair_intensity.restype = f64
     L.emu_pair_intensity.argtypes = [i32, i32]
     return L
@@ -37,8 +38,12 @@ def test_pair_intensity_known_answers(emu):
     assert emu.emu_pair_intensity(0, 1) == 1.0529
 
 
+@pytest.mark.parametrize("bfs_device", [0, 1])
 @pytest.mark.parametrize("name", CASES)
-def test_assign_elevation_bit_exact(emu, oracle, name):
+def test_assign_elevation_bit_exact(emu, oracle, name, bfs_device):
+    """bfs_device = 1: the FIFO BFS fields by the device formulation (csrc/elevation_bfs.h: level-synchronous claims, and
+    push / count / scan / assign levels that rebuild the reference's queue order for the carried attributes)."""
+    emu.emu_set_bfs_device(bfs_device)
     g = load_golden(name)
     meta, *_ = load_case(g)
     N, seed = meta["numRegions"], meta["seed"]
@@ -78,8 +83,10 @@ def large_case():
     return g, meta, mesh, xyz, nd, crc
 
 
-def test_assign_elevation_large_bit_exact(emu, oracle):
+@pytest.mark.parametrize("bfs_device", [0, 1])
+def test_assign_elevation_large_bit_exact(emu, oracle, bfs_device):
     """numRegions > 200 000: the reference switches to 2 warp octaves and scales reaches / pass counts (js/elevation.js)."""
+    emu.emu_set_bfs_device(bfs_device)
     g, meta, mesh, xyz, nd, crc = large_case()
     N, seed = meta["numRegions"], meta["seed"]
     n, has, pole, om, oc, de = dense_table(g["plateSeeds"], g["plateVec"], g["plateDensity"], g["plateIsOcean"])
