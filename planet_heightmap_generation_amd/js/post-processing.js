@@ -6,14 +6,20 @@ import { performance } from 'perf_hooks';
 import addon, { planetFor } from './native.js';
 
 export function runPostProcessing(mesh, r_xyz, r_elevation, params, neighborDist, seed, r_hotspot) {
-    const { smoothing, glacialErosion, hydraulicErosion, thermalErosion, ridgeSharpening, terrainWarp } = params;
-    const timing = [];
     const p = planetFor(mesh, r_xyz, neighborDist);
-    const N = mesh.numRegions;
-    const timed = (stage, fn) => { const t0 = performance.now(); fn(); addon.planetSync(p); timing.push({ stage, ms: performance.now() - t0 }); };
-
     addon.planetUpload(p, r_elevation, null);
     if (r_hotspot) addon.planetUploadHotspot(p, r_hotspot);
+    return runPostProcessingResident(p, mesh.numRegions, r_elevation, params, seed, !!r_hotspot);
+}
+
+// The same on a field that is ALREADY resident in HBM (the worker's "reapply": js/planet-worker.js:341-440 restores the
+// pre-erosion field on the device and calls this; nothing is uploaded).  r_elevation receives the result.
+export function runPostProcessingResident(p, N, r_elevation, params, seed, useHotspot) {
+    const { smoothing, glacialErosion, hydraulicErosion, thermalErosion, ridgeSharpening, terrainWarp } = params;
+    const timing = [];
+    const r_hotspot = useHotspot;
+    const timed = (stage, fn) => { const t0 = performance.now(); fn(); addon.planetSync(p); timing.push({ stage, ms: performance.now() - t0 }); };
+
     if (terrainWarp > 0) {
         timed(`Terrain warp (strength=${terrainWarp.toFixed(2)})`, () => addon.warpTerrainResident(p, seed, terrainWarp, r_hotspot ? 1 : 0));
     }

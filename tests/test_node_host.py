@@ -155,3 +155,54 @@ def test_js_project_coarse_plates(tmp_path):
                          "coarseRegions": c["cmesh"].numRegions, "coff": "coff.bin", "cadj": "cadj.bin", "cxyz": "cxyz.bin", "cplate": "cplate.bin",
                          "seed": c["meta"]["seed"], "P": c["meta"]["P"], "out": "rp.bin"}])
     assert np.array_equal(np.fromfile(tmp_path / "rp.bin", np.int32), c["projected"])
+
+
+@pytest.mark.gpu
+def test_worker_threads_counterpart(tmp_path):
+    """planet_heightmap_generation_amd/js/planet-worker.js: the reference worker's retained state + `reapply` message
+    (js/planet-worker.js:277-292, 341-440, 944-954) as a Node worker thread.  The reapply result equals the direct
+    pipeline bit for bit, repeats exactly from the retained (device-resident) pre-erosion field, and errors / progress
+    messages have the reference's shapes."""
+    g = load_golden("post_N10000_s1")
+    m = load_golden("mesh_N10000_s1")
+    for k, arr in (("tri", m["triangles"]), ("off", g["adjOffset"]), ("adj", g["adjList"]), ("xyz", g["xyz"]), ("nd", g["neighborDist"]), ("e0", g["elevation0"]),
+                   ("hot", g["hotspot"])):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"{k}.bin")
+    params = dict(terrainWarp=0.75, smoothing=0.10, glacialErosion=0.5, hydraulicErosion=0.5, thermalErosion=0.1, ridgeSharpening=0.5)
+    params2 = dict(terrainWarp=0.3, smoothing=0.0, glacialErosion=0.0, hydraulicErosion=0.8, thermalErosion=0.4, ridgeSharpening=0.0)
+    job = dict(numRegions=int(g["numRegions"]), adjOffset="off.bin", adjList="adj.bin", triangles="tri.bin", xyz="xyz.bin", neighborDist="nd.bin",
+               elevation="e0.bin", hotspot="hot.bin", seed=1, params=params, params2=params2)
+    (tmp_path / "worker_job.json").write_text(json.dumps(job))
+    r = subprocess.run([NODE, "--no-warnings", str(REPO / "tests" / "node" / "run_worker.mjs"), str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads((tmp_path / "worker_result.json").read_text())
+    assert res["beforeRetain"] == {"type": "error", "message": "No retained state for reapply"}
+    assert res["unknown"] == {"type": "error", "message": "Unknown command: frobnicate"}
+    assert res["hostStage"]["type"] == "error" and "generate" in res["hostStage"]["message"]
+    assert res["retained"] == {"type": "retained", "numRegions": int(g["numRegions"])}
+    f = res["first"]
+    assert f["type"] == "reapplyDone" and f["skipClimate"] is True and f["n"] == int(g["numRegions"]) and f["nt"] == m["triangles"].size // 3
+    assert {"r_elevation", "t_elevation", "erosionDelta", "_reapplyTiming", "_postTiming", "skipClimate", "type"} <= set(f["keys"])
+    assert f["timingKeys"] == sorted(["clone", "postProcessing", "wind", "ocean", "precipitation", "temperature", "triangleElevations", "workerTotal"])
+    assert f["postTiming"][0].startswith("Terrain warp") and f["postTiming"][-1] == "Soil creep (3 iters)"
+    assert [p["pct"] for p in res["progress"][:3]] == [0, 20, 70] and res["progress"][0]["label"].startswith("Reapplying terrain")
+    # reapply == the direct pipeline on the same inputs, bit for bit; the triangle elevations and the delta belong to it
+    from planet_heightmap_generation_amd import sphere_mesh as S, terrain_post as TP
+
+    class _M:
+        adjOffset, adjList, numRegions = g["adjOffset"], g["adjList"], int(g["numRegions"])
+    pl = TP.Planet(_M, g["xyz"], g["neighborDist"])
+    e = g["elevation0"].copy()
+    oc, delta = TP.run_post_processing(pl, e, params, 1.0, g["hotspot"])
+    e1 = np.fromfile(tmp_path / "w_elev1.bin", np.float32)
+    assert np.array_equal(e1, e)
+    assert np.array_equal(np.fromfile(tmp_path / "w_delta1.bin", np.float32), delta)
+    tri = np.fromfile(tmp_path / "w_tri1.bin", np.float32)
+    t = m["triangles"].reshape(-1, 3)
+    assert np.allclose(tri, (e1[t[:, 0]].astype(np.float64) + e1[t[:, 1]] + e1[t[:, 2]]) / 3, atol=1e-6)
+    e2 = g["elevation0"].copy()
+    TP.run_post_processing(pl, e2, params2, 1.0, g["hotspot"])
+    assert np.array_equal(np.fromfile(tmp_path / "w_elev2.bin", np.float32), e2) and not np.array_equal(e2, e)
+    assert np.array_equal(np.fromfile(tmp_path / "w_elev3.bin", np.float32), e)          # back to the first sliders: same field again
+    assert res["disposed"] == {"type": "disposed"} and res["afterDispose"]["message"] == "No retained state for reapply"
+    pl.close()
