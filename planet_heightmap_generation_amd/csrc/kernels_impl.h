@@ -417,28 +417,19 @@ constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;
 // alone, which tasks are certainly still blocked: a task is if its remembered blocker is an external granule that is
 // not there yet, or a patch-local task that is itself certainly blocked (chains settle by polling LDS).  Only the
 // other tasks load their 48-byte records and look at all three predecessors.
-// Cross-patch hand-off inside a launch.  A granule is one aligned 64-bit word {value, tag}; it is published with an
-// agent-scope store and read with an agent-scope load (sc1: served coherently past the per-CU L1 and the per-XCD L2),
-// so a workgroup may consume what another workgroup produced EARLIER IN THE SAME LAUNCH instead of waiting for the
-// next kernel boundary: the results do not depend on the schedule (single-assignment dataflow), only the number of
-// launches does.  After a visit a workgroup whose remaining tasks wait on external granules polls those for a bounded
-// number of rounds and visits again when one has arrived (`revisits` / `waitSpins`); the bound keeps every
-// workgroup finite, so workgroups that are not resident yet always get their turn (no deadlock by construction).
-__device__ inline unsigned long long granule_load(const Granule* g) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void granule_store(Granule* g, unsigned long long w) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(g), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (Tried in round 2 and measured slower, not kept: publishing / reading the granules with agent-scope 64-bit accesses so that
+// a workgroup consumes what another one produced earlier in the SAME launch, plus bounded in-launch revisits.  Launches per
+// iteration fell from 60 to 6-27 but the pass took 670 ms instead of 575 ms per 200 iterations at 10 M cells: it is bound by
+// the visits themselves (every wave of every active patch pays a chain of dependent loads), not by kernel boundaries, and
+// the sc1 accesses are dearer than cached ones.  DESIGN.md section 5.)
 __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int32_t L, int32_t launchTag,
-                                                                   int32_t* patchPending, int32_t* totalPending, double K, double m, double dt,
-                                                                   int32_t revisits, int32_t waitSpins) {
+                                                                   int32_t* patchPending, int32_t* totalPending, double K, double m, double dt) {
     __shared__ Granule s_out[2 * WO_PATCH];
     __shared__ int32_t s_st[WO_PATCH];                      // 0 unsettled, 1 certainly blocked, 2 candidate or done
     __shared__ int32_t s_left;
     const int p = blockIdx.x, tid = threadIdx.x;
     if (patchPending[p] == 0) return;                       // block-uniform
-    Granule* G = reinterpret_cast<Granule*>(F.out);
+    const Granule* G = reinterpret_cast<const Granule*>(F.out);
     const int32_t s = p * WO_PATCH + tid;                   // store index = patch slot
     const int32_t base = 2 * p * WO_PATCH;                  // first granule of this patch
     const bool have = s < L;
@@ -446,103 +437,84 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
     if (have) mine = F.out[s];
     bool done = !have || mine.self.tag != 0;
     auto is_local = [&](int32_t g) { return (uint32_t)(g - base) < (uint32_t)(2 * WO_PATCH); };
-    auto ext_ready = [&](int32_t g, double& v) {            // external granule produced (in an earlier launch or earlier in this one)?
-        const unsigned long long w = granule_load(G + g);
-        if ((int32_t)(w >> 32) == 0) return false;
-        v = __uint_as_float((uint32_t)w); return true;
+    auto ext_ready = [&](int32_t g, double& v) {            // external granule produced in an earlier launch?
+        const Granule q = G[g];
+        if (q.tag == 0 || q.tag >= launchTag) return false;
+        v = q.v; return true;
     };
-    auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
-    const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
-    volatile int32_t* vst = s_st;
-    volatile unsigned long long* vs = reinterpret_cast<volatile unsigned long long*>(s_out);
-    int32_t extBlocker = -1;                                // external granule this task was last seen waiting for
-    for (int visit = 0;; ++visit) {
-        // ---- settle the remembered blockers
-        int32_t st = 2, waitOn = -1;
-        extBlocker = -1;
-        if (!done) {
-            const int32_t b = F.blk[s];
-            if (b >= 0) {
-                if (is_local(b)) { st = 0; waitOn = (b - base) >> 1; }
-                else { double unused; if (ext_ready(b, unused)) st = 2; else { st = 1; extBlocker = b; } }
-            }
-        }
-        s_st[tid] = st;
-        if (tid == 0) s_left = 0;
-        __syncthreads();
-        for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
-            if (st == 0) { const int32_t w = vst[waitOn]; if (w != 0) { st = w; vst[tid] = w; } }
-        }
-        // ---- candidates load their record and check the external predecessors
-        SolveTask T;
-        double er = 0, et = 0, et2 = 0, factor = 0;
-        bool unresolved = !done && st == 2;
-        if (__syncthreads_or(unresolved)) {
-            if (unresolved) {
-                T = F.task[s];
-                er = T.e0r; et = T.e0t; et2 = T.e0t2;
-                int32_t fail = -1;
-                if (T.predSelf >= 0 && !is_local(T.predSelf) && !ext_ready(T.predSelf, er)) fail = T.predSelf;
-                if (T.predT >= 0 && !is_local(T.predT) && !ext_ready(T.predT, et)) fail = T.predT;
-                if (T.predT2 >= 0 && !is_local(T.predT2) && !ext_ready(T.predT2, et2)) fail = T.predT2;
-                if (fail >= 0) { F.blk[s] = fail; extBlocker = fail; unresolved = false; }
-                else factor = solve_factor(T, K, m, dt);
-            }
-            Granule a = mine.self, b2 = mine.dep;
-            if (!done) { a.v = 0; b2.v = 0; a.tag = unresolved ? 0 : -1; b2.tag = a.tag; }
-            s_out[2 * tid] = a; s_out[2 * tid + 1] = b2;
-            __syncthreads();
-            // ---- run: poll the patch-local predecessors.  A granule is one aligned 64-bit LDS word {value, tag}: it is
-            // published and read with single 64-bit accesses, so no fence sits on the chain and a poll is one LDS round trip.
-            for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(unresolved); ++spin) {
-                if (spin && WO_PATCH_SLEEP) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
-                if (!unresolved) continue;
-                int32_t open = 0, fail = -1;
-                double a2 = er, b3 = et, c = et2;
-                auto rd = [&](int32_t g, double& v) {
-                    if (g < 0 || !is_local(g)) return;
-                    const unsigned long long w = vs[g - base];
-                    const int32_t tg = (int32_t)(w >> 32);
-                    if (tg < 0) fail = g;
-                    else if (tg == 0) open = 1;
-                    else v = __uint_as_float((uint32_t)w);
-                };
-                rd(T.predSelf, a2); rd(T.predT, b3); rd(T.predT2, c);
-                if (fail >= 0) {
-                    vs[2 * tid] = BLOCKED; vs[2 * tid + 1] = BLOCKED;
-                    F.blk[s] = fail;
-                    unresolved = false;
-                } else if (!open) {
-                    const SolveOut o = solve_apply(T, factor, a2, b3, c, launchTag);
-                    vs[2 * tid] = pack(o.self); vs[2 * tid + 1] = pack(o.dep);      // local consumers first ...
-                    granule_store(G + 2 * s, pack(o.self));                         // ... then the other workgroups
-                    granule_store(G + 2 * s + 1, pack(o.dep));
-                    mine = o;
-                    unresolved = false; done = true;
-                }
-            }
-        }
-        // block total of the still-pending tasks
-        if (!done) atomicAdd(&s_left, 1);
-        __syncthreads();
-        const int32_t left = s_left;
-        if (left == 0 || visit >= revisits) {
-            if (tid == 0) { patchPending[p] = left; if (left) atomicAdd(totalPending, left); }
-            return;
-        }
-        // ---- something is left: wait a bounded time for one of the external granules the tasks are parked on
-        bool arrived = false;
-        for (int w = 0; w < waitSpins; ++w) {
-            bool mineArrived = false;
-            if (!done && extBlocker >= 0) { double unused; mineArrived = ext_ready(extBlocker, unused); }
-            if (__syncthreads_or(mineArrived)) { arrived = true; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (!arrived) {
-            if (tid == 0) { patchPending[p] = left; atomicAdd(totalPending, left); }
-            return;
+    // ---- settle the remembered blockers
+    int32_t st = 2, waitOn = -1;
+    if (!done) {
+        const int32_t b = F.blk[s];
+        if (b >= 0) {
+            if (is_local(b)) { st = 0; waitOn = (b - base) >> 1; }
+            else { double unused; st = ext_ready(b, unused) ? 2 : 1; }
         }
     }
+    s_st[tid] = st;
+    if (tid == 0) s_left = 0;
+    __syncthreads();
+    volatile int32_t* vst = s_st;
+    for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
+        if (st == 0) { const int32_t w = vst[waitOn]; if (w != 0) { st = w; vst[tid] = w; } }
+    }
+    // ---- candidates load their record and check the external predecessors
+    SolveTask T;
+    double er = 0, et = 0, et2 = 0, factor = 0;
+    bool unresolved = !done && st == 2;
+    if (!__syncthreads_or(unresolved)) {                    // nothing can move in this patch: same pending count as before
+        if (tid == 0) atomicAdd(totalPending, patchPending[p]);
+        return;
+    }
+    if (unresolved) {
+        T = F.task[s];
+        er = T.e0r; et = T.e0t; et2 = T.e0t2;
+        int32_t fail = -1;
+        if (T.predSelf >= 0 && !is_local(T.predSelf) && !ext_ready(T.predSelf, er)) fail = T.predSelf;
+        if (T.predT >= 0 && !is_local(T.predT) && !ext_ready(T.predT, et)) fail = T.predT;
+        if (T.predT2 >= 0 && !is_local(T.predT2) && !ext_ready(T.predT2, et2)) fail = T.predT2;
+        if (fail >= 0) { F.blk[s] = fail; unresolved = false; }
+        else factor = solve_factor(T, K, m, dt);
+    }
+    if (!done && !unresolved) { mine.self.tag = -1; mine.dep.tag = -1; }
+    s_out[2 * tid] = mine.self; s_out[2 * tid + 1] = mine.dep;
+    __syncthreads();
+    // ---- run: poll the patch-local predecessors.  A granule is one aligned 64-bit LDS word {value, tag}: it is published
+    // and read with single 64-bit accesses, so no fence sits on the chain (a workgroup fence would also wait for the
+    // global store of the result, hundreds of cycles per chain step) and a poll is one LDS round trip, not two.
+    volatile unsigned long long* vs = reinterpret_cast<volatile unsigned long long*>(s_out);
+    auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
+    const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
+    for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(unresolved); ++spin) {
+        // a wave that only waits should not compete for issue slots with the waves that carry a chain
+        if (spin && WO_PATCH_SLEEP) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
+        if (!unresolved) continue;
+        int32_t open = 0, fail = -1;
+        double a = er, b = et, c = et2;
+        auto rd = [&](int32_t g, double& v) {
+            if (g < 0 || !is_local(g)) return;
+            const unsigned long long w = vs[g - base];
+            const int32_t tg = (int32_t)(w >> 32);
+            if (tg < 0) fail = g;
+            else if (tg == 0) open = 1;
+            else v = __uint_as_float((uint32_t)w);
+        };
+        rd(T.predSelf, a); rd(T.predT, b); rd(T.predT2, c);
+        if (fail >= 0) {
+            vs[2 * tid] = BLOCKED; vs[2 * tid + 1] = BLOCKED;
+            F.blk[s] = fail;
+            unresolved = false;
+        } else if (!open) {
+            const SolveOut o = solve_apply(T, factor, a, b, c, launchTag);
+            vs[2 * tid] = pack(o.self); vs[2 * tid + 1] = pack(o.dep);      // consumers first ...
+            F.out[s] = o;                                                   // ... the global copy is for later launches
+            unresolved = false; done = true;
+        }
+    }
+    // block total of the still-pending tasks
+    if (!done) atomicAdd(&s_left, 1);
+    __syncthreads();
+    if (tid == 0) { const int32_t left = s_left; patchPending[p] = left; if (left) atomicAdd(totalPending, left); }
 }
 
 __global__ __launch_bounds__(WO_BLOCK) void k_slot_scatter(const int32_t* patchOrder, int32_t* slotOf, int32_t L) {

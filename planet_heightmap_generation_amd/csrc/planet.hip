@@ -232,8 +232,6 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
     const int np = p->numPatches;
     launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, 1, (int32_t)np);
     // one pending-total slot per launch, cleared once per pass (a memset per launch was 13.6 k fill kernels per step)
-    static const int32_t revisits = [] { const char* e = std::getenv("WO_PATCH_REVISITS"); return e ? std::atoi(e) : 2; }();
-    static const int32_t waitSpins = [] { const char* e = std::getenv("WO_PATCH_WAIT"); return e ? std::atoi(e) : 8; }();
     int32_t* tot = p->d_patchTotals;
     WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
     int64_t launches = 0;
@@ -243,7 +241,7 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         const int burst = (tag == 1) ? std::max<int>(1, (int)p->lastPatchLaunches - 1) : 3;
         for (int b = 0; b < burst; ++b, ++tag) {
             if (tag % WO_PATCH_TOTAL_SLOTS == 0) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: slots are free again (stream order)
-            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt, revisits, waitSpins);
+            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt);
             ++launches;
         }
         if (read_count(p, tot + ((tag - 1) % WO_PATCH_TOTAL_SLOTS)) == 0) break;

@@ -15,7 +15,10 @@ landmasses are inert ocean cells to it), and after the stack the ranks exchange 
 once (all-gather of 4 B per land cell: RCCL between GPUs, gloo in the CPU tests).  The result is bit-identical to the
 unpartitioned run (tests/test_decomposed.py with the oracle as the per-rank engine, tests/test_gpu_parity.py with the
 HIP path).  Landmasses are dealt to ranks largest first onto the least loaded rank; the speed-up is bounded by the
-largest landmass (14.5 % of the land of the 10 M-cell bench planet: 6.9x at 8 ranks by cell count).
+largest landmass (14.5 % of the land of the 10 M-cell bench planet: 6.9x at 8 ranks by cell count).  One subtlety: the
+flood starts only from coasts of the OPEN ocean (the largest ocean component), so an island inside an inland sea is never
+flooded; it travels with the landmass that encloses its sea (plan_landmasses), otherwise its rank would see that sea
+open (found at 10 M cells: 746 cells in 4 lake islands differed by one flood EPS before this rule).
 
 This complements banded.py (index bands with a one-ring halo per iteration), which is the decomposition of the Jacobi
 passes that DO couple across water (smoothElevation over all cells, smoothField).
@@ -61,12 +64,32 @@ class LandmassPlan:
         return int(max((c.size for c in self.cells), default=0))
 
 
+def open_ocean(mesh, r_isOcean) -> np.ndarray:
+    """The reference's open ocean (js/terrain-post.js:66-94): the largest connected component of the ocean cells, the one
+    holding the smallest cell id among equally large ones.  Returns a bool mask."""
+    oc = np.asarray(r_isOcean) != 0
+    lab = land_components(mesh, (~oc).astype(np.uint8))          # components of the ocean cells (members = cells flagged 0)
+    ids = lab[oc]
+    if ids.size == 0:
+        return np.zeros(oc.size, bool)
+    labs, counts = np.unique(ids, return_counts=True)
+    main = labs[np.flatnonzero(counts == counts.max())[0]]       # labels ascend: the first of the largest
+    return lab == main
+
+
 def plan_landmasses(mesh, r_isOcean, world: int) -> LandmassPlan:
     """Deal the landmasses to `world` ranks: largest first, each onto the least loaded rank (ties: lowest rank; equal
-    sizes: lowest label first) — the same plan on every rank, no communication."""
+    sizes: lowest label first) — the same plan on every rank, no communication.
+
+    The unit that is dealt is a landmass TOGETHER WITH the inland seas it encloses and the islands in them (a connected
+    component of the cells that are not open ocean): the flood only starts from coasts of the open ocean (:118-128), so
+    land inside an inland sea is never flooded — it must not see that sea become open because the enclosing landmass was
+    masked away on its rank."""
     if world < 1:
         raise ValueError("world must be >= 1")
-    label = land_components(mesh, r_isOcean)
+    oc = np.ascontiguousarray(r_isOcean, np.uint8)
+    label = land_components(mesh, open_ocean(mesh, oc).astype(np.uint8))     # components of land + inland seas
+    label = np.where(oc != 0, -1, label).astype(np.int32)                    # only land cells are owned
     land = np.flatnonzero(label >= 0).astype(np.int32)
     owner = np.full(label.size, -1, np.int32)
     load = np.zeros(world, np.int64)

@@ -20,6 +20,41 @@ def make_case(oracle, cells, seed):
     return mesh, xyz, nd, e, (e <= 0).astype(np.uint8)
 
 
+def _hops(mesh, sources, limit):
+    """Breadth-first hop distance from the source cells (numpy frontier expansion), capped at `limit`."""
+    N = mesh.numRegions
+    dist = np.full(N, limit + 1, np.int32)
+    dist[sources] = 0
+    front = np.asarray(sources)
+    for d in range(1, limit + 1):
+        if front.size == 0:
+            break
+        nb = np.concatenate([mesh.adjList[mesh.adjOffset[r]:mesh.adjOffset[r + 1]] for r in front])
+        nb = np.unique(nb[dist[nb] > d])
+        dist[nb] = d
+        front = nb
+    return dist
+
+
+def add_lake_with_island(mesh, xyz, e):
+    """An inland sea with an island in it, cut into a landmass: around the land cell farthest from any ocean cell (D hops),
+    the cells 4..4+(D-8)/2 hops away become sea and the cells nearer stay land (the island).  The island touches no open
+    ocean: the reference never floods it."""
+    oc = (e <= 0).astype(np.uint8)
+    toOcean = _hops(mesh, np.flatnonzero(oc == 1), 64)
+    c0 = int(np.argmax(np.where(oc == 0, toOcean, -1)))
+    D = int(toOcean[c0])
+    assert D >= 12, D
+    fromC = _hops(mesh, np.array([c0]), D)
+    h1, h2 = 4, 4 + max(2, (D - 8) // 2)
+    out = e.copy()
+    ring = (fromC >= h1) & (fromC <= h2)
+    assert (toOcean[ring] >= 2).all()                       # the ring stays inside the landmass: the sea is enclosed
+    out[ring] = -0.2
+    assert ((fromC < h1) & (out > 0)).sum() >= 30 and ring.sum() > 60
+    return out
+
+
 def run_ranks(tmp_path, world, engine, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", WO_HOST_THREADS="2")
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
@@ -49,9 +84,16 @@ def test_plan_is_a_partition_of_the_land(oracle):
         assert plan.load.max() >= plan.largest
 
 
-@pytest.mark.parametrize("world,cells,seed,iters", [(2, 20000, 1, (8, 8, 3)), (3, 40000, 4, (12, 6, 0))])
-def test_partitioned_equals_unpartitioned_with_the_oracle(oracle, tmp_path, world, cells, seed, iters):
+@pytest.mark.parametrize("world,cells,seed,iters,lake", [(2, 20000, 1, (8, 8, 3), False), (3, 40000, 4, (12, 6, 0), False), (4, 150000, 2, (8, 4, 2), True)])
+def test_partitioned_equals_unpartitioned_with_the_oracle(oracle, tmp_path, world, cells, seed, iters, lake):
     mesh, xyz, nd, e, oc = make_case(oracle, cells, seed)
+    if lake:
+        from planet_heightmap_generation_amd import decomposed as D
+        e = add_lake_with_island(mesh, xyz, e)
+        oc = (e <= 0).astype(np.uint8)
+        # the island is a landmass of its own, yet it must share a rank with the landmass around its sea
+        plan = D.plan_landmasses(mesh, oc, world)
+        assert len(np.unique(D.land_components(mesh, oc)[oc == 0])) > plan.num_landmasses
     np.savez(tmp_path / "case.npz", adjOffset=mesh.adjOffset, adjList=mesh.adjList, xyz=xyz, neighborDist=nd, elevation=e, isOcean=oc,
              iters=np.array(iters))
     om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
