@@ -50,7 +50,10 @@ struct alignas(16) SolveTask {
     float cellDist, cellDistT;         // cellDist[r], cellDist[target]
     int32_t pad_[2];
 };
-constexpr int WO_PATCH = 512;          // land cells (= solve tasks) per spatial patch / workgroup
+#ifndef WO_PATCH_CELLS
+#define WO_PATCH_CELLS 1024
+#endif
+constexpr int WO_PATCH = WO_PATCH_CELLS;   // land cells (= solve tasks) per spatial patch / workgroup
 // {value, round tag}: tag 0 = not produced yet.  Written once per pass, consumed only by later rounds.
 struct alignas(8) Granule { float v; int32_t tag; };
 struct alignas(16) SolveOut { Granule self, dep; };

@@ -396,98 +396,118 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
 // Patch-local solve.  Land cells are grouped in spatial patches of WO_PATCH cells (Morton order); one workgroup
 // owns one patch and keeps the {value, tag} granules of its tasks in LDS.  In a launch a workgroup runs every task
 // whose predecessors are (a) outside the patch and produced by an EARLIER launch, or (b) inside the patch and already
-// produced — by an earlier launch or by an earlier sub-round of this launch (visible through LDS after a barrier).  So a
-// chain segment that stays inside a patch advances at LDS latency and only patch-crossing edges wait for a kernel
-// boundary.  The dataflow is single-assignment, so the bits do not depend on the schedule (same results as the
-// level-synchronous rounds; checked by the parity tests).  patchPending[p] = tasks of patch p still waiting.
+// produced — by an earlier launch or earlier in this visit (visible through LDS).  So a chain segment that stays inside a
+// patch advances at LDS latency and only patch-crossing edges wait for a kernel boundary.  The dataflow is
+// single-assignment, so the bits do not depend on the schedule (same results as the level-synchronous rounds; checked by
+// the parity tests).  patchPending[p] = tasks of patch p still waiting.
+//
+// A visit, in order:
+//  1. settle.  F.blk remembers, per task, one granule that was unresolved when the task last failed (initially the receiver's
+//     event).  From those words alone every thread decides whether its task is certainly still blocked: it is if the
+//     remembered blocker is an external granule that is not there yet, or a patch-local task that is itself certainly
+//     blocked (chains settle by polling LDS).  Blocked tasks mark their granules BLOCKED (-1, LDS only).
+//  2. hand-out.  The other pending tasks ("runnable") are handed to threads 0..n-1 through an LDS list, and every wave that
+//     got none RETURNS: at 10 M cells a visit finds 36-50 runnable tasks among the patch's (250 in the first launch), and a
+//     finished wave frees its slot for the next workgroup.  No barrier follows this point.
+//  3. run.  A runnable task loads its 48-byte record, checks its external predecessors (not there: it blocks and remembers
+//     which), then polls its patch-local predecessors in LDS and runs as soon as they are there.  A granule is one aligned
+//     64-bit LDS word {value, tag}, published and read with single accesses: no fence sits on the chain.  A task that finds a
+//     BLOCKED predecessor blocks itself; a runnable task's granules stay open (tag 0) until it has run or blocked.
+//  4. the last wave to finish (LDS counter) writes the patch's pending count.
+// The polling loop is capped (spinCap passes): what is still open then simply stays pending.  A launch lasts as long as its
+// slowest visit, and a few patches hold chains of ~300 steps while the typical visit needs 14, so short visits and a few more
+// launches are faster than long ones (10 M cells, per 200 iterations: no cap 513 ms / 13.6 k launches, cap 16: 420 ms /
+// 15.1 k, cap 4: 617 ms / 29 k; with 1024-cell patches and cap 16: 358 ms / 13.0 k).
+// (Also tried in round 2, measured slower, not kept: (a) granules published / read with agent-scope accesses so that a
+// workgroup consumes what another one produced earlier in the SAME launch, plus bounded in-launch revisits: 6-27 launches per
+// iteration instead of 60, but 670 ms; (b) narrower workgroups settling several tasks per thread (64 / 128 / 256 threads for
+// 512 tasks: 840-1200 / 612 / 490 ms); (c) 256-cell patches: 669 ms; 2048-cell patches with two tasks per thread: 493 ms.)
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WO_PATCH_THREADS = WO_PATCH;                 // one task per thread
-constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;
+constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;               // settle loop bound (never reached: every chain ends at a settled task)
+constexpr int WO_PATCH_SPIN_CAP = 16;                      // default spinCap
 #ifndef WO_PATCH_SLEEP
 #define WO_PATCH_SLEEP 1
-#endif               // passes of one wave over its tasks before it gives up for this launch
-// Inside a launch the waves of a patch do not meet at barriers: every task polls its patch-local predecessors in LDS
-// and runs as soon as they are there (value stored before tag, tag read before value; LDS operations of a wave stay
-// in order).  A task whose external predecessors are not from an earlier launch marks its granules BLOCKED (-1), and
-// a task that finds a blocked predecessor blocks itself, so every task of the visit ends up done or blocked and each
-// wave leaves its loop; blocked marks live in LDS only.  The set of tasks that complete in a launch (and therefore
-// every tag) is the same as with barrier-separated sub-rounds; only the waiting is finer grained.
-// Most tasks of an inland patch stay blocked for many launches.  F.blk remembers, per task, one granule that was
-// unresolved when the task last failed (initially the receiver's event).  A visit first settles, from those words
-// alone, which tasks are certainly still blocked: a task is if its remembered blocker is an external granule that is
-// not there yet, or a patch-local task that is itself certainly blocked (chains settle by polling LDS).  Only the
-// other tasks load their 48-byte records and look at all three predecessors.
-// (Tried in round 2 and measured slower, not kept: publishing / reading the granules with agent-scope 64-bit accesses so that
-// a workgroup consumes what another one produced earlier in the SAME launch, plus bounded in-launch revisits.  Launches per
-// iteration fell from 60 to 6-27 but the pass took 670 ms instead of 575 ms per 200 iterations at 10 M cells: it is bound by
-// the visits themselves (every wave of every active patch pays a chain of dependent loads), not by kernel boundaries, and
-// the sc1 accesses are dearer than cached ones.  DESIGN.md section 5.)
-__global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int32_t L, int32_t launchTag,
-                                                                   int32_t* patchPending, int32_t* totalPending, double K, double m, double dt) {
+#endif
+// dbg (diagnostic, may be null), per launch: [0] visits that found nothing runnable, [1] visits that ran, [2] runnable tasks,
+// [3] completed tasks, [4] largest number of polling passes of a wave
+__global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int32_t L, int32_t launchTag, int32_t* patchPending, int32_t* totalPending,
+                                                                   double K, double m, double dt, int32_t* dbg, int32_t spinCap) {
     __shared__ Granule s_out[2 * WO_PATCH];
     __shared__ int32_t s_st[WO_PATCH];                      // 0 unsettled, 1 certainly blocked, 2 candidate or done
-    __shared__ int32_t s_left;
+    __shared__ int32_t s_cand[WO_PATCH];
+    __shared__ int32_t s_ncand, s_pend, s_done, s_fin;
     const int p = blockIdx.x, tid = threadIdx.x;
     if (patchPending[p] == 0) return;                       // block-uniform
     const Granule* G = reinterpret_cast<const Granule*>(F.out);
-    const int32_t s = p * WO_PATCH + tid;                   // store index = patch slot
-    const int32_t base = 2 * p * WO_PATCH;                  // first granule of this patch
-    const bool have = s < L;
-    SolveOut mine; mine.self.v = 0; mine.self.tag = 0; mine.dep.v = 0; mine.dep.tag = 0;
-    if (have) mine = F.out[s];
-    bool done = !have || mine.self.tag != 0;
+    const int32_t s0 = p * WO_PATCH;
+    const int32_t base = 2 * s0;
     auto is_local = [&](int32_t g) { return (uint32_t)(g - base) < (uint32_t)(2 * WO_PATCH); };
-    auto ext_ready = [&](int32_t g, double& v) {            // external granule produced in an earlier launch?
+    auto ext_ready = [&](int32_t g, double& v) {
         const Granule q = G[g];
         if (q.tag == 0 || q.tag >= launchTag) return false;
         v = q.v; return true;
     };
-    // ---- settle the remembered blockers
-    int32_t st = 2, waitOn = -1;
-    if (!done) {
-        const int32_t b = F.blk[s];
-        if (b >= 0) {
+    if (tid == 0) { s_ncand = 0; s_pend = 0; s_done = 0; s_fin = 0; }
+    // ---- every task: granules to LDS, remembered blocker settled
+    {
+        const int32_t sm = s0 + tid;
+        SolveOut mine; mine.self.v = 0; mine.self.tag = 1; mine.dep.v = 0; mine.dep.tag = 1;      // beyond L: counts as done
+        int32_t b = -1;
+        if (sm < L) { mine = F.out[sm]; b = F.blk[sm]; }
+        const bool pending = mine.self.tag == 0;
+        int32_t st = 2, waitOn = -1;
+        if (pending && b >= 0) {
             if (is_local(b)) { st = 0; waitOn = (b - base) >> 1; }
             else { double unused; st = ext_ready(b, unused) ? 2 : 1; }
         }
+        s_st[tid] = st;
+        s_out[2 * tid] = mine.self; s_out[2 * tid + 1] = mine.dep;
+        __syncthreads();
+        volatile int32_t* vst = s_st;
+        for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
+            if (st == 0) { const int32_t w = vst[waitOn]; if (w != 0) { st = w; vst[tid] = w; } }
+        }
+        if (pending) {
+            if (st == 2) s_cand[atomicAdd(&s_ncand, 1)] = tid;
+            else { s_out[2 * tid].tag = -1; s_out[2 * tid + 1].tag = -1; }
+        }
+        const unsigned long long pm = __ballot(pending);
+        if ((tid & 63) == 0 && pm) atomicAdd(&s_pend, __popcll(pm));
     }
-    s_st[tid] = st;
-    if (tid == 0) s_left = 0;
     __syncthreads();
-    volatile int32_t* vst = s_st;
-    for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
-        if (st == 0) { const int32_t w = vst[waitOn]; if (w != 0) { st = w; vst[tid] = w; } }
-    }
-    // ---- candidates load their record and check the external predecessors
-    SolveTask T;
-    double er = 0, et = 0, et2 = 0, factor = 0;
-    bool unresolved = !done && st == 2;
-    if (!__syncthreads_or(unresolved)) {                    // nothing can move in this patch: same pending count as before
-        if (tid == 0) atomicAdd(totalPending, patchPending[p]);
+    const int32_t ncand = s_ncand;
+    if (ncand == 0) {                                       // nothing can move in this patch: same pending count as before
+        if (tid == 0) { atomicAdd(totalPending, s_pend); if (dbg) atomicAdd(&dbg[0], 1); }
         return;
     }
+    if ((tid & ~63) >= ncand) return;                       // this wave got no task
+    const int32_t aliveWaves = (ncand + 63) >> 6;
+    if (dbg && tid == 0) { atomicAdd(&dbg[1], 1); atomicAdd(&dbg[2], ncand); }
+    // ---- runnable tasks: record, external predecessors
+    const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
+    volatile unsigned long long* vs = reinterpret_cast<volatile unsigned long long*>(s_out);
+    SolveTask T;
+    double er = 0, et = 0, et2 = 0, factor = 0;
+    bool unresolved = tid < ncand;
+    int32_t t = 0, s = 0, ran = 0;
     if (unresolved) {
+        t = s_cand[tid]; s = s0 + t;
         T = F.task[s];
         er = T.e0r; et = T.e0t; et2 = T.e0t2;
         int32_t fail = -1;
         if (T.predSelf >= 0 && !is_local(T.predSelf) && !ext_ready(T.predSelf, er)) fail = T.predSelf;
         if (T.predT >= 0 && !is_local(T.predT) && !ext_ready(T.predT, et)) fail = T.predT;
         if (T.predT2 >= 0 && !is_local(T.predT2) && !ext_ready(T.predT2, et2)) fail = T.predT2;
-        if (fail >= 0) { F.blk[s] = fail; unresolved = false; }
+        if (fail >= 0) { F.blk[s] = fail; unresolved = false; vs[2 * t] = BLOCKED; vs[2 * t + 1] = BLOCKED; }
         else factor = solve_factor(T, K, m, dt);
     }
-    if (!done && !unresolved) { mine.self.tag = -1; mine.dep.tag = -1; }
-    s_out[2 * tid] = mine.self; s_out[2 * tid + 1] = mine.dep;
-    __syncthreads();
-    // ---- run: poll the patch-local predecessors.  A granule is one aligned 64-bit LDS word {value, tag}: it is published
-    // and read with single 64-bit accesses, so no fence sits on the chain (a workgroup fence would also wait for the
-    // global store of the result, hundreds of cycles per chain step) and a poll is one LDS round trip, not two.
-    volatile unsigned long long* vs = reinterpret_cast<volatile unsigned long long*>(s_out);
+    // ---- run: poll the patch-local predecessors
     auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
-    const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
-    for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(unresolved); ++spin) {
-        // a wave that only waits should not compete for issue slots with the waves that carry a chain
+    int spins = 0;
+    for (int spin = 0; spin < spinCap && __any(unresolved); ++spin) {
         if (spin && WO_PATCH_SLEEP) __builtin_amdgcn_s_sleep(WO_PATCH_SLEEP);
+        ++spins;
         if (!unresolved) continue;
         int32_t open = 0, fail = -1;
         double a = er, b = et, c = et2;
@@ -501,20 +521,30 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
         };
         rd(T.predSelf, a); rd(T.predT, b); rd(T.predT2, c);
         if (fail >= 0) {
-            vs[2 * tid] = BLOCKED; vs[2 * tid + 1] = BLOCKED;
+            vs[2 * t] = BLOCKED; vs[2 * t + 1] = BLOCKED;
             F.blk[s] = fail;
             unresolved = false;
         } else if (!open) {
             const SolveOut o = solve_apply(T, factor, a, b, c, launchTag);
-            vs[2 * tid] = pack(o.self); vs[2 * tid + 1] = pack(o.dep);      // consumers first ...
-            F.out[s] = o;                                                   // ... the global copy is for later launches
-            unresolved = false; done = true;
+            vs[2 * t] = pack(o.self); vs[2 * t + 1] = pack(o.dep);
+            F.out[s] = o;
+            unresolved = false; ran = 1;
         }
     }
-    // block total of the still-pending tasks
-    if (!done) atomicAdd(&s_left, 1);
-    __syncthreads();
-    if (tid == 0) { const int32_t left = s_left; patchPending[p] = left; if (left) atomicAdd(totalPending, left); }
+    // ---- the last wave to finish publishes the patch's pending count
+    const unsigned long long rm = __ballot(ran != 0);
+    if (dbg && (tid & 63) == 0) atomicMax(&dbg[4], spins);
+    if ((tid & 63) == 0) {
+        if (rm) atomicAdd(&s_done, __popcll(rm));
+        __threadfence_block();
+        if (atomicAdd(&s_fin, 1) == aliveWaves - 1) {
+            const int32_t done = atomicAdd(&s_done, 0);
+            const int32_t left = s_pend - done;
+            patchPending[p] = left;
+            if (left) atomicAdd(totalPending, left);
+            if (dbg) atomicAdd(&dbg[3], done);
+        }
+    }
 }
 
 __global__ __launch_bounds__(WO_BLOCK) void k_slot_scatter(const int32_t* patchOrder, int32_t* slotOf, int32_t L) {

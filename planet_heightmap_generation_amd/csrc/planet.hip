@@ -235,17 +235,32 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
     int32_t* tot = p->d_patchTotals;
     WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
     int64_t launches = 0;
+    // WO_SOLVE_SPINS: polling passes per visit (kernels_impl.h).  WO_SOLVE_STATS=<n>: per-launch counters of the n-th solve
+    // pass of the planet -> stderr (diagnostic).
+    static const int spinCap = getenv("WO_SOLVE_SPINS") ? std::max(1, atoi(getenv("WO_SOLVE_SPINS"))) : WO_PATCH_SPIN_CAP;
+    static const int statsIter = getenv("WO_SOLVE_STATS") ? atoi(getenv("WO_SOLVE_STATS")) : -1;
+    constexpr int DBG_W = 8, DBG_N = 512;
+    int32_t* dbg = nullptr;
+    if (statsIter >= 0 && p->solveCalls++ == statsIter) { WO_HIP(hipMalloc(&dbg, DBG_N * DBG_W * sizeof(int32_t))); WO_HIP(hipMemsetAsync(dbg, 0, DBG_N * DBG_W * sizeof(int32_t), s)); }
     for (int32_t tag = 1;; ) {
         // The pending total is read back (one stream sync) after every burst.  The launch count barely changes from one
         // erosion iteration to the next, so the first burst is sized by the previous count; then small bursts to finish.
         const int burst = (tag == 1) ? std::max<int>(1, (int)p->lastPatchLaunches - 1) : 3;
         for (int b = 0; b < burst; ++b, ++tag) {
             if (tag % WO_PATCH_TOTAL_SLOTS == 0) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: slots are free again (stream order)
-            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt);
+            launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
+                   dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)spinCap);
             ++launches;
         }
         if (read_count(p, tot + ((tag - 1) % WO_PATCH_TOTAL_SLOTS)) == 0) break;
         if (launches > 4 * (int64_t)p->N + 1024) throw HipError{"patch solve does not converge"};
+    }
+    if (dbg) {
+        std::vector<int32_t> h(DBG_N * DBG_W);
+        WO_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        WO_HIP(hipFree(dbg));
+        fprintf(stderr, "solve stats: %d patches of %d, %d tasks, %lld launches, spin cap %d\nlaunch idle_visits running_visits runnable completed max_passes\n", np, WO_PATCH, p->L, (long long)launches, spinCap);
+        for (int t = 1; t <= std::min<int64_t>(launches, DBG_N - 1); ++t) { const int32_t* q = &h[DBG_W * t]; fprintf(stderr, "%d %d %d %d %d %d\n", t, q[0], q[1], q[2], q[3], q[4]); }
     }
     p->lastPatchLaunches = launches;
     return launches;
