@@ -223,6 +223,40 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     blend_collision_layers(N, S, P, H);
 
     lap("sets+blend");
+    // ---- plate representatives (:368-382) ----
+    {
+        std::vector<int32_t> rep(I.plates.numIds, -1);
+        for (int32_t r = 0; r < N; ++r) {
+            const int32_t pid = I.plate[r];
+            if (rep[pid] < 0 && !mountain.has(r) && !coastline.has(r) && !ocean.has(r)) rep[pid] = r;
+        }
+        for (int32_t i = 0; i < I.numPlateSeeds; ++i) {
+            const int32_t pid = I.plateSeeds[i];
+            if (pid >= 0 && pid < I.plates.numIds && rep[pid] >= 0) (I.plates.isOcean[pid] ? ocean : coastline).add(rep[pid]);
+        }
+    }
+    // ---- isOcean by plate, coast seeds (:396-425) ----
+    H.isOcean.assign(N, 0);
+    for (int32_t r = 0; r < N; ++r) H.isOcean[r] = I.plates.isOcean[I.plate[r]] ? 1 : 0;
+    OrderedSet coastSeeds(N);
+    std::vector<int32_t> landCoastSeeds;
+    for (int32_t r = 0; r < N; ++r) {
+        if (H.isOcean[r]) continue;
+        for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni)
+            if (H.isOcean[M.adj[ni]]) { coastSeeds.add(M.adj[ni]); landCoastSeeds.push_back(r); break; }
+    }
+    // ---- five distance fields (:392-426): serial by definition (every step draws from the LCG), independent of each other ->
+    // one host thread each.  Three of them (ocean, coast, land coast) do not depend on the propagated stress and start now, so
+    // that the longest one (the coast distance reaches every cell) runs while the stress propagates; the other two start
+    // once their seeds / stops exist.
+    H.distMountain.resize(N); H.distOcean.resize(N); H.distCoastline.resize(N); H.distCoast.resize(N); H.distCoastLand.resize(N);
+    std::vector<std::thread> walks; walks.reserve(5);
+    struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for (auto& x : t) if (x.joinable()) x.join(); } } joinWalks{walks};
+    walks.emplace_back([&]() { distance_field(M, coastSeeds.items, nullptr, I.seed + 4, H.distCoast.data()); });
+    walks.emplace_back([&]() { distance_field(M, ocean.items, coastline.in.data(), I.seed + 2, H.distOcean.data()); });
+    walks.emplace_back([&]() { distance_field(M, landCoastSeeds, H.isOcean.data(), I.seed + 5, H.distCoastLand.data()); });
+
+    lap("reps+seeds");
     // ---- stress propagation (:329-362) ----
     const double scaleFactor = std::sqrt((double)N / 10000);
     const double baseDecay = 0.5 + I.spread * 0.04;
@@ -244,38 +278,18 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
     }
 
     lap("stress");
-    // ---- plate representatives (:368-382) ----
-    {
-        std::vector<int32_t> rep(I.plates.numIds, -1);
-        for (int32_t r = 0; r < N; ++r) {
-            const int32_t pid = I.plate[r];
-            if (rep[pid] < 0 && !mountain.has(r) && !coastline.has(r) && !ocean.has(r)) rep[pid] = r;
-        }
-        for (int32_t i = 0; i < I.numPlateSeeds; ++i) {
-            const int32_t pid = I.plateSeeds[i];
-            if (pid >= 0 && pid < I.plates.numIds && rep[pid] >= 0) (I.plates.isOcean[pid] ? ocean : coastline).add(rep[pid]);
-        }
-    }
     std::vector<int32_t> stressMountain;
     for (int32_t r : mountain.items) if ((double)H.subduct[r] < 0.55) stressMountain.push_back(r);
     H.mountain = mountain.items; H.coastline = coastline.items; H.ocean = ocean.items;
 
-    // ---- isOcean by plate, coast seeds (:396-425) ----
-    H.isOcean.assign(N, 0);
-    for (int32_t r = 0; r < N; ++r) H.isOcean[r] = I.plates.isOcean[I.plate[r]] ? 1 : 0;
-    OrderedSet coastSeeds(N);
-    std::vector<int32_t> landCoastSeeds;
-    for (int32_t r = 0; r < N; ++r) {
-        if (H.isOcean[r]) continue;
-        for (int32_t ni = M.off[r]; ni < M.off[r + 1]; ++ni)
-            if (H.isOcean[M.adj[ni]]) { coastSeeds.add(M.adj[ni]); landCoastSeeds.push_back(r); break; }
-    }
     std::vector<uint8_t> stopAll(N, 0);
     for (int32_t r : stressMountain) stopAll[r] = 1;
     for (int32_t r : coastline.items) stopAll[r] = 1;
     for (int32_t r : ocean.items) stopAll[r] = 1;
 
-    lap("reps+seeds");
+    walks.emplace_back([&]() { distance_field(M, stressMountain, ocean.in.data(), I.seed + 1, H.distMountain.data()); });
+    walks.emplace_back([&]() { distance_field(M, coastline.items, stopAll.data(), I.seed + 3, H.distCoastline.data()); });
+
     // ---- scalars (:431-460) ----
     auto rnd = [](double x) { return std::floor(x + 0.5); };
     Q.N = N; Q.scaleFactor = scaleFactor; Q.noiseMag = I.noiseMag;
@@ -312,18 +326,9 @@ void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const Collisio
 
     lap("scalars+pctl");
     // the FIFO BFS fields do not depend on the distance fields: the product starts them on the device now and they run
-    // while the serial RNG-ordered walks below occupy the host threads
+    // while the serial RNG-ordered walks occupy the host threads
     if (bfsOnDevice) bfsOnDevice(Q, maxCD, maxStress);
-    // ---- five distance fields (:392-426), independent -> one host thread each ----
-    H.distMountain.resize(N); H.distOcean.resize(N); H.distCoastline.resize(N); H.distCoast.resize(N); H.distCoastLand.resize(N);
-    {
-        std::thread a([&]() { distance_field(M, stressMountain, ocean.in.data(), I.seed + 1, H.distMountain.data()); });
-        std::thread b([&]() { distance_field(M, ocean.items, coastline.in.data(), I.seed + 2, H.distOcean.data()); });
-        std::thread c([&]() { distance_field(M, coastline.items, stopAll.data(), I.seed + 3, H.distCoastline.data()); });
-        std::thread d([&]() { distance_field(M, coastSeeds.items, nullptr, I.seed + 4, H.distCoast.data()); });
-        distance_field(M, landCoastSeeds, H.isOcean.data(), I.seed + 5, H.distCoastLand.data());
-        a.join(); b.join(); c.join(); d.join();
-    }
+    for (auto& x : walks) x.join();
 
     lap("distance fields");
     if (!bfsOnDevice) {
