@@ -16,6 +16,9 @@ landmasses masked as ocean; one all-gather of the land elevations per step over 
 unpartitioned run) -> value = cells x 200 x steps / wall of that one planet, "scaling": "strong".
 --mode ensemble: one independent planet per rank with seed = 1 + rank (BASELINE config 5; no data-path collective)
 -> "scaling": "weak".
+N = 1 with --mode decomposed [--shares S]: the partitioned code path on ONE GPU — the planet is split into S landmass shares
+(the plan an S-GPU run would use), the shares are eroded one after the other with the same masks, merged, and checked against
+the oracle's CRC; the line reports the time of every share (what each of S GPUs would spend) next to the sequential total.
 
 Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel family, HIP-event timed) and
 `cpu_baseline` (the CPU oracle on a bounded sample of the same workload, rank 0, N=1 only) objects.
@@ -190,6 +193,60 @@ def one_step_decomposed(pl, seed, params, dec: Decomposition):
     dec.merge()
 
 
+class VirtualShares:
+    """--mode decomposed on one GPU: the S-rank plan executed share by share (same masks, same merge rule)."""
+
+    def __init__(self, mesh, pl, shares):
+        self.mesh, self.pl, self.S = mesh, pl, shares
+        self.plan, self.true_oc, self.share_ms, self.prep_ms, self.merge_ms, self.plan_ms = None, None, [], 0.0, 0.0, 0.0
+
+    def step(self, seed, params):
+        from planet_heightmap_generation_amd import decomposed as D
+        pl, p = self.pl, dict(params)
+        t0 = time.perf_counter()
+        pl.restore_state()
+        pl.warp_terrain_resident(seed, WARP)
+        pl.ocean_from_elevation()
+        oc = pl.download_ocean()
+        merged = pl.download()
+        if self.true_oc is None or not np.array_equal(oc, self.true_oc):
+            tp = time.perf_counter()
+            self.plan, self.true_oc = D.plan_landmasses(self.mesh, oc, self.S), oc
+            self.plan_ms = (time.perf_counter() - tp) * 1e3
+        warped = merged.copy()
+        self.prep_ms = (time.perf_counter() - t0) * 1e3
+        self.share_ms = []
+        tm = 0.0
+        for k in range(self.S):
+            pl.upload(warped, self.plan.rank_mask(k, oc))
+            pl.sync()
+            t1 = time.perf_counter()
+            pl.erode_composite_resident(p["hIters"], p["K"], p["m"], p["dt"], p["tIters"], p["talusSlope"], p["kThermal"], p["gIters"],
+                                        p["glacialStrength"])
+            pl.apply_soil_creep_resident(*CREEP)
+            pl.sync()
+            self.share_ms.append((time.perf_counter() - t1) * 1e3)
+            t2 = time.perf_counter()
+            part = pl.download()
+            merged[self.plan.cells[k]] = part[self.plan.cells[k]]
+            tm += time.perf_counter() - t2
+        pl.upload(merged, oc)
+        pl.sync()
+        self.merge_ms = tm * 1e3
+
+    def summary(self, unpartitioned_ms):
+        L = max(1, int(self.plan.load.sum()))
+        worst = max(self.share_ms)
+        return dict(shares=self.S, landmasses=self.plan.num_landmasses, largest_landmass_fraction=round(self.plan.largest / L, 4),
+                    land_cells_per_share=[int(v) for v in self.plan.load], speedup_bound_by_cell_count=round(L / max(1, int(self.plan.load.max())), 2),
+                    share_ms_last_step=[round(v, 1) for v in self.share_ms], unpartitioned_stack_ms=round(unpartitioned_ms, 1),
+                    projected_speedup_one_gpu_per_share=round(unpartitioned_ms / worst, 2),
+                    hand_off_rounds_per_iteration=0, exchange="one all-gather of 4 B per land cell per step; nothing inside the iteration loop",
+                    plan_ms_when_mask_changes=round(self.plan_ms, 1), host_merge_ms_last_step=round(self.merge_ms, 1),
+                    note="erodeComposite + creep per share, measured one after the other on ONE GPU, each including the mask-dependent tables a rank of a real run builds once (~0.1 s at 10 M cells); `value` is the sequential total "
+                         "(what this one GPU did), the projection is unpartitioned / slowest share")
+
+
 def ensemble_in_flight(TP, mesh, xyz, nd, seed, params, B: int, device: int):
     """Supplementary figure, NOT `value`: B independent planets in flight on one GPU (one host thread, context and
     stream per planet; BASELINE config 5 runs 8 planets per GPU).  The dependency-bound kernels of one planet leave
@@ -305,7 +362,9 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo + --share-gpu: rehearse the multi-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0")
     ap.add_argument("--mode", choices=("auto", "decomposed", "ensemble"), default="auto",
-                    help="N > 1: 'decomposed' = one planet over all GPUs by landmass (strong scaling, default), 'ensemble' = one planet per GPU (weak)")
+                    help="N > 1: 'decomposed' = one planet over all GPUs by landmass (strong scaling, default), 'ensemble' = one planet per GPU (weak); "
+                         "N = 1 with 'decomposed': the partitioned code path, --shares landmass shares one after the other")
+    ap.add_argument("--shares", type=int, default=8, help="N = 1, --mode decomposed: number of landmass shares")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -339,6 +398,17 @@ def main():
 
     dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}" if args.backend == "nccl" else None) if decomposed_mode else None
     step = (lambda: one_step_decomposed(pl, seed, params, dec)) if decomposed_mode else (lambda: one_step(pl, seed, params))
+    virt = VirtualShares(mesh, pl, max(1, args.shares)) if (world == 1 and args.mode == "decomposed") else None
+    unpart_ms = None
+    if virt:
+        one_step(pl, seed, params); pl.sync()                 # tables for the true mask, then the unpartitioned stack for reference
+        pl.restore_state(); pl.warp_terrain_resident(seed, WARP); pl.ocean_from_elevation(); pl.sync()
+        tu = time.perf_counter()
+        pl.erode_composite_resident(params["hIters"], params["K"], params["m"], params["dt"], params["tIters"], params["talusSlope"], params["kThermal"],
+                                    params["gIters"], params["glacialStrength"])
+        pl.apply_soil_creep_resident(*CREEP); pl.sync()
+        unpart_ms = (time.perf_counter() - tu) * 1e3
+        step = lambda: virt.step(seed, params)
     cold_ms = None
     for w in range(args.warmup):
         tc = time.perf_counter()
@@ -362,7 +432,7 @@ def main():
     iters = max(params["hIters"], params["tIters"], params["gIters"])
 
     roofline = None
-    if rank == 0 and not args.no_profile and not decomposed_mode:
+    if rank == 0 and not args.no_profile and not decomposed_mode and not virt:
         # separate pass with every launch bracketed by HIP events on the planet's stream
         pl.profile_reset()
         pl.profile_enable(True)
@@ -405,11 +475,11 @@ def main():
                                          achieved_GBs=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9,
                                          frac=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9 / HBM_PEAK_GBS))
     ensemble = None
-    if rank == 0 and world == 1 and args.in_flight > 1:
+    if rank == 0 and world == 1 and args.in_flight > 1 and not virt:
         ensemble = ensemble_in_flight(TP, mesh, xyz, nd, seed, params, args.in_flight, local_rank)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not virt:
         cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters, iters)
 
     if rank == 0:
@@ -417,14 +487,15 @@ def main():
         out = {
             "metric": "Mcells·iter/s, terrain-post erosion stack", "value": value, "unit": "Mcells·iter/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3 / args.steps,
-            "higher_is_better": True, "scaling": "strong" if decomposed_mode else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (decomposed_mode or virt) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 3: {N} cells (Fibonacci sphere {args.cells}+pole, jitter 0.75, seed 1+rank), "
                                    f"warp 0.75 + erodeComposite(h={params['hIters']},t={params['tIters']},g={params['gIters']}) + creep x3, "
-                                   + ("ONE planet over all GPUs" if decomposed_mode else "one planet per GPU"), "cells": N, "land_cells": L, "iterations": iters,
+                                   + ("ONE planet over all GPUs" if decomposed_mode else (f"ONE planet as {virt.S} landmass shares, one after the other on one GPU" if virt else "one planet per GPU")), "cells": N, "land_cells": L, "iterations": iters,
                        "parallelism": (f"landmass decomposition x{world}: every rank erodes its share of the planet's landmasses, one all-gather of the land "
                                        f"elevations per step over RCCL (bit-identical to the unpartitioned run)") if decomposed_mode
-                                      else f"ensemble x{world} (no collective on the data path)"},
-            "decomposition": dec.summary() if dec else None,
+                                      else (f"landmass decomposition, {virt.S} shares executed sequentially on one GPU (partitioned code path)" if virt
+                                            else f"ensemble x{world} (no collective on the data path)")},
+            "decomposition": dec.summary() if dec else (virt.summary(unpart_ms) if virt else None),
             "roofline": roofline, "cpu_baseline": cpu, "ensemble_in_flight": ensemble,
             "parity": crc, "cold_first_step_ms": cold_ms, "host_threads": host_thread_usage(),
             "hbm_d2d_copy_GBs_measured": round(d2d_bandwidth_GBs(local_rank), 1),
