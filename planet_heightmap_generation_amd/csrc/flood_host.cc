@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -245,6 +246,29 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     S.surface.resize(L); S.state.resize(L); S.root.resize(L); S.eL.resize(L);
     S.order.resize(L); S.order2.resize(L); S.bits.resize(L); S.bits2.resize(L); S.list2.resize(L);
     lap("seeds+alloc");
+    {   // Landmasses: connected components of the compact land graph.  The flood never crosses water (ocean cells are
+        // "visited" from the start, :119), so every landmass floods from its own seeds and pass 1 can give each its own
+        // heap (flood_pass1_landmasses).  Seeds are grouped by landmass (ascending original id inside, the order the
+        // reference pushes them in); landmasses are taken largest first.
+        std::vector<int32_t> comp(L);
+        mesh_components(L, S.offL.data(), S.adjL.data(), [](int32_t) { return true; }, [](int32_t, int32_t) { return true; }, comp.data());
+        std::vector<int32_t> size(L, 0);
+        for (int32_t i = 0; i < L; ++i) ++size[comp[i]];
+        const int32_t nS = (int32_t)S.seedCell.size();
+        std::vector<int32_t> ord(nS);
+        for (int32_t k = 0; k < nS; ++k) ord[k] = k;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) {
+            const int32_t ca = comp[S.seedCell[a]], cb = comp[S.seedCell[b]];
+            return size[ca] != size[cb] ? size[ca] > size[cb] : ca < cb;
+        });
+        S.compSeeds.assign(ord.begin(), ord.end());
+        S.compSeedStart.clear(); S.compSize.clear();
+        for (int32_t k = 0; k < nS; ++k)
+            if (k == 0 || comp[S.seedCell[ord[k]]] != comp[S.seedCell[ord[k - 1]]]) { S.compSeedStart.push_back(k); S.compSize.push_back(size[comp[S.seedCell[ord[k]]]]); }
+        S.compSeedStart.push_back(nS);
+        S.stamp.resize(L);
+    }
+    lap("landmasses");
     S.staticValid = true;
     S.staticN = N;
     ++S.staticVersion;
@@ -335,6 +359,161 @@ void flood_pass1_host(FloodScratch& S) {
     T.lap("pass1");
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pass 1, one heap per landmass.  With distinct keys a binary heap pops the smallest key whatever its array looks
+// like, and landmasses share neither cells nor claims, so the pops of the reference's single heap, restricted to one
+// landmass, are the pops of a heap that holds only that landmass.  What a separate heap cannot reproduce is the
+// single heap's choice between EQUAL keys (it depends on the array's whole history, other landmasses included), so
+// that choice is never relied upon here; instead the walk tracks where it could matter:
+//
+//  * a TIE GROUP opens when a cell pops with key K while another entry with key K is in the heap (then, and only
+//    then, the new top has key K); it lasts until a key > K pops.  Its members are the tied cells (popped in an
+//    order we must not trust) and, after each, the cascade of descendants with keys < K: together a FAMILY.
+//    Cascades may hold tie groups of their own (a stack of open groups).
+//  * the families of a group evolve independently of their order unless a cell of one family meets a cell that
+//    another family of the same group claimed.  Every claim made inside a group is stamped with the family's id
+//    (ids grow monotonically, so "claimed by an earlier family of this group" is firstFam <= stamp < fam), and
+//    every already-visited neighbour a popping cell sees is checked: a hit is a CONTESTED cell.
+//  * no contested cell  ->  drainTo / surface are the single heap's, bit for bit, whatever it did with its ties.
+//  * a contested cell whose surface (hence key) is the same under either claimant and whose key is above the
+//    group's level pops after the group either way: only its drainTo is open.  It is reported in rep.alt and
+//    passes 2/3 decide whether the elevations depend on it (flood_pass23_host).
+//  * anything else (a claimant would change a surface, or the cell cascades inside the group)  ->  return false,
+//    the caller runs the serial walk (flood_pass1_host), the reference's order by construction.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct TieGroup { float level; int32_t firstFam, fam; };
+struct Contest { int32_t cell, other; float level; };
+
+void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
+                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
+    const double EPS = 1e-7;
+    const int32_t* landCell = S.landCell.data();
+    const int32_t* offL = S.offL.data();
+    const int32_t* adjL = S.adjL.data();
+    const float* eL = S.eL.data();
+    FloodCell* st = S.state.data();
+    int32_t* stamp = S.stamp.data();
+    if (store.size() < 1024) store.resize(1024);
+    KeyHeap heap(store);
+    for (int32_t q = 0; q < nSeeds; ++q) {                  // :118-128, ascending r
+        const int32_t s = seeds[q], i = S.seedCell[s];
+        st[i].drain = TO_OCEAN;
+        st[i].root = s;
+        heap.push(i, (float)((double)eL[i] + cell_noise(landCell[i])));
+    }
+    int32_t famCounter = 0;
+    TieGroup groups[64]; int nOpen = 0;
+    while (heap.n > 0) {
+        const float kc = store.data()[0].key;
+        const int32_t c = heap.pop();
+        const FloodHeapItem* hp = store.data();
+        const bool tieTop = heap.n > 0 && hp[0].key == kc;
+        if (tieTop || nOpen) {
+            while (nOpen && kc > groups[nOpen - 1].level) --nOpen;
+            if (nOpen && kc == groups[nOpen - 1].level) groups[nOpen - 1].fam = ++famCounter;       // the next tied cell: a new family
+            else if (tieTop) {
+                if (nOpen == 64) { contests.push_back(Contest{c, -1, kc}); }                        // cannot happen in practice: reported as unresolved
+                else { if (nOpen) ++nNested; ++nGroups; ++famCounter; groups[nOpen++] = TieGroup{kc, famCounter, famCounter}; }
+            }
+        }
+        {
+            const size_t lim2 = heap.n < 7 ? heap.n : 7;
+            for (size_t q = 0; q < lim2; ++q) {
+                const int32_t cc = hp[q].cell;
+                __builtin_prefetch(&offL[cc]); __builtin_prefetch(&st[cc]);
+            }
+            if (heap.n > 0) {
+                const int32_t c0 = hp[0].cell;
+                for (int32_t j = offL[c0]; j < offL[c0 + 1]; ++j) __builtin_prefetch(&st[adjL[j]]);
+            }
+            for (size_t q = 1; q < lim2 && q < 3; ++q) __builtin_prefetch(&adjL[offL[hp[q].cell]]);
+        }
+        const int32_t curFam = nOpen ? groups[nOpen - 1].fam : 0;
+        const double lim = (double)st[c].surface + EPS;
+        const int32_t iEnd = offL[c + 1];
+        const int32_t rootC = st[c].root;
+        for (int32_t i = offL[c]; i < iEnd; ++i) {
+            const int32_t nb = adjL[i];
+            FloodCell& sn = st[nb];
+            if (sn.drain != UNVISITED) {
+                if (curFam) {
+                    const int32_t sv = stamp[nb];
+                    if (sv) for (int g = 0; g < nOpen; ++g)
+                        if (sv >= groups[g].firstFam && sv < groups[g].fam) { contests.push_back(Contest{nb, c, groups[g].level}); break; }
+                }
+                continue;
+            }
+            sn.drain = c;
+            sn.root = rootC;
+            if (curFam) stamp[nb] = curFam;
+            float k;
+            if ((double)sn.e < lim) {
+                sn.surface = (float)lim;
+                k = (float)((double)sn.surface + cell_noise(landCell[nb]));
+            } else {
+                k = (float)((double)sn.e + cell_noise(landCell[nb]));
+            }
+            heap.push(nb, k);
+        }
+    }
+}
+int flood_workers(int64_t items) {
+    static const int capThreads = [] { const char* e = std::getenv("WO_FLOOD_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 24; }();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(host_threads(), capThreads), items));
+}
+}  // namespace
+
+bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep) {
+    const double EPS = 1e-7;
+    FloodTimer T;
+    const int32_t nComp = (int32_t)S.compSize.size();
+    rep = FloodTieReport{};
+    rep.landmasses = nComp;
+    if (nComp == 0) return true;
+    parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { std::memset(S.stamp.data() + b, 0, sizeof(int32_t) * (size_t)(en - b)); });
+    const int nt = flood_workers(nComp);
+    rep.workers = nt;
+    if ((int)S.workerHeaps.size() < nt) S.workerHeaps.resize(nt);
+    std::vector<std::vector<Contest>> contests(nt);
+    std::vector<int64_t> ng(nt, 0), nn(nt, 0);
+    std::atomic<int32_t> next{0};
+    auto worker = [&](int w) {
+        for (;;) {
+            const int32_t k = next.fetch_add(1);
+            if (k >= nComp) break;
+            walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], contests[w], ng[w], nn[w]);
+        }
+    };
+    if (nt == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < nt; ++w) th.emplace_back(worker, w);
+        for (auto& t : th) t.join();
+    }
+    const FloodCell* st = S.state.data();
+    for (int w = 0; w < nt; ++w) {
+        rep.groups += ng[w]; rep.nested += nn[w];
+        for (const Contest& ct : contests[w]) {
+            ++rep.contested;
+            if (ct.other < 0) { ++rep.unresolved; continue; }
+            const FloodCell& x = st[ct.cell];
+            const float kx = (float)((double)x.surface + cell_noise(S.landCell[ct.cell]));
+            const double limO = (double)st[ct.other].surface + EPS;
+            const float altSurface = ((double)x.e < limO) ? (float)limO : x.e;
+            const bool sameSurface = std::memcmp(&altSurface, &x.surface, 4) == 0;
+            // pass 3 visits cells by ascending surface: both possible targets must be final when the cell's turn comes
+            const bool ordered = x.drain >= 0 && st[x.drain].surface < x.surface && st[ct.other].surface < x.surface;
+            if (kx > ct.level && sameSurface && ordered) { ++rep.openParents; rep.alt.push_back({ct.cell, ct.other}); }
+            else ++rep.unresolved;
+        }
+    }
+    T.lap("pass1 par");
+    if (T.on) std::fprintf(stderr, "[flood] landmasses %d, workers %d, tie groups %lld (nested %lld), contested %lld, open parents %lld, unresolved %lld\n",
+                           rep.landmasses, rep.workers, (long long)rep.groups, (long long)rep.nested, (long long)rep.contested, (long long)rep.openParents, (long long)rep.unresolved);
+    return rep.unresolved == 0;
+}
+
 // results of the device pass 1 (flood_kernels.h) into the host state of passes 2 and 3: parent in land-index space
 // (FL_NONE = -1 unreached, FL_SEED = -2 drains to the open ocean), surface, tree id (position of the tree's seed)
 void flood_import_pass1(const int32_t* par, const float* surface, const int32_t* root, FloodScratch& S) {
@@ -350,9 +529,20 @@ void flood_import_pass1(const int32_t* par, const float* surface, const int32_t*
 }
 
 // passes 2 and 3 (:152-214) on the state pass 1 left, then the land elevations back into e
-void flood_pass23_host(float* e, double carveStrength, FloodScratch& S) {
+bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const std::vector<std::pair<int32_t, int32_t>>* openAlt) {
     const double EPS = 1e-7;
     FloodTimer T;
+    // Cells whose parent pass 1 left open (equal keys, same surface under either parent).  The elevations do not depend
+    // on the choice when (i) no carve path runs through the cell — a path exists only below a deficit cell, so then the
+    // cell keeps its height through pass 2 and both parents see the same carves — and (ii) pass 3 leaves the cell alone
+    // under either parent (it stands above both parents' final heights).  Checked after pass 3; otherwise: false.
+    const bool track = openAlt && !openAlt->empty();
+    uint8_t* onPath = nullptr;
+    if (track) {
+        S.onPath.resize(S.L);
+        onPath = S.onPath.data();
+        parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { std::memset(onPath + b, 0, (size_t)(en - b)); });
+    }
     const bool timing = T.on;
     const int32_t L = S.L;
     const int32_t* landCell = S.landCell.data();
@@ -443,6 +633,7 @@ void flood_pass23_host(float* e, double carveStrength, FloodScratch& S) {
                 path.push_back(cur);
                 if ((double)eL[cur] > peakElev) { peakElev = eL[cur]; peakIdx = (int32_t)path.size() - 1; }
             }
+            if (onPath) for (int32_t c : path) onPath[c] = 1;
             const int32_t len = (int32_t)path.size();
             myLen += len;
             if (peakIdx < 0) continue;
@@ -495,17 +686,59 @@ void flood_pass23_host(float* e, double carveStrength, FloodScratch& S) {
     });
     if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
     T.lap("pass2+3");
+    if (track) {
+        for (const auto& oa : *openAlt) {
+            const int32_t x = oa.first, p0 = st[x].drain, p1 = oa.second;
+            const bool untouched = !onPath[x] && std::memcmp(&eL[x], &st[x].e, 4) == 0;
+            const double h = (double)st[x].e;
+            if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) return false;
+        }
+    }
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
+    return true;
+}
+
+// gather + pass 1 + passes 2/3 on the host.  Pass 1 runs one heap per landmass on the tree workers; when that cannot
+// vouch for the single heap's result (FloodTieReport) the serial walk redoes it.  WO_FLOOD_HOST=serial skips the attempt.
+void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHostStats* stats) {
+    static const bool serialOnly = [] { const char* v = std::getenv("WO_FLOOD_HOST"); return v && std::string(v) == "serial"; }();
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    FloodHostStats local;
+    FloodHostStats& st = stats ? *stats : local;
+    ++st.calls;
+    flood_gather(e, S);
+    bool done = false;
+    if (!serialOnly) {
+        FloodTieReport rep;
+        auto t0 = clock::now();
+        const bool exact = flood_pass1_landmasses(S, rep);
+        auto t1 = clock::now();
+        st.pass1Ms += ms(t0, t1);
+        st.tieGroups += rep.groups; st.contested += rep.contested; st.openParents += rep.openParents; st.unresolved += rep.unresolved;
+        if (exact) {
+            done = flood_pass23_host(e, carveStrength, S, &rep.alt);
+            st.pass23Ms += ms(t1, clock::now());
+            if (!done) ++st.pathRedo;
+        }
+        if (!done) flood_gather(e, S);
+    }
+    if (!done) {
+        auto t0 = clock::now();
+        flood_pass1_host(S);
+        auto t1 = clock::now();
+        flood_pass23_host(e, carveStrength, S);
+        st.pass1Ms += ms(t0, t1); st.pass23Ms += ms(t1, clock::now());
+        ++st.serialPass1;
+    }
 }
 
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S) {
     if (!S.staticValid || S.staticN != N) flood_build_static(N, off, adj, xyz, ocean, S);
     if (S.L == 0) return;
-    flood_gather(e, S);
-    flood_pass1_host(S);
-    flood_pass23_host(e, carveStrength, S);
+    flood_host_passes(e, carveStrength, S, nullptr);
 }
 
 }  // namespace wo

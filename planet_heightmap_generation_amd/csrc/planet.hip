@@ -295,7 +295,7 @@ struct StageClock {
 // those by its array mechanics); the decisions that did are counted and, unless WO_FLOOD_TIES=id accepts the cell-id
 // order, pass 1 is redone on the host.
 // ---------------------------------------------------------------------------------------------------
-struct FloodRun { double deviceMs = 0; int64_t rounds = 0, epochs = 0, evals = 0, ties = 0; bool usedDevice = false, fellBack = false; };
+struct FloodRun { double deviceMs = 0; int64_t rounds = 0, epochs = 0, evals = 0, ties = 0; bool usedDevice = false, fellBack = false; FloodHostStats host; };
 
 static void flood_gpu_free(wo_flood_gpu& G) {
     dfree(G.off); dfree(G.adj); dfree(G.cell); dfree(G.seedIdx); dfree(G.seeds); dfree(G.nz); dfree(G.e);
@@ -430,12 +430,14 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     const bool useDevice = !hostOnly && flood_device_pass1(p, R);       // synchronises the stream
     if (hostOnly) WO_HIP(hipStreamSynchronize(s));
     lap(hostOnly ? "D2H" : "device pass1");
-    flood_gather(p->h_pinned, S);
-    if (useDevice) flood_import_pass1(p->fgpu.h_par, p->fgpu.h_surf, p->fgpu.h_root, S);
-    else flood_pass1_host(S);
-    lap(useDevice ? "import" : "host pass1");
-    flood_pass23_host(p->h_pinned, carveStrength, S);
-    lap("host pass2+3");
+    if (useDevice) {
+        flood_gather(p->h_pinned, S);
+        flood_import_pass1(p->fgpu.h_par, p->fgpu.h_surf, p->fgpu.h_root, S);
+        flood_pass23_host(p->h_pinned, carveStrength, S);
+    } else {
+        flood_host_passes(p->h_pinned, carveStrength, S, &R.host);
+    }
+    lap(useDevice ? "import + host pass2+3" : "host passes");
     WO_HIP(hipMemcpyAsync(p->d_e, p->h_pinned, bytes, hipMemcpyHostToDevice, s));
     if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("H2D"); }
 }
@@ -649,7 +651,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"carve_rounds_total", (double)carveRounds}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
                      {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
-                     {"flood_pass1_on_host", (floodRun.usedDevice && !floodRun.fellBack) ? 0.0 : 1.0}};
+                     {"flood_pass1_on_host", (floodRun.usedDevice && !floodRun.fellBack) ? 0.0 : 1.0},
+                     {"flood_host_calls", (double)floodRun.host.calls}, {"flood_host_serial_pass1", (double)floodRun.host.serialPass1},
+                     {"flood_host_tie_groups", (double)floodRun.host.tieGroups}, {"flood_host_contested", (double)floodRun.host.contested},
+                     {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
+                     {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
+                     {"flood_host_pass23_ms", floodRun.host.pass23Ms}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {

@@ -28,6 +28,21 @@ struct FloodScratch {
     hvec<int32_t> root, order, order2, list2;
     hvec<uint32_t> bits, bits2;
     hvec<FloodHeapItem> heapStore;
+    // landmasses of the compact land graph (static per mask): pass 1 walks them concurrently (flood_pass1_landmasses)
+    hvec<int32_t> compSeeds;                 // seed positions (indices into seedCell) grouped by landmass, ascending inside
+    std::vector<int32_t> compSeedStart;      // compSeeds range per seeded landmass, landmasses in descending size
+    std::vector<int32_t> compSize;
+    hvec<int32_t> stamp;                     // tie-family id of the claim that reached a cell (0 = outside any tie group)
+    hvec<uint8_t> onPath;                    // pass 2: the cell lay on a carve path (only tracked when pass 1 left open parents)
+    std::vector<hvec<FloodHeapItem>> workerHeaps;
+};
+// What the landmass-parallel pass 1 reports.  A cell is "contested" when two cells with EQUAL keys that sat in the heap
+// together (and their sub-key cascades) both reached it: which one claims it is decided by the array history of the
+// reference's single heap, which separate heaps cannot know.
+struct FloodTieReport {
+    int64_t groups = 0, nested = 0, contested = 0, openParents = 0, unresolved = 0;
+    int32_t landmasses = 0, workers = 0;
+    std::vector<std::pair<int32_t, int32_t>> alt;      // (cell, alternative parent) where only drainTo is undecided
 };
 // (re)builds the mask-dependent tables (Morton-ordered land list `landCell`, compact CSR, seeds)
 void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S);
@@ -38,8 +53,16 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
 void flood_cell_noise(const FloodScratch& S, double* out);            // cellNoise per land cell, compact order
 void flood_gather(const float* e, FloodScratch& S);                   // land elevations -> compact arrays, pass-1 start state
 void flood_pass1_host(FloodScratch& S);                               // serial heap walk (reference order incl. heap tie mechanics)
+// One heap per landmass, landmasses concurrently; equal-key decisions that could differ from the single heap's are
+// detected (FloodTieReport).  Returns false when one of them changes surfaces/keys: the caller redoes pass 1 serially.
+bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep);
+// pass 1 (landmass-parallel when exact, else the serial walk) + passes 2/3; stats: see flood_host.cc
+struct FloodHostStats { int64_t calls = 0, serialPass1 = 0, tieGroups = 0, contested = 0, openParents = 0, unresolved = 0, pathRedo = 0; double pass1Ms = 0, pass23Ms = 0; };
+void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHostStats* stats);
 void flood_import_pass1(const int32_t* par, const float* surface, const int32_t* root, FloodScratch& S);
-void flood_pass23_host(float* e, double carveStrength, FloodScratch& S);
+// openAlt: cells whose parent pass 1 could not decide between equal keys (same surface either way); returns false when
+// the carve / fix-up result depends on that choice (nothing is written back to e then)
+bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const std::vector<std::pair<int32_t, int32_t>>* openAlt = nullptr);
 
 // plates_host.cc — js/plates.js:241-348 (r_plate rewritten in place; plateSeeds in the Set's iteration order)
 void smooth_reconnect_plates_host(int32_t N, const int32_t* off, const int32_t* adj, int32_t* r_plate, int32_t numSeeds,

@@ -283,6 +283,28 @@ extern "C" void emu_warp(int32_t N, const int32_t* off, const int32_t* adj, floa
     std::memcpy(e, out.data(), sizeof(float) * (size_t)N);
 }
 
+// priorityFloodCarve through the host stage's two pass-1 routes.  mode 0: the serial heap walk; mode 1: one heap per
+// landmass with the tie-group checks (falls back to the serial walk when it cannot vouch for the result).
+// stats: [calls, serialPass1, tieGroups, contested, openParents, unresolved, pathRedo, pass1Ms, pass23Ms]
+extern "C" void emu_flood_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, const uint8_t* ocean, double cs,
+                               int32_t mode, int32_t repeats, double* stats) {
+    FloodScratch S;
+    flood_build_static(N, off, adj, xyz, ocean, S);
+    if (S.L == 0) return;
+    FloodHostStats hs;
+    std::vector<float> e0(e, e + N);
+    for (int32_t k = 0; k < (repeats < 1 ? 1 : repeats); ++k) {
+        std::memcpy(e, e0.data(), sizeof(float) * (size_t)N);
+        if (mode == 0) { ++hs.calls; ++hs.serialPass1; flood_gather(e, S); flood_pass1_host(S); flood_pass23_host(e, cs, S); }
+        else flood_host_passes(e, cs, S, &hs);
+    }
+    if (stats) {
+        const double v[9] = {(double)hs.calls, (double)hs.serialPass1, (double)hs.tieGroups, (double)hs.contested, (double)hs.openParents,
+                             (double)hs.unresolved, (double)hs.pathRedo, hs.pass1Ms, hs.pass23Ms};
+        for (int i = 0; i < 9; ++i) stats[i] = v[i];
+    }
+}
+
 extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, float* e, const uint8_t* ocean, double cs) {
     FloodScratch fs;
     priority_flood_carve_host(N, off, adj, nullptr, e, ocean, cs, fs);
