@@ -26,7 +26,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -242,17 +242,24 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
     constexpr int DBG_W = 8, DBG_N = 512;
     int32_t* dbg = nullptr;
     if (statsIter >= 0 && p->solveCalls++ == statsIter) { WO_HIP(hipMalloc(&dbg, DBG_N * DBG_W * sizeof(int32_t))); WO_HIP(hipMemsetAsync(dbg, 0, DBG_N * DBG_W * sizeof(int32_t), s)); }
+    int64_t need = 0;
     for (int32_t tag = 1;; ) {
-        // The pending total is read back (one stream sync) after every burst.  The launch count barely changes from one
-        // erosion iteration to the next, so the first burst is sized by the previous count; then small bursts to finish.
-        const int burst = (tag == 1) ? std::max<int>(1, (int)p->lastPatchLaunches - 1) : 3;
+        // The pending totals are read back (one stream sync) after every burst.  The number of launches a pass needs barely
+        // changes from one erosion iteration to the next, so the first burst is the previous need plus one; then small bursts.
+        // Launches after the one that emptied the list find nothing pending and return at once.
+        const int32_t first = tag;
+        const int burst = (tag == 1) ? std::max<int>(1, (int)std::min<int64_t>(p->lastPatchLaunches, WO_PATCH_TOTAL_SLOTS / 2)) : 3;
         for (int b = 0; b < burst; ++b, ++tag) {
             if (tag % WO_PATCH_TOTAL_SLOTS == 0) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: slots are free again (stream order)
             launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
                    dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)spinCap);
             ++launches;
         }
-        if (read_count(p, tot + ((tag - 1) % WO_PATCH_TOTAL_SLOTS)) == 0) break;
+        static_assert(WO_PATCH_TOTAL_SLOTS <= WO_MAX_LEVEL + 2, "h_levelStart doubles as the read-back buffer of the pending totals");
+        WO_HIP(hipMemcpyAsync(p->h_levelStart, tot, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        WO_HIP(hipStreamSynchronize(s));
+        for (int32_t t = first; t < tag && !need; ++t) if (p->h_levelStart[t % WO_PATCH_TOTAL_SLOTS] == 0) need = t;
+        if (need) break;
         if (launches > 4 * (int64_t)p->N + 1024) throw HipError{"patch solve does not converge"};
     }
     if (dbg) {
@@ -262,8 +269,8 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         fprintf(stderr, "solve stats: %d patches of %d, %d tasks, %lld launches, spin cap %d\nlaunch idle_visits running_visits runnable completed max_passes\n", np, WO_PATCH, p->L, (long long)launches, spinCap);
         for (int t = 1; t <= std::min<int64_t>(launches, DBG_N - 1); ++t) { const int32_t* q = &h[DBG_W * t]; fprintf(stderr, "%d %d %d %d %d %d\n", t, q[0], q[1], q[2], q[3], q[4]); }
     }
-    p->lastPatchLaunches = launches;
-    return launches;
+    p->lastPatchLaunches = need + 1;
+    return need;
 }
 
 struct StageClock {
@@ -523,9 +530,15 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const double gCarve = 0.02 * gScale, gConv = 0.01 * gScale, gDep = 0.005 * gScale, gFjord = 0.015 * gScale;
     const int32_t midIter = (int32_t)std::floor(total * 0.75 + 0.5);
     bool midDone = false;
+    // WO_RIVER_PATCHES=<n>: rebuild the patch list along the drainage forest every n-th pass.  Default 0 = spatial (Morton)
+    // patches: measured at 10 M cells the river list needs 17 launches per pass instead of 54 when rebuilt every pass, but
+    // its visits hold one long chain each instead of ~40 short ones (77 us per launch against 32), rebuilding costs 1.3 ms,
+    // and a list that is one pass old already needs 28 launches (profiles/r02c_river_patch_experiment.txt).
+    static const int riverEvery = getenv("WO_RIVER_PATCHES") ? atoi(getenv("WO_RIVER_PATCHES")) : 0;
+    int sinceRiver = -1;
 
     for (int32_t iter = 0; iter < total; ++iter) {
-        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
+        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); sinceRiver = -1; }
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
         if (gNow || hNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
 
@@ -608,10 +621,19 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, F, p->d_flowCnt);
             clk.end();
             clk.begin("solve");
+            // the solve's patch list follows the drainage forest (river.hip); the forest drifts slowly, so the list is
+            // rebuilt every riverEvery-th pass and right after a flood (which re-routes whole basins)
+            if (riverEvery > 0 && p->patchVersion >= 0 && (sinceRiver >= riverEvery || sinceRiver < 0)) {
+                river_patch_slots(p);
+                p->patchVersion = 0;            // not the Morton list any more: the next erodeComposite starts from it again
+                sinceRiver = 0; ++p->riverRefreshes;
+            }
+            ++sinceRiver;
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
                 const int64_t r = run_solve_patches(p, F, K, m, dt);
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
+                if (getenv("WO_SOLVE_TRACE")) fprintf(stderr, "iter %d: %lld patch launches\n", iter, (long long)r);
             } else {
                 const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
@@ -825,6 +847,7 @@ void wo_planet_destroy(wo_planet* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     flood_gpu_free(p->fgpu);
+    river_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
