@@ -42,7 +42,10 @@ constexpr int32_t WO_NOT_DONE = 0x7fffffff;
 // index order, by solve_setup; a round then costs: task record -> <=3 predecessor granules.
 // Records are stored at the task's *store index*: the cell id, or — for the patch-local solve — the cell's slot in
 // the Morton-ordered patch list, so that a patch's records are contiguous (Fields::slotOf, store_index()).
-struct alignas(16) SolveTask {
+#ifndef WO_TASK_ALIGN
+#define WO_TASK_ALIGN 16                // 64 (whole blocks per scattered write) measured no faster at 10 M cells
+#endif
+struct alignas(WO_TASK_ALIGN) SolveTask {
     int32_t predSelf, predT, predT2;   // granule index 2*store + (0: that task's own turn, 1: its deposit on its receiver), -1: none
     uint32_t flags;                    // bit0: target is ocean, bit1: t2 is ocean, bit2: has a target, bit3: has a t2
     float e0r, e0t, e0t2;              // heights before the pass (used where there is no predecessor event)
@@ -60,6 +63,14 @@ struct alignas(16) SolveOut { Granule self, dep; };
 
 // {drainTarget, rank} of a cell in one 8-byte word: the solve's setup/final passes ask both of every neighbour
 struct alignas(8) TargetRank { int32_t target; int32_t rank; };
+// Events on one location x during the solve pass, in processing order (descending rank): x's own turn and the deposits
+// of its donors.  Built once per pass by the flow accumulation's last kernel (which has x's row and the {target, rank} of
+// its neighbours in registers anyway); solve_setup then finds a task's <=3 predecessor events in the 32-byte lists of
+// r, its receiver and the receiver's receiver instead of re-reading three neighbour rows (24 gathers), and solve_final
+// reads the latest event off the end of the list.  Locations with more than WO_EVENTS events (own turn + >3 donors:
+// ~1 % of the cells) carry the overflow mark and take the row scans.
+constexpr int WO_EVENTS = 4;
+struct alignas(16) EventList { int32_t cell[WO_EVENTS]; int32_t rank[WO_EVENTS]; };     // unused slots: rank -1; overflow: rank[0] == -2
 constexpr int WO_CARVE_DEPS = 16;       // dependency slots per active carve task
 struct Fields {
     int32_t N;                 // numRegions
@@ -90,6 +101,7 @@ struct Fields {
     const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean [N]; nullptr: store index = cell
     SolveOut* out;                      // per-task event outputs {own turn, deposit on receiver} [N], at the store index
     int32_t* blk;                       // patch solve: granule that was seen unresolved when the task last failed, or -1 [N], at the store index
+    EventList* ev;                      // events per location [N] (land entries written by flow_final_cell); nullptr: row scans
     int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]
     // thermal
     double* totalExcess;                // [N]
@@ -311,6 +323,58 @@ WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
     return (F.rank[r] < F.rank[t]) ? t : -1;
 }
 
+// final flow of land cell c (js/terrain-post.js:604-611): its forwarded total plus the totals of its late donors (ranked
+// after c: the serial loop adds them to flow[c] after c has already passed its own total on), and the event list of c.
+WO_HD inline void event_insert(EventList& E, int& n, bool& over, int32_t cell, int32_t rank) {
+    if (n == WO_EVENTS) { over = true; return; }
+    int k = n++;
+#pragma unroll
+    for (int q = WO_EVENTS - 1; q > 0; --q)                 // descending rank; ranks of land cells are distinct
+        if (q <= k && E.rank[q - 1] < rank) { E.cell[q] = E.cell[q - 1]; E.rank[q] = E.rank[q - 1]; k = q - 1; }
+    E.cell[k] = cell; E.rank[k] = rank;
+}
+WO_HD inline void flow_final_cell(const Fields& F, int32_t c) {
+    uint32_t f = F.accA[c];
+    const TargetRank trc = F.tr[c];
+    const int32_t rc = trc.rank;
+    EventList E;
+#pragma unroll
+    for (int q = 0; q < WO_EVENTS; ++q) { E.cell[q] = -1; E.rank[q] = -1; }
+    int n = 0; bool over = false;
+    if (trc.target >= 0) event_insert(E, n, over, c, rc);
+    int32_t b, nbs[WO_ROW];
+    const int deg = load_row(F, c, b, nbs);
+    if (deg <= WO_ROW) {
+        TargetRank q[WO_ROW];
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) q[k] = F.tr[nbs[k]];                        // ocean cells carry target -1
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) {
+            if (k < deg && q[k].target == c) {
+                if (q[k].rank > rc) f += F.accA[nbs[k]];                              // late donor, un-forwarded
+                event_insert(E, n, over, nbs[k], q[k].rank);
+            }
+        }
+    } else {
+        for (int32_t j = b; j < b + deg; ++j) {
+            const int32_t nb = F.adj[j];
+            const TargetRank v = F.tr[nb];
+            if (v.target != c) continue;
+            if (v.rank > rc) f += F.accA[nb];
+            event_insert(E, n, over, nb, v.rank);
+        }
+    }
+    F.flow[c] = (float)f;
+    if (F.ev) { if (over) E.rank[0] = -2; F.ev[c] = E; }
+}
+// latest event on the list's location strictly before the turn of task r (rank rr), r's own events excluded; -1: none
+WO_HD inline int32_t event_before(const EventList& E, int32_t r, int32_t rr) {
+    int32_t best = -1;
+#pragma unroll
+    for (int q = 0; q < WO_EVENTS; ++q) if (E.rank[q] > rr && E.cell[q] != r) best = E.cell[q];     // descending ranks: the last hit is the closest
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hydraulic: implicit solve + deposition as dataflow (js/terrain-post.js:614-641)
 // Processing time of a land cell: tau = -rank (the serial loop walks landCells backwards), so
@@ -349,7 +413,53 @@ WO_HD inline int32_t store_index(const Fields& F, int32_t cell) { return F.slotO
 WO_HD inline int32_t granule_index(const Fields& F, int32_t x, int32_t p) { return p < 0 ? -1 : 2 * store_index(F, p) + (p == x ? 0 : 1); }
 
 WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r);
+WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r);
+// setup from the event lists (flow_final_cell); any list involved overflowed -> the row scans
 WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
+    if (F.ocean[r]) return;
+    if (!F.ev) { solve_setup_cell_rows(F, r); return; }
+    const TargetRank trr = F.tr[r];
+    const int32_t t = trr.target, rr = trr.rank;
+    const EventList Er = F.ev[r];
+    TargetRank trt; trt.target = -1; trt.rank = -1;
+    if (t >= 0) trt = F.tr[t];
+    const bool tLand = t >= 0 && trt.rank >= 0;                     // ocean cells carry rank -1
+    EventList Et, Et2; Et.rank[0] = -1; Et2.rank[0] = -1;
+    float cdT = 0.0f;
+    if (tLand) { Et = F.ev[t]; cdT = F.cellDist[t]; }
+    const int32_t t2 = (tLand && trt.target >= 0 && cdT > 0) ? trt.target : -1;
+    TargetRank trt2; trt2.target = -1; trt2.rank = -1;
+    if (t2 >= 0) trt2 = F.tr[t2];
+    const bool t2Land = t2 >= 0 && trt2.rank >= 0;
+    if (t2Land) Et2 = F.ev[t2];
+    if (Er.rank[0] == -2 || Et.rank[0] == -2 || Et2.rank[0] == -2) { solve_setup_cell_plain(F, r); return; }
+    SolveTask T;
+    T.predSelf = granule_index(F, r, event_before(Er, r, rr));
+    T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
+    T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
+    T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
+    if (t >= 0) {
+        T.flags |= 4u;
+        T.e0t = F.e[t];
+        if (!tLand) T.flags |= 1u;
+        else {
+            T.predT = granule_index(F, t, event_before(Et, r, rr));
+            T.cellDistT = cdT;
+            if (t2 >= 0) {
+                T.flags |= 8u;
+                T.e0t2 = F.e[t2];
+                if (!t2Land) T.flags |= 2u;
+                else T.predT2 = granule_index(F, t2, event_before(Et2, r, rr));
+            }
+        }
+    }
+    const int32_t si = store_index(F, r);
+    F.task[si] = T;
+    SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
+    F.out[si] = z;
+    if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+}
+WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r) {
     if (F.ocean[r]) return;
     // batched form: rows of r, of its receiver t and of t's receiver t2 first, then every neighbour's {target, rank}
     const TargetRank trr = F.tr[r];
@@ -485,6 +595,16 @@ WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K
 // final height of land cell x after the pass = value left by the latest event on x
 WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
     if (F.ocean[x]) return F.e[x];
+    if (F.ev) {
+        const EventList E = F.ev[x];
+        if (E.rank[0] != -2) {
+            int32_t last = -1;
+#pragma unroll
+            for (int q = 0; q < WO_EVENTS; ++q) if (E.rank[q] >= 0) last = E.cell[q];           // descending ranks: the last one is the latest
+            if (last < 0) return F.e[x];
+            return (last == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, last)].dep.v;
+        }
+    }
     int32_t best = -1, bestRank = 0x7fffffff;      // latest == smallest rank
     { const TargetRank v = F.tr[x]; if (v.target >= 0) { best = x; bestRank = v.rank; } }
     int32_t b, nbs[WO_ROW];

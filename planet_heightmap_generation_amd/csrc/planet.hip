@@ -55,7 +55,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
-    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_ev = dalloc<EventList>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
@@ -76,7 +76,7 @@ static void ensure_scratch(wo_planet* p) {
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = (getenv("WO_NO_EVENT_LISTS") == nullptr) ? d_ev : nullptr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -575,6 +575,34 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 if (count > 0) launch(p, FAM_CARVE_SETUP, k_carve_pairs_init, blocks_for(count), WO_BLOCK, (const int32_t*)p->d_listB, (const int32_t*)(c + 1), p->d_carvePairs[0]);
                 int64_t k = 1;
                 int cur = 0;
+                // WO_PERSISTENT_ROUNDS=1: all rounds in one cooperative launch with a grid barrier (k_carve_rounds_persistent).
+                // Measured slower at 10 M cells and therefore off: 168 ms per step at the best grid (128 workgroups; 258 / 188 /
+                // 190 ms with 32 / 64 / 256) against 122 ms for one launch per round — a round is bound by its chain of dependent
+                // loads, which a wide launch overlaps across more workgroups, not by the launch itself
+                // (profiles/r02f_persistent_rounds_grid.txt).
+                static const bool persistentRounds = getenv("WO_PERSISTENT_ROUNDS") != nullptr;
+                if (count > 0 && persistentRounds) {
+                    // one cooperative launch walks every round (k_carve_rounds_persistent); the grid must be resident as a whole
+                    static int perCu = 0;
+                    if (!perCu) { WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_carve_rounds_persistent, WO_BLOCK, 0)); if (perCu < 1) perCu = 1; }
+                    static const int roundGrid = getenv("WO_ROUND_GRID") ? std::max(1, atoi(getenv("WO_ROUND_GRID"))) : 128;
+                    const int grid = std::max(1, std::min(std::min(perCu * p->ctx->prop.multiProcessorCount, roundGrid), blocks_for(count)));
+                    int2* la = p->d_carvePairs[0]; int2* lb = p->d_carvePairs[1];
+                    int32_t maxRounds = (int32_t)std::min<int64_t>(4 * (int64_t)p->N + 1024, 0x7ffffff0);
+                    int32_t* status = c + 4; int32_t* bar = c + 6;
+                    WO_HIP(hipMemsetAsync(bar, 0, sizeof(int32_t), s));
+                    double gc = gCarve, gv = gConv, gs = gStrength;
+                    void* args[] = {(void*)&F, (void*)&la, (void*)&lb, (void*)&c, (void*)&maxRounds, (void*)&gc, (void*)&gv, (void*)&gs, (void*)&status, (void*)&bar};
+                    hipEvent_t ea = nullptr, eb = nullptr;
+                    if (p->profiling) { ea = profile_event(p); eb = profile_event(p); WO_HIP(hipEventRecord(ea, s)); }
+                    WO_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_carve_rounds_persistent), dim3(grid), dim3(WO_BLOCK), args, 0, s));
+                    if (p->profiling) { WO_HIP(hipEventRecord(eb, s)); p->pending.push_back({FAM_CARVE_ROUND, ea, eb}); }
+                    WO_HIP(hipMemcpyAsync(p->h_count, status, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+                    WO_HIP(hipStreamSynchronize(s));
+                    if (p->h_count[1] != 0) throw HipError{"carve rounds do not converge"};
+                    k = (int64_t)p->h_count[0] + 1;
+                    count = 0;
+                }
                 while (count > 0) {
                     const int grid = blocks_for(count, 2048);
                     for (int b = 0; b < 16; ++b, ++k) {
@@ -850,7 +878,7 @@ void wo_planet_destroy(wo_planet* p) {
     river_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

@@ -25,6 +25,7 @@ struct Emu {
     std::vector<SolveTask> task; std::vector<SolveOut> out;
     std::vector<int32_t> land, landIdx, rank, target, jumpA, doneAt, iceTarget, arank, blocker, blk;
     std::vector<TargetRank> tr;
+    std::vector<EventList> ev;
     std::vector<float> me;
     std::vector<uint32_t> accA;
     std::vector<double> totalExcess;
@@ -153,7 +154,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
     F.e2 = E.e2.data(); F.rank = E.rank.data(); F.target = E.target.data(); F.cellDist = E.cellDist.data();
     F.flow = E.flow.data(); F.accA = E.accA.data(); F.jumpA = E.jumpA.data(); F.task = E.task.data(); F.out = E.out.data();
     F.doneAt = E.doneAt.data(); F.totalExcess = E.totalExcess.data(); F.glac = E.glac.data();
-    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data(); E.blocker.assign(N, -1); F.blocker = E.blocker.data(); E.blk.assign(N, -1); F.blk = E.blk.data(); E.tr.assign(N, TargetRank{-1, -1}); F.tr = E.tr.data(); E.me.assign(N, 0.f); F.me = E.me.data();
+    F.iceTarget = E.iceTarget.data(); F.iceFlow = E.iceFlow.data(); F.iceUp = E.iceUp.data(); F.arank = E.arank.data(); E.blocker.assign(N, -1); F.blocker = E.blocker.data(); E.blk.assign(N, -1); F.blk = E.blk.data(); E.tr.assign(N, TargetRank{-1, -1}); F.tr = E.tr.data(); E.ev.resize(N); F.ev = std::getenv("WO_NO_EVENT_LISTS") ? nullptr : E.ev.data(); E.me.assign(N, 0.f); F.me = E.me.data();
     F.coast = E.coast.data();
     for (int32_t r = 0; r < N; ++r) E.coast[r] = coast_flag(F, r);
     for (int32_t r = 0; r < N; ++r) if (!ocean[r]) E.land.push_back(r);
@@ -217,12 +218,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
             }
             for (int32_t c = 0; c < N; ++c) {
                 if (ocean[c]) { F.flow[c] = 0; continue; }
-                uint32_t f = F.accA[c];
-                for (int32_t j = off[c]; j < off[c + 1]; ++j) {
-                    const int32_t n = adj[j];
-                    if (!ocean[n] && F.target[n] == c && F.rank[n] > F.rank[c]) f += F.accA[n];
-                }
-                F.flow[c] = (float)f;
+                flow_final_cell(F, c);                      // flow + the event list of c (k_flow_final)
             }
             for (int32_t r = 0; r < N; ++r) solve_setup_cell(F, r);
             int64_t n3 = usePatches ? run_solve_patches_emu(E, F.L, K, m, dt) : run_solve_rounds_pred(E, level, K, m, dt);

@@ -101,3 +101,24 @@ def test_flood_open_ocean_choice(emu, oracle):
         e = e0.copy()
         emu.emu_flood(N, P(mesh.adjOffset), P(mesh.adjList), P(e), P(oc), 0.5)
         assert np.array_equal(e, ref), (i, int((e != ref).sum()))
+
+
+def test_solve_event_lists_equal_row_scans(emu, oracle, monkeypatch):
+    """solve_setup / solve_final from the per-location event lists (flow_final_cell) and from the neighbour-row scans
+    (WO_NO_EVENT_LISTS) are the same dataflow: both equal the oracle, on terrain with flats and cells that have more
+    donors than a list holds."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(30000, 0.75, 9)
+    e0 = oracle.synthetic_terrain(xyz, 9)
+    eq = (np.round(e0 * 256) / 256).astype(np.float32)
+    oc = (eq <= 0).astype(np.uint8)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    ref = oracle.erode_composite(om, eq, xyz, oc, 9, 3e-4, 0.5, 1.0, 9, 1.16, 0.015, 0, 0.8, nd)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("WO_NO_EVENT_LISTS", "1")
+        e = eq.copy()
+        stats = np.zeros(8)
+        rc = emu.emu_erode_composite(mesh.numRegions, P(mesh.adjOffset), P(mesh.adjList), P(e), P(xyz), P(oc), 9, 3e-4, 0.5, 1.0, 9,
+                                     1.16, 0.015, 0, 0.8, P(nd), P(stats))
+        assert rc == 0 and np.array_equal(e, ref), (off, int((e != ref).sum()))
