@@ -267,6 +267,20 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
             if (k == 0 || comp[S.seedCell[ord[k]]] != comp[S.seedCell[ord[k - 1]]]) { S.compSeedStart.push_back(k); S.compSize.push_back(size[comp[S.seedCell[ord[k]]]]); }
         S.compSeedStart.push_back(nS);
         S.stamp.resize(L);
+        // per seeded landmass: its cells in ascending original id (the order pass 2 is defined in), and each seed's position
+        // among its landmass's seeds (= local tree number)
+        const int32_t nComp = (int32_t)S.compSize.size();
+        std::vector<int32_t> compIndex(L, -1);               // by component root
+        S.seedLocal.assign(nS, 0);
+        for (int32_t k = 0; k < nComp; ++k) {
+            compIndex[comp[S.seedCell[ord[S.compSeedStart[k]]]]] = k;
+            for (int32_t q = S.compSeedStart[k]; q < S.compSeedStart[k + 1]; ++q) S.seedLocal[ord[q]] = q - S.compSeedStart[k];
+        }
+        S.compCellStart.assign(nComp + 1, 0);
+        for (int32_t k = 0; k < nComp; ++k) S.compCellStart[k + 1] = S.compCellStart[k] + S.compSize[k];
+        S.compCells.resize(S.compCellStart[nComp]);
+        std::vector<int32_t> pos(S.compCellStart.begin(), S.compCellStart.end() - 1);
+        for (int32_t q = 0; q < L; ++q) { const int32_t i = S.landByR[q]; const int32_t k = compIndex[comp[i]]; if (k >= 0) S.compCells[pos[k]++] = i; }
     }
     lap("landmasses");
     S.staticValid = true;
@@ -528,6 +542,79 @@ void flood_import_pass1(const int32_t* par, const float* surface, const int32_t*
     });
 }
 
+// Passes 2 and 3 of one drainage tree (:152-214).  cells: the tree's land indices in ascending ORIGINAL id (the order pass 2
+// visits them in); on return sorted by (surface, id), the order of pass 3.  surface may be null (then st[].surface).
+namespace {
+struct TreeCtx { const FloodCell* st; float* eL; const float* surface; double carveStrength; uint8_t* onPath; };
+void tree_pass23(const TreeCtx& X, int32_t* cells, int32_t n, std::vector<int32_t>& path, int64_t& lenSum, int64_t& nDeficit) {
+    const double EPS = 1e-7;
+    const FloodCell* st = X.st;
+    float* eL = X.eL;
+    const double carveStrength = X.carveStrength;
+    uint8_t* onPath = X.onPath;
+    auto surf = [&](int32_t i) { return X.surface ? X.surface[i] : st[i].surface; };
+    for (int32_t q = 0; q < n; ++q) {
+        const int32_t r = cells[q];
+        const double deficit = (double)surf(r) - (double)eL[r];      // against the CURRENT height (:154)
+        if (deficit <= EPS) continue;
+        ++nDeficit;
+        path.clear();
+        int32_t peakIdx = -1;
+        double peakElev = -INFINITY;
+        for (int32_t cur = r; cur >= 0; cur = st[cur].drain) {
+            path.push_back(cur);
+            if ((double)eL[cur] > peakElev) { peakElev = eL[cur]; peakIdx = (int32_t)path.size() - 1; }
+        }
+        if (onPath) for (int32_t c : path) onPath[c] = 1;
+        const int32_t len = (int32_t)path.size();
+        lenSum += len;
+        if (peakIdx < 0) continue;
+        const double carveAmount = deficit * carveStrength;
+        const double rc = std::ceil((double)len * 0.3);
+        const int32_t radius = rc > 3.0 ? (int32_t)rc : 3;
+        const int32_t k0 = peakIdx - radius > 0 ? peakIdx - radius : 0;
+        const int32_t k1 = peakIdx + radius < len - 1 ? peakIdx + radius : len - 1;
+        double kernelSum = 0;
+        for (int32_t k = k0; k <= k1; ++k) kernelSum += 1 - std::fabs((double)(k - peakIdx)) / (radius + 1);
+        if (kernelSum > 0) {
+            for (int32_t k = k0; k <= k1; ++k) {
+                const double w = (1 - std::fabs((double)(k - peakIdx)) / (radius + 1)) / kernelSum;
+                float v = (float)((double)eL[path[k]] - carveAmount * w);
+                if (v < 0) v = 0;
+                eL[path[k]] = v;
+            }
+        }
+        eL[r] = (float)((double)eL[r] + deficit * (1 - carveStrength));
+    }
+    // --- pass 3 for this tree (:199-214): its cells by ascending surface, ties by ascending original id (the
+    // reference's stable sort of an ascending-id list), then the ordered fix-up.  The tree's cells are hot in cache.
+    if (n > 1) {
+        if (n <= 2048) {
+            std::stable_sort(cells, cells + n, [&](int32_t a, int32_t b) { return asc_bits(surf(a)) < asc_bits(surf(b)); });
+        } else {                                        // big trees: stable LSD radix on the key bits
+            std::vector<uint32_t> k0(n), k1(n); std::vector<int32_t> c1(n);
+            for (int32_t i = 0; i < n; ++i) k0[i] = asc_bits(surf(cells[i]));
+            uint32_t* ka = k0.data(); uint32_t* kb = k1.data(); int32_t* ca = cells; int32_t* cb = c1.data();
+            for (int pass = 0; pass < 3; ++pass) {
+                const int sh = pass * 11; const uint32_t mask = pass == 2 ? 1023u : 2047u;
+                uint32_t cnt[2049]; std::memset(cnt, 0, sizeof(cnt));
+                for (int32_t i = 0; i < n; ++i) cnt[((ka[i] >> sh) & mask) + 1]++;
+                for (int i = 0; i < 2048; ++i) cnt[i + 1] += cnt[i];
+                for (int32_t i = 0; i < n; ++i) { const uint32_t d = cnt[(ka[i] >> sh) & mask]++; kb[d] = ka[i]; cb[d] = ca[i]; }
+                std::swap(ka, kb); std::swap(ca, cb);
+            }
+            if (ca != cells) std::memcpy(cells, ca, sizeof(int32_t) * (size_t)n);     // 3 passes: result sits in c1
+        }
+    }
+    for (int32_t q = 0; q < n; ++q) {
+        const int32_t c = cells[q], t = st[c].drain;
+        if (t == NO_TARGET || t == UNVISITED) continue;
+        const double te = (t == TO_OCEAN) ? 0.0 : (double)eL[t];
+        if ((double)eL[c] <= te) eL[c] = (float)(te + EPS);
+    }
+}
+}  // namespace
+
 // passes 2 and 3 (:152-214) on the state pass 1 left, then the land elevations back into e
 bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const std::vector<std::pair<int32_t, int32_t>>* openAlt) {
     const double EPS = 1e-7;
@@ -617,74 +704,15 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
         for (auto& t : th) t.join();
     };
     T.lap("group2");
-    std::atomic<int64_t> nDef{0}, totLen{0};
+    std::atomic<int64_t> nDeficit{0}, totLen{0};
+    const TreeCtx ctx{st, eL, surface, carveStrength, onPath};
     for_trees(cnt2, [&](int32_t tree) {
-        std::vector<int32_t> path;
+        static thread_local std::vector<int32_t> path;
         int64_t myLen = 0, myDef = 0;
-        for (int32_t q = cnt2[tree]; q < cnt2[tree + 1]; ++q) {
-            const int32_t r = list2[q];
-            const double deficit = (double)surface[r] - (double)eL[r];      // against the CURRENT height (:154)
-            if (deficit <= EPS) continue;
-            ++myDef;
-            path.clear();
-            int32_t peakIdx = -1;
-            double peakElev = -INFINITY;
-            for (int32_t cur = r; cur >= 0; cur = st[cur].drain) {
-                path.push_back(cur);
-                if ((double)eL[cur] > peakElev) { peakElev = eL[cur]; peakIdx = (int32_t)path.size() - 1; }
-            }
-            if (onPath) for (int32_t c : path) onPath[c] = 1;
-            const int32_t len = (int32_t)path.size();
-            myLen += len;
-            if (peakIdx < 0) continue;
-            const double carveAmount = deficit * carveStrength;
-            const double rc = std::ceil((double)len * 0.3);
-            const int32_t radius = rc > 3.0 ? (int32_t)rc : 3;
-            const int32_t k0 = peakIdx - radius > 0 ? peakIdx - radius : 0;
-            const int32_t k1 = peakIdx + radius < len - 1 ? peakIdx + radius : len - 1;
-            double kernelSum = 0;
-            for (int32_t k = k0; k <= k1; ++k) kernelSum += 1 - std::fabs((double)(k - peakIdx)) / (radius + 1);
-            if (kernelSum > 0) {
-                for (int32_t k = k0; k <= k1; ++k) {
-                    const double w = (1 - std::fabs((double)(k - peakIdx)) / (radius + 1)) / kernelSum;
-                    float v = (float)((double)eL[path[k]] - carveAmount * w);
-                    if (v < 0) v = 0;
-                    eL[path[k]] = v;
-                }
-            }
-            eL[r] = (float)((double)eL[r] + deficit * (1 - carveStrength));
-        }
-        if (timing) { totLen += myLen; nDef += myDef; }
-        // --- pass 3 for this tree (:199-214): its cells by ascending surface, ties by ascending original id (the
-        // reference's stable sort of an ascending-id list), then the ordered fix-up.  The tree's cells are hot in cache.
-        const int32_t q0 = cnt2[tree], n = cnt2[tree + 1] - q0;
-        int32_t* cells = list2 + q0;                        // ascending original id
-        if (n > 1) {
-            if (n <= 2048) {
-                std::stable_sort(cells, cells + n, [&](int32_t a, int32_t b) { return asc_bits(surface[a]) < asc_bits(surface[b]); });
-            } else {                                        // big trees: stable LSD radix on the key bits
-                std::vector<uint32_t> k0(n), k1(n); std::vector<int32_t> c1(n);
-                for (int32_t i = 0; i < n; ++i) k0[i] = asc_bits(surface[cells[i]]);
-                uint32_t* ka = k0.data(); uint32_t* kb = k1.data(); int32_t* ca = cells; int32_t* cb = c1.data();
-                for (int pass = 0; pass < 3; ++pass) {
-                    const int sh = pass * 11; const uint32_t mask = pass == 2 ? 1023u : 2047u;
-                    uint32_t cnt[2049]; std::memset(cnt, 0, sizeof(cnt));
-                    for (int32_t i = 0; i < n; ++i) cnt[((ka[i] >> sh) & mask) + 1]++;
-                    for (int i = 0; i < 2048; ++i) cnt[i + 1] += cnt[i];
-                    for (int32_t i = 0; i < n; ++i) { const uint32_t d = cnt[(ka[i] >> sh) & mask]++; kb[d] = ka[i]; cb[d] = ca[i]; }
-                    std::swap(ka, kb); std::swap(ca, cb);
-                }
-                if (ca != cells) std::memcpy(cells, ca, sizeof(int32_t) * (size_t)n);     // 3 passes: result sits in c1
-            }
-        }
-        for (int32_t q = 0; q < n; ++q) {
-            const int32_t c = cells[q], t = st[c].drain;
-            if (t == NO_TARGET || t == UNVISITED) continue;
-            const double te = (t == TO_OCEAN) ? 0.0 : (double)eL[t];
-            if ((double)eL[c] <= te) eL[c] = (float)(te + EPS);
-        }
+        tree_pass23(ctx, list2 + cnt2[tree], cnt2[tree + 1] - cnt2[tree], path, myLen, myDef);
+        if (timing) { totLen += myLen; nDeficit += myDef; }
     });
-    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDef.load(), nTrees, (long long)totLen.load());
+    if (timing) std::fprintf(stderr, "[flood] pass2: %lld deficit cells in %d trees, total path length %lld\n", (long long)nDeficit.load(), nTrees, (long long)totLen.load());
     T.lap("pass2+3");
     if (track) {
         for (const auto& oa : *openAlt) {
@@ -694,6 +722,139 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
             if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) return false;
         }
     }
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
+    T.lap("writeback");
+    return true;
+}
+
+// Pass 1 + passes 2/3, pipelined per landmass.  A landmass's trees, carve paths and fix-ups stay inside it, so its passes
+// 2/3 need only its own pass 1.  Workers take landmasses largest first; after the walk of one they resolve its contested
+// cells, group its cells by tree and run the trees — a big landmass hands its trees out in chunks so that every worker
+// that has run out of landmasses helps.  While the largest landmass (14 % of the land on the bench planet) is still in
+// its walk, the carving of all the others is already done.
+bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo) {
+    const double EPS = 1e-7;
+    FloodTimer T;
+    const int32_t nComp = (int32_t)S.compSize.size();
+    const int32_t L = S.L;
+    rep = FloodTieReport{};
+    rep.landmasses = nComp;
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(S.stamp.data() + b, 0, sizeof(int32_t) * (size_t)(en - b)); });
+    S.onPath.resize(L);
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(S.onPath.data() + b, 0, (size_t)(en - b)); });
+    const int nt = flood_workers(std::max(nComp, 1));
+    rep.workers = nt;
+    if ((int)S.workerHeaps.size() < nt) S.workerHeaps.resize(nt);
+    FloodCell* st = S.state.data();
+    float* eL = S.eL.data();
+    int32_t* list2 = S.list2.data();
+    constexpr int32_t BIG = 32768, CHUNK = 4096;
+    struct BigJob {
+        int32_t k = -1; std::vector<int32_t> cnt, chunkStart; bool track = false;
+        std::atomic<int> ready{0}; std::atomic<size_t> nextChunk{0}, doneChunks{0};
+    };
+    int32_t nBig = 0;
+    while (nBig < nComp && S.compSize[nBig] >= BIG) ++nBig;               // landmasses are in descending size
+    std::vector<BigJob> big(nBig);
+    std::atomic<int32_t> next{0}, bigLeft{nBig};
+    std::atomic<bool> abort{false};
+    struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; };
+    std::vector<Local> loc(nt);
+    auto run_chunks = [&](BigJob& J, std::vector<int32_t>& path) {
+        const TreeCtx ctx{st, eL, nullptr, carveStrength, J.track ? S.onPath.data() : nullptr};
+        const size_t nChunks = J.chunkStart.size() - 1;
+        const int32_t base = S.compCellStart[J.k];
+        for (;;) {
+            const size_t c = J.nextChunk.fetch_add(1);
+            if (c >= nChunks) break;
+            int64_t a = 0, b = 0;
+            for (int32_t t = J.chunkStart[c]; t < J.chunkStart[c + 1]; ++t)
+                if (J.cnt[t + 1] > J.cnt[t]) tree_pass23(ctx, list2 + base + J.cnt[t], J.cnt[t + 1] - J.cnt[t], path, a, b);
+            if (J.doneChunks.fetch_add(1) + 1 == nChunks) bigLeft.fetch_sub(1);
+        }
+    };
+    auto worker = [&](int w) {
+        Local& me = loc[w];
+        std::vector<int32_t> path, cnt;
+        for (;;) {
+            const int32_t k = next.fetch_add(1);
+            if (k >= nComp || abort.load(std::memory_order_relaxed)) break;
+            // --- pass 1 of landmass k
+            me.contests.clear();
+            walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
+            bool track = false;
+            for (const Contest& ct : me.contests) {
+                ++me.contested;
+                bool open = false;
+                if (ct.other >= 0) {
+                    const FloodCell& x = st[ct.cell];
+                    const float kx = (float)((double)x.surface + cell_noise(S.landCell[ct.cell]));
+                    const double limO = (double)st[ct.other].surface + EPS;
+                    const float altSurface = ((double)x.e < limO) ? (float)limO : x.e;
+                    const bool sameSurface = std::memcmp(&altSurface, &x.surface, 4) == 0;
+                    const bool ordered = x.drain >= 0 && st[x.drain].surface < x.surface && st[ct.other].surface < x.surface;
+                    open = kx > ct.level && sameSurface && ordered;
+                }
+                if (open) { me.alt.push_back({ct.cell, ct.other}); track = true; }
+                else { ++me.unresolved; abort.store(true); }
+            }
+            if (abort.load(std::memory_order_relaxed)) break;
+            // --- its cells grouped by tree (stable: ascending original id inside a tree)
+            const int32_t base = S.compCellStart[k], n = S.compCellStart[k + 1] - base, nTrees = S.compSeedStart[k + 1] - S.compSeedStart[k];
+            const int32_t* cells = S.compCells.data() + base;
+            std::vector<int32_t>& c = (k < nBig) ? big[k].cnt : cnt;
+            c.assign((size_t)nTrees + 1, 0);
+            for (int32_t q = 0; q < n; ++q) ++c[S.seedLocal[st[cells[q]].root] + 1];
+            for (int32_t t = 0; t < nTrees; ++t) c[t + 1] += c[t];
+            {
+                static thread_local std::vector<int32_t> pos;
+                pos.assign(c.begin(), c.end() - 1);
+                for (int32_t q = 0; q < n; ++q) { const int32_t i = cells[q]; list2[base + pos[S.seedLocal[st[i].root]]++] = i; }
+            }
+            if (k < nBig) {                                  // hand the trees out in chunks
+                BigJob& J = big[k];
+                J.k = k; J.track = track;
+                J.chunkStart.clear(); J.chunkStart.push_back(0);
+                for (int32_t t = 0, last = 0; t < nTrees; ++t) if (c[t + 1] - c[last] >= CHUNK) { J.chunkStart.push_back(t + 1); last = t + 1; }
+                if (J.chunkStart.back() != nTrees) J.chunkStart.push_back(nTrees);
+                J.ready.store(1, std::memory_order_release);
+                run_chunks(J, path);
+            } else {
+                const TreeCtx ctx{st, eL, nullptr, carveStrength, track ? S.onPath.data() : nullptr};
+                int64_t a = 0, b = 0;
+                for (int32_t t = 0; t < nTrees; ++t) if (c[t + 1] > c[t]) tree_pass23(ctx, list2 + base + c[t], c[t + 1] - c[t], path, a, b);
+            }
+        }
+        // --- no landmass left to start: help with the big ones until all of them are through
+        while (bigLeft.load() > 0 && !abort.load(std::memory_order_relaxed)) {
+            bool did = false;
+            for (int32_t k = 0; k < nBig; ++k) {
+                BigJob& J = big[k];
+                if (J.ready.load(std::memory_order_acquire) && J.nextChunk.load() < J.chunkStart.size() - 1) { run_chunks(J, path); did = true; }
+            }
+            if (!did) std::this_thread::yield();
+        }
+    };
+    if (nt == 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < nt; ++w) th.emplace_back(worker, w);
+        for (auto& t : th) t.join();
+    }
+    for (const Local& l : loc) { rep.groups += l.groups; rep.nested += l.nested; rep.contested += l.contested; rep.unresolved += l.unresolved; rep.openParents += (int64_t)l.alt.size(); }
+    T.lap("pipeline");
+    if (T.on) std::fprintf(stderr, "[flood] landmasses %d (%d big), workers %d, tie groups %lld (nested %lld), contested %lld, open parents %lld, unresolved %lld\n",
+                           rep.landmasses, nBig, rep.workers, (long long)rep.groups, (long long)rep.nested, (long long)rep.contested, (long long)rep.openParents, (long long)rep.unresolved);
+    if (abort.load()) return false;
+    // open parents (see flood_pass23_host): the elevations must not depend on the choice
+    for (const Local& l : loc)
+        for (const auto& oa : l.alt) {
+            const int32_t x = oa.first, p0 = st[x].drain, p1 = oa.second;
+            const bool untouched = !S.onPath[x] && std::memcmp(&eL[x], &st[x].e, 4) == 0;
+            const double h = (double)st[x].e;
+            if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) { ++pathRedo; return false; }
+        }
+    const int32_t* landCell = S.landCell.data();
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
@@ -711,17 +872,23 @@ void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHos
     flood_gather(e, S);
     bool done = false;
     if (!serialOnly) {
+        static const bool twoPhase = [] { const char* v = std::getenv("WO_FLOOD_HOST"); return v && std::string(v) == "two-phase"; }();
         FloodTieReport rep;
         auto t0 = clock::now();
-        const bool exact = flood_pass1_landmasses(S, rep);
-        auto t1 = clock::now();
-        st.pass1Ms += ms(t0, t1);
-        st.tieGroups += rep.groups; st.contested += rep.contested; st.openParents += rep.openParents; st.unresolved += rep.unresolved;
-        if (exact) {
-            done = flood_pass23_host(e, carveStrength, S, &rep.alt);
-            st.pass23Ms += ms(t1, clock::now());
-            if (!done) ++st.pathRedo;
+        if (twoPhase) {                                     // all walks first, then all trees (kept for comparison)
+            const bool exact = flood_pass1_landmasses(S, rep);
+            auto t1 = clock::now();
+            st.pass1Ms += ms(t0, t1);
+            if (exact) {
+                done = flood_pass23_host(e, carveStrength, S, &rep.alt);
+                st.pass23Ms += ms(t1, clock::now());
+                if (!done) ++st.pathRedo;
+            }
+        } else {
+            done = flood_landmass_pipeline(e, carveStrength, S, rep, st.pathRedo);
+            st.pass1Ms += ms(t0, clock::now());             // pass 1 and passes 2/3 overlap: one figure
         }
+        st.tieGroups += rep.groups; st.contested += rep.contested; st.openParents += rep.openParents; st.unresolved += rep.unresolved;
         if (!done) flood_gather(e, S);
     }
     if (!done) {

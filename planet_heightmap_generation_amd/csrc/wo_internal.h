@@ -32,6 +32,8 @@ struct FloodScratch {
     hvec<int32_t> compSeeds;                 // seed positions (indices into seedCell) grouped by landmass, ascending inside
     std::vector<int32_t> compSeedStart;      // compSeeds range per seeded landmass, landmasses in descending size
     std::vector<int32_t> compSize;
+    std::vector<int32_t> compCellStart;      // per seeded landmass: its cells in compCells (ascending original id inside)
+    hvec<int32_t> compCells, seedLocal;      // seedLocal[s]: position of seed s among its landmass's seeds
     hvec<int32_t> stamp;                     // tie-family id of the claim that reached a cell (0 = outside any tie group)
     hvec<uint8_t> onPath;                    // pass 2: the cell lay on a carve path (only tracked when pass 1 left open parents)
     std::vector<hvec<FloodHeapItem>> workerHeaps;
@@ -56,6 +58,10 @@ void flood_pass1_host(FloodScratch& S);                               // serial 
 // One heap per landmass, landmasses concurrently; equal-key decisions that could differ from the single heap's are
 // detected (FloodTieReport).  Returns false when one of them changes surfaces/keys: the caller redoes pass 1 serially.
 bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep);
+// The same per landmass, with passes 2/3 of a landmass starting as soon as its own pass 1 is over (the largest landmass
+// bounds pass 1; the others' carving runs beside it).  Returns false — nothing written to e — when an equal-key decision
+// could matter (caller: serial walk).
+bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo);
 // pass 1 (landmass-parallel when exact, else the serial walk) + passes 2/3; stats: see flood_host.cc
 struct FloodHostStats { int64_t calls = 0, serialPass1 = 0, tieGroups = 0, contested = 0, openParents = 0, unresolved = 0, pathRedo = 0; double pass1Ms = 0, pass23Ms = 0; };
 void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHostStats* stats);
