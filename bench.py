@@ -331,8 +331,11 @@ def host_thread_usage():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ht = int(os.environ.get("WO_HOST_THREADS", min(n, 64)))
     fl = int(os.environ.get("WO_FLOOD_THREADS", 24))
-    return dict(available=n, mesh_builder_and_static_tables=ht, flood_pass1_heap_walk=1, flood_pass2_pass3_tree_workers=min(ht, fl),
-                note="inside the timed step the host runs only the priority flood (two calls): pass 1 on one thread, passes 2/3 on the tree workers")
+    serial = os.environ.get("WO_FLOOD_HOST") == "serial"
+    return dict(available=n, mesh_builder_and_static_tables=ht, flood_workers=1 if serial else min(ht, fl), flood_pass2_pass3_tree_workers=min(ht, fl),
+                note="inside the timed step the host runs only the priority flood (two calls per step): one heap per landmass, landmasses and their "
+                     "drainage trees dealt to the flood workers (erode_stats.flood_host_serial_pass1 counts the calls that had to fall back to the "
+                     "single serial heap walk)")
 
 
 def parity_crc(pl, cells: int, iters: int):
