@@ -794,6 +794,9 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     const bool sameSurface = std::memcmp(&altSurface, &x.surface, 4) == 0;
                     const bool ordered = x.drain >= 0 && st[x.drain].surface < x.surface && st[ct.other].surface < x.surface;
                     open = kx > ct.level && sameSurface && ordered;
+                    if (!open && T.on) std::fprintf(stderr, "[flood] unresolved contested cell %d (other %d): %s%s%s level %.9g key %.9g surface %.9g / %.9g e %.9g\n", S.landCell[ct.cell], S.landCell[ct.other],
+                                                    kx > ct.level ? "" : "cascades-inside-the-group ", sameSurface ? "" : "surface-differs ", ordered ? "" : "pass3-order ", (double)ct.level, (double)kx,
+                                                    (double)x.surface, (double)altSurface, (double)x.e);
                 }
                 if (open) { me.alt.push_back({ct.cell, ct.other}); track = true; }
                 else { ++me.unresolved; abort.store(true); }
