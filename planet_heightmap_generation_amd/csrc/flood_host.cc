@@ -835,7 +835,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                 BigJob& J = big[k];
                 if (J.ready.load(std::memory_order_acquire) && J.nextChunk.load() < J.chunkStart.size() - 1) { run_chunks(J, path); did = true; }
             }
-            if (!did) std::this_thread::yield();
+            if (!did) std::this_thread::sleep_for(std::chrono::microseconds(25));      // not a busy wait: the walk of the largest landmass is the critical path and may share a core
         }
     };
     if (nt == 1) worker(0);
