@@ -327,11 +327,16 @@ WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
 // after c: the serial loop adds them to flow[c] after c has already passed its own total on), and the event list of c.
 WO_HD inline void event_insert(EventList& E, int& n, bool& over, int32_t cell, int32_t rank) {
     if (n == WO_EVENTS) { over = true; return; }
-    int k = n++;
+    ++n;
+    // descending rank, unused slots hold rank -1: the new event sinks in from the top and pushes the smaller ones down
+    // (static indices only: the list stays in registers; a dynamically indexed array went to scratch memory)
 #pragma unroll
-    for (int q = WO_EVENTS - 1; q > 0; --q)                 // descending rank; ranks of land cells are distinct
-        if (q <= k && E.rank[q - 1] < rank) { E.cell[q] = E.cell[q - 1]; E.rank[q] = E.rank[q - 1]; k = q - 1; }
-    E.cell[k] = cell; E.rank[k] = rank;
+    for (int q = 0; q < WO_EVENTS; ++q) {
+        const bool up = rank > E.rank[q];
+        const int32_t c2 = E.cell[q], r2 = E.rank[q];
+        E.cell[q] = up ? cell : c2; E.rank[q] = up ? rank : r2;
+        cell = up ? c2 : cell; rank = up ? r2 : rank;
+    }
 }
 WO_HD inline void flow_final_cell(const Fields& F, int32_t c) {
     uint32_t f = F.accA[c];
@@ -668,6 +673,70 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
 // New height of cell c (reads F.e, the pre-thermal field).  inShare / inRank are caller-provided scratch for the
 // <= degree incoming events, element k at [k * stride] (LDS columns on the device: a per-thread array indexed at
 // run time would live in scratch memory and tripled this kernel's HBM traffic).
+// thermal_apply_cell for rows of at most WO_ROW neighbours (99.9 % of the cells), with every per-neighbour quantity in a
+// statically indexed slot: the replay of the serial loop's additions (senders in ascending rank, c's own sends at c's turn
+// in adjacency order) selects by scanning the 8 slots instead of indexing a list, so nothing lives in scratch memory.
+WO_HD inline float thermal_apply_row(const Fields& F, double h, int32_t myRank, double myTotal, int32_t b, const int32_t (&nbs)[WO_ROW], int deg,
+                                     double talus, double kThermal) {
+    const double myTransfer = kThermal * myTotal * 0.5;
+    float mh[WO_ROW], dd[WO_ROW];
+    double tx[WO_ROW]; int32_t rk[WO_ROW]; bool snd[WO_ROW];
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) { mh[k] = F.me[nbs[k]]; dd[k] = (k < deg) ? F.dist[b + k] : 1.0f; }
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) {
+        const double nh = mh[k], d = nd_or_eps(dd[k]);
+        snd[k] = k < deg && nh > h && ((nh - h) / d > talus);
+        tx[k] = snd[k] ? F.totalExcess[nbs[k]] : 0.0;
+        rk[k] = snd[k] ? F.rank[nbs[k]] : 0;
+    }
+    double inSh[WO_ROW], outSh[WO_ROW]; int32_t inRk[WO_ROW]; bool outOn[WO_ROW];
+    bool hasOut = false, hasIn = false;
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) {
+        inRk[k] = 0x7fffffff; inSh[k] = 0; outSh[k] = 0; outOn[k] = false;
+        if (k >= deg) continue;
+        const double nh = mh[k];             // +inf for ocean neighbours: a sender whose totalExcess is 0
+        const double d = nd_or_eps(dd[k]);
+        if (nh < h) {                           // c sends to nb on c's own turn
+            const double slope = (h - nh) / d;
+            if (slope > talus && myTotal > 0) {
+                hasOut = true; outOn[k] = true;
+                const float excess = (float)((slope - talus) * d);
+                outSh[k] = ((double)excess / myTotal) * myTransfer;
+            }
+        } else if (snd[k]) {                    // nb sends to c on nb's turn
+            const double slope = (nh - h) / d;
+            const double tot = tx[k];
+            if (tot > 0) {
+                const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
+                inSh[k] = ((double)excess / tot) * (kThermal * tot * 0.5);
+                inRk[k] = rk[k];
+                hasIn = true;
+            }
+        }
+    }
+    if (!hasIn && !hasOut) return (float)(h + 0.0);   // e += delta with delta == 0 (also maps -0 -> +0 like the f32 add)
+    float delta = 0.0f;
+    int32_t last = -1;
+    bool ownPending = hasOut;
+    for (int it = 0; it < WO_ROW + 2; ++it) {
+        int32_t pr = 0x7fffffff; double v = 0;
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) { const bool hit = inRk[k] > last && inRk[k] < pr; pr = hit ? inRk[k] : pr; v = hit ? inSh[k] : v; }
+        if (ownPending && myRank < pr) {        // c's own turn comes before the next sender's: its sends, in adjacency order (js/terrain-post.js:676-680)
+#pragma unroll
+            for (int k = 0; k < WO_ROW; ++k) if (outOn[k]) delta = (float)((double)delta - outSh[k]);
+            ownPending = false;
+            continue;
+        }
+        if (pr == 0x7fffffff) break;
+        delta = (float)((double)delta + v);
+        last = pr;
+    }
+    return (float)(h + (double)delta);
+}
+
 WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, double kThermal, double* inShare, int32_t* inRank, int stride,
                                       double* outShare = nullptr) {
     if (F.ocean[c]) return F.e[c];
@@ -678,43 +747,8 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
     int nIn = 0, nOut = 0; bool hasOut = false;
     int32_t b, nbs[WO_ROW];
     const int deg = load_row(F, c, b, nbs);
-    const bool batched = deg <= WO_ROW;
-    float mh[WO_ROW], dd[WO_ROW];
-    if (batched) {
-        // one batch for the row's heights and distances, a second one for the senders' totals and ranks
-        double tx[WO_ROW]; int32_t rk[WO_ROW]; bool snd[WO_ROW];
-#pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) { mh[k] = F.me[nbs[k]]; dd[k] = (k < deg) ? F.dist[b + k] : 1.0f; }
-#pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) {
-            const double nh = mh[k], d = nd_or_eps(dd[k]);
-            snd[k] = k < deg && nh > h && ((nh - h) / d > talus);
-            tx[k] = snd[k] ? F.totalExcess[nbs[k]] : 0.0;
-            rk[k] = snd[k] ? F.rank[nbs[k]] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) {
-            if (k >= deg) continue;
-            const double nh = mh[k];         // +inf for ocean neighbours: falls into the sender branch and finds totalExcess 0
-            const double d = nd_or_eps(dd[k]);
-            if (nh < h) {                       // c sends to nb on c's own turn
-                const double slope = (h - nh) / d;
-                if (slope > talus && myTotal > 0) {
-                    hasOut = true;
-                    if (outShare) { const float excess = (float)((slope - talus) * d); outShare[nOut++ * stride] = ((double)excess / myTotal) * myTransfer; }
-                }
-            } else if (snd[k]) {                // nb sends to c on nb's turn
-                const double slope = (nh - h) / d;
-                const double tot = tx[k];
-                if (tot > 0) {
-                    const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
-                    inShare[nIn * stride] = ((double)excess / tot) * (kThermal * tot * 0.5);
-                    inRank[nIn * stride] = rk[k];
-                    ++nIn;
-                }
-            }
-        }
-    } else {
+    if (deg <= WO_ROW) return thermal_apply_row(F, h, myRank, myTotal, b, nbs, deg, talus, kThermal);
+    {
         for (int32_t j = b; j < b + deg; ++j) {
             const int32_t nb = F.adj[j];
             const double nh = F.me[nb];         // +inf for ocean neighbours: falls into the branch below and finds totalExcess 0
@@ -755,9 +789,9 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
             for (int k = 0; k < nOut; ++k) delta = (float)((double)delta - outShare[k * stride]);
         } else if (phase == 0 && hasOut) {
             for (int32_t j = b; j < b + deg; ++j) {
-                const double nh = batched ? (double)mh[j - b] : (double)F.me[F.adj[j]];
+                const double nh = (double)F.me[F.adj[j]];
                 if (!(nh < h)) continue;
-                const double d = nd_or_eps(batched ? dd[j - b] : F.dist[j]);
+                const double d = nd_or_eps(F.dist[j]);
                 const double slope = (h - nh) / d;
                 if (slope > talus) {
                     const float excess = (float)((slope - talus) * d);
