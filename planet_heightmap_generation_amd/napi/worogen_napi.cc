@@ -291,6 +291,17 @@ napi_value LastStageTiming(napi_env env, napi_callback_info info) {
     return arr;
 }
 
+// lastErodeStats(planet) -> {name: number}: counters of the last erodeComposite (rounds, launches, the host flood's route)
+napi_value LastErodeStats(napi_env env, napi_callback_info info) {
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
+    const char* names[64]; double vals[64]; int32_t n = 0;
+    if (wo_last_erode_stats(p, 64, names, vals, &n)) return throw_wo(env, "lastErodeStats");
+    napi_value o; napi_create_object(env, &o);
+    for (int32_t i = 0; i < n; ++i) { napi_value v; napi_create_double(env, vals[i], &v); napi_set_named_property(env, o, names[i], v); }
+    return o;
+}
+
 // noisePoint(perm, pm12, kind, octaves, p0, p1, p2, x, y, z) -> number (host)
 napi_value NoisePoint(napi_env env, napi_callback_info info) {
     Args a(env, info);
@@ -473,7 +484,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"warpTerrainResident", WarpTerrainResident}, {"smoothElevationResident", SmoothElevationResident},
         {"erodeCompositeResident", ErodeCompositeResident}, {"sharpenRidgesResident", SharpenRidgesResident},
         {"applySoilCreepResident", ApplySoilCreepResident}, {"timerStart", TimerStart}, {"timerStopMs", TimerStopMs},
-        {"lastStageTiming", LastStageTiming}, {"assignElevation", AssignElevation},
+        {"lastStageTiming", LastStageTiming}, {"lastErodeStats", LastErodeStats}, {"assignElevation", AssignElevation},
         {"projectCoarsePlates", ProjectCoarsePlates}, {"smoothField", SmoothField}, {"smoothAndReconnectPlates", SmoothAndReconnectPlates},
         {"diffuseOceanWarmth", DiffuseOceanWarmth}, {"computeWindConvergence", WindConvergence}, {"advectMoisture", AdvectMoisture},
         {"landComponents", LandComponents},

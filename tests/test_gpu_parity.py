@@ -108,6 +108,9 @@ def test_against_oracle_large(TP, oracle, N, seed, h, t, g):
     got2 = e0.copy()
     pl.erode_composite(got2, oc, h, 3e-4, 0.5, 1.0, t, 1.16, 0.015, 0, 0.0)
     assert np.array_equal(got2, ref2)
+    # the flood ran one heap per landmass and vouched for the single heap's result (no serial redo on ordinary terrain)
+    st = pl.last_erode_stats()
+    assert st["flood_host_calls"] == 2 and st["flood_host_serial_pass1"] == 0 and st["flood_host_unresolved"] == 0, st
     # the other exports at this size
     for fn, ofn, args in (("warp_terrain", "warp_terrain", None), ("smooth_elevation", "smooth_elevation", (2, 0.3)),
                           ("sharpen_ridges", "sharpen_ridges", (3, 0.04)), ("apply_soil_creep", "soil_creep", (3, 0.1125))):
@@ -323,6 +326,40 @@ def test_planets_in_flight_match_sequential(TP):
     assert not np.array_equal(seq[0], seq[1])
     with pytest.raises(ZeroDivisionError):
         EnsembleRunner(mesh, xyz, nd, in_flight=2).map(lambda pl, s: 1 // 0, [1, 2, 3])
+
+
+def test_flood_routes_agree(TP, oracle, monkeypatch):
+    """The host flood's three routes — one heap per landmass pipelined with passes 2/3 (default), the same in two phases,
+    and the single serial heap walk (WO_FLOOD_HOST) — are read once per process, so each runs in its own interpreter;
+    all must give the oracle's field (reference: js/terrain-post.js:59-215)."""
+    import os, subprocess, sys, textwrap
+    from conftest import REPO
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from oracle import pyoracle as O
+        from planet_heightmap_generation_amd import sphere_mesh as S, terrain_post as TP
+        mesh, xyz, nd = S.build_sphere(150000, 0.75, 11)
+        pl = TP.Planet(mesh, xyz, nd)
+        pl.synthetic_terrain(11)
+        e0, oc = pl.download(), pl.download_ocean()
+        om = O.Mesh(mesh.adjOffset, mesh.adjList)
+        ref = O.erode_composite(om, e0, xyz, oc, 8, 3e-4, 0.5, 1.0, 8, 1.16, 0.015, 0, 0.0, nd)
+        got = e0.copy()
+        pl.erode_composite(got, oc, 8, 3e-4, 0.5, 1.0, 8, 1.16, 0.015, 0, 0.0)
+        st = pl.last_erode_stats()
+        print("ROUTE", int(np.array_equal(got, ref)), int(st["flood_host_serial_pass1"]), int(st["flood_host_calls"]))
+    """) % str(REPO)
+    for route, serial_calls in ((None, 0), ("two-phase", 0), ("serial", 2)):
+        env = dict(os.environ)
+        env.pop("WO_FLOOD_HOST", None)
+        if route:
+            env["WO_FLOOD_HOST"] = route
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("ROUTE")]
+        assert line, (route, out.stdout[-500:], out.stderr[-1500:])
+        same, serial, calls = (int(v) for v in line[0].split()[1:])
+        assert same == 1 and calls == 2 and serial == serial_calls, (route, line)
 
 
 def test_device_flood_is_order_equivalent(TP, oracle, monkeypatch):
