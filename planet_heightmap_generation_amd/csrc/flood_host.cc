@@ -617,7 +617,6 @@ void tree_pass23(const TreeCtx& X, int32_t* cells, int32_t n, std::vector<int32_
 
 // passes 2 and 3 (:152-214) on the state pass 1 left, then the land elevations back into e
 bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const std::vector<std::pair<int32_t, int32_t>>* openAlt) {
-    const double EPS = 1e-7;
     FloodTimer T;
     // Cells whose parent pass 1 left open (equal keys, same surface under either parent).  The elevations do not depend
     // on the choice when (i) no carve path runs through the cell — a path exists only below a deficit cell, so then the
@@ -742,7 +741,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(S.stamp.data() + b, 0, sizeof(int32_t) * (size_t)(en - b)); });
     S.onPath.resize(L);
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(S.onPath.data() + b, 0, (size_t)(en - b)); });
-    const int nt = flood_workers(std::max(nComp, 1));
+    const int nt = std::min(flood_workers(std::max(nComp, 1)), std::max(1, L / 16384));    // small planets: a thread costs more than it saves
     rep.workers = nt;
     if ((int)S.workerHeaps.size() < nt) S.workerHeaps.resize(nt);
     FloodCell* st = S.state.data();
