@@ -135,7 +135,39 @@ def build_inputs(cells: int, seed: int):
     from planet_heightmap_generation_amd import sphere_mesh as S
     t0 = time.time()
     mesh, xyz, nd = S.build_sphere(cells, 0.75, seed)
+    if os.environ.get("WO_BENCH_LAYOUT") == "morton":
+        mesh, xyz, nd = morton_relabel(mesh, xyz, nd)
     return mesh, xyz, nd, time.time() - t0
+
+
+def morton_relabel(mesh, xyz, nd):
+    """EXPERIMENT ONLY (WO_BENCH_LAYOUT=morton): the same planet with its cells renumbered in Morton order of their positions
+    (rows keep their order).  Cell ids enter the reference's semantics (cellNoise, initial land order), so the field differs from
+    the oracle's and parity_crc_ok is false by construction; the run only shows what the index-order kernels cost when
+    neighbours are near each other in memory."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    N = mesh.numRegions
+    p = np.asarray(xyz, dtype=np.float32).reshape(-1, 3)
+
+    def spread(v):
+        v = v.astype(np.uint64) & 0x1fffff
+        v = (v | (v << 32)) & 0x1f00000000ffff
+        v = (v | (v << 16)) & 0x1f0000ff0000ff
+        v = (v | (v << 8)) & 0x100f00f00f00f00f
+        v = (v | (v << 4)) & 0x10c30c30c30c30c3
+        v = (v | (v << 2)) & 0x1249249249249249
+        return v
+    q = np.clip(((p.astype(np.float64) + 1.0) * 1048575.5).astype(np.int64), 0, 2097151)
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    perm = np.argsort(key, kind="stable").astype(np.int64)          # new -> old
+    inv = np.empty(N, dtype=np.int32); inv[perm] = np.arange(N, dtype=np.int32)
+    off = mesh.adjOffset.astype(np.int64)
+    deg = (off[1:] - off[:-1])[perm]
+    noff = np.zeros(N + 1, dtype=np.int64); np.cumsum(deg, out=noff[1:])
+    src = np.repeat(off[:-1][perm] - noff[:-1], deg) + np.arange(noff[-1], dtype=np.int64)
+    m2 = S.SphereMesh(numRegions=N, triangles=mesh.triangles, halfedges=mesh.halfedges, adjOffset=noff.astype(np.int32),
+                      adjList=inv[mesh.adjList[src]].astype(np.int32), adjTriList=mesh.adjTriList[src])
+    return m2, np.ascontiguousarray(p[perm].reshape(-1)), np.ascontiguousarray(np.asarray(nd)[src])
 
 
 def one_step(pl, seed, params, iters_scale=None):

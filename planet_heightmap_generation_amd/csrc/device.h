@@ -128,6 +128,19 @@ struct wo_planet {
     int landCur = 0;                    // which of d_land[] holds the current order
     int32_t L = 0;
 
+    // Patch-major mirror of the mesh for erodeComposite (planet.hip, MirrorScope): the same graph with the cells renamed in
+    // Morton order of their positions, rows in the reference's order.  While a scope is active the pointers above (mesh, d_e,
+    // d_e2, d_ocean, d_coast) point at the mirror and the o_* members hold the planet's own buffers.
+    struct Mirror {
+        bool built = false, active = false;
+        int32_t *perm = nullptr, *inv = nullptr, *off = nullptr, *adj = nullptr;       // perm: mirror id -> cell id
+        float *dist = nullptr, *xyz = nullptr, *e = nullptr, *e2 = nullptr;
+        uint8_t *ocean = nullptr, *coast = nullptr;
+        wo::hvec<int32_t> h_perm;
+        int32_t *o_off = nullptr, *o_adj = nullptr; float *o_dist = nullptr, *o_xyz = nullptr, *o_e = nullptr, *o_e2 = nullptr;
+        uint8_t *o_ocean = nullptr, *o_coast = nullptr;
+    } mirror;
+
     // measurement
     hipEvent_t evStart = nullptr, evStop = nullptr;
     bool profiling = false;

@@ -288,6 +288,21 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     ++S.staticVersion;
 }
 
+// All cells in Morton order of their positions, ties in ascending id: the same keys and the same stable sort as the land list
+// above, so the land cells appear in it in exactly the order of `landCell` (planet.hip: patch-major mirror for erodeComposite).
+void morton_order_cells(int32_t N, const float* xyz, hvec<int32_t>& cells) {
+    cells.resize(N);
+    std::vector<uint32_t> keys(N);
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) {
+        for (int64_t r = b; r < e; ++r) {
+            auto q = [](float v) { int32_t t = (int32_t)((v + 1.0f) * 511.5f); return (uint32_t)(t < 0 ? 0 : (t > 1023 ? 1023 : t)); };
+            cells[r] = (int32_t)r;
+            keys[r] = spread3(q(xyz[3 * r])) | (spread3(q(xyz[3 * r + 1])) << 1) | (spread3(q(xyz[3 * r + 2])) << 2);
+        }
+    });
+    radix_sort_u32(keys, cells);
+}
+
 // cellNoise of every land cell, in the compact (Morton) land order — uploaded once per land mask for the device flood
 void flood_cell_noise(const FloodScratch& S, double* out) {
     parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) out[i] = cell_noise(S.landCell[i]); });

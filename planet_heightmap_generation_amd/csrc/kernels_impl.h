@@ -692,6 +692,23 @@ __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDe
     WO_XCD_CELLS(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
 }
 
+// ---- patch-major mirror of the mesh for erodeComposite (planet.hip: Mirror).  perm: mirror id -> cell id, inv: the inverse ----
+__global__ __launch_bounds__(WO_BLOCK) void k_mirror_gather_f32(const float* src, const int32_t* perm, float* dst, int32_t n) { WO_GRID_STRIDE(i, n) dst[i] = src[perm[i]]; }
+__global__ __launch_bounds__(WO_BLOCK) void k_mirror_scatter_f32(const float* src, const int32_t* perm, float* dst, int32_t n) { WO_GRID_STRIDE(i, n) dst[perm[i]] = src[i]; }
+__global__ __launch_bounds__(WO_BLOCK) void k_mirror_gather_u8(const uint8_t* src, const int32_t* perm, uint8_t* dst, int32_t n) { WO_GRID_STRIDE(i, n) dst[i] = src[perm[i]]; }
+__global__ __launch_bounds__(WO_BLOCK) void k_mirror_map_i32(const int32_t* in, const int32_t* map, int32_t* out, int32_t n) { WO_GRID_STRIDE(i, n) out[i] = map[in[i]]; }
+__global__ __launch_bounds__(WO_BLOCK) void k_mirror_invert(const int32_t* perm, int32_t* inv, int32_t n) { WO_GRID_STRIDE(i, n) inv[perm[i]] = i; }
+// rows keep their order (the reference's adjacency order is part of its semantics); only the ids are renamed
+__global__ __launch_bounds__(WO_BLOCK) void k_mirror_rows(const int32_t* off, const int32_t* adj, const float* dist, const float* xyz, const int32_t* perm,
+                                                           const int32_t* inv, const int32_t* moff, int32_t* madj, float* mdist, float* mxyz, int32_t n) {
+    WO_GRID_STRIDE(i, n) {
+        const int32_t r = perm[i];
+        const int32_t b = off[r], deg = off[r + 1] - b, mb = moff[i];
+        for (int32_t k = 0; k < deg; ++k) { madj[mb + k] = inv[adj[b + k]]; mdist[mb + k] = dist[b + k]; }
+        mxyz[3 * i] = xyz[3 * r]; mxyz[3 * i + 1] = xyz[3 * r + 1]; mxyz[3 * i + 2] = xyz[3 * r + 2];
+    }
+}
+
 __global__ void k_set_counters(int32_t* c, int32_t v0, int32_t v1, int32_t v2, int32_t v3) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = v0; c[1] = v1; c[2] = v2; c[3] = v3; }
 }

@@ -453,6 +453,93 @@ static void coast_flags(wo_planet* p) {
     launch(p, FAM_COAST, k_coast, xcd_grid(p->N), WO_BLOCK, p->fields(), p->d_coast);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Patch-major mirror of the mesh for erodeComposite.  The reference numbers the cells along the Fibonacci spiral, where the
+// neighbours of consecutive cells lie in ~8 separate clusters 5*sqrt(N) ids apart and a 128-byte line of per-cell state
+// holds 32 cells of which 9 are land: the neighbour gathers of every erosion pass cost an L2 transaction each.
+// Inside erodeComposite nothing depends on the NAME of a cell except (i) the initial order of landCells (ascending id,
+// js/terrain-post.js:384-390; later orders are stable sorts of it) and (ii) the flood's cellNoise(r) — rows keep the
+// reference's adjacency order, ranks are positions in landCells.  So the whole call runs on a renamed copy of the graph
+// (cells in Morton order of their positions: a wave's 64 cells and their neighbours share a few lines), with the initial
+// land order mapped through the renaming and the field moved back to the planet's own order around each flood and at the end.
+// Results are bit-identical (same operations on the same values in the same order); measured at 10 M cells the step went
+// 1.10 -> 0.85 s.  WO_LAYOUT=index switches the mirror off.
+// ---------------------------------------------------------------------------------------------------
+static bool mirror_wanted(const wo_planet* p) {
+    const char* e = std::getenv("WO_LAYOUT");
+    return !(e && std::string(e) == "index") && !p->h_xyz.empty() && p->N > 1;
+}
+static void mirror_build(wo_planet* p) {
+    auto& M = p->mirror;
+    if (M.built) return;
+    const int32_t N = p->N; const size_t E = (size_t)p->E;
+    hipStream_t s = p->ctx->stream;
+    morton_order_cells(N, p->h_xyz.data(), M.h_perm);
+    hvec<int32_t> moff((size_t)N + 1);
+    moff[0] = 0;
+    for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_perm[i]; moff[i + 1] = moff[i] + (p->h_off[r + 1] - p->h_off[r]); }
+    M.perm = dalloc<int32_t>(N); M.inv = dalloc<int32_t>(N); M.off = dalloc<int32_t>((size_t)N + 1); M.adj = dalloc<int32_t>(E);
+    M.dist = dalloc<float>(E); M.xyz = dalloc<float>(3 * (size_t)N); M.e = dalloc<float>(N); M.e2 = dalloc<float>(N);
+    M.ocean = dalloc<uint8_t>(N); M.coast = dalloc<uint8_t>(N);
+    WO_HIP(hipMemcpyAsync(M.perm, M.h_perm.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
+    WO_HIP(hipMemcpyAsync(M.off, moff.data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice, s));
+    launch(p, FAM_MISC, k_mirror_invert, blocks_for(N, 4096), WO_BLOCK, (const int32_t*)M.perm, M.inv, N);
+    launch(p, FAM_MISC, k_mirror_rows, blocks_for(N, 4096), WO_BLOCK, (const int32_t*)p->d_off, (const int32_t*)p->d_adj, (const float*)p->d_dist,
+           (const float*)p->d_xyz, (const int32_t*)M.perm, (const int32_t*)M.inv, (const int32_t*)M.off, M.adj, M.dist, M.xyz, N);
+    WO_HIP(hipStreamSynchronize(s));                    // moff / h_perm uploads done
+    M.built = true;
+}
+static void mirror_free(wo_planet* p) {
+    auto& M = p->mirror;
+    dfree(M.perm); dfree(M.inv); dfree(M.off); dfree(M.adj); dfree(M.dist); dfree(M.xyz); dfree(M.e); dfree(M.e2); dfree(M.ocean); dfree(M.coast);
+    M.built = false;
+}
+struct MirrorScope {
+    wo_planet* p; bool on = false; float *cur = nullptr, *cur2 = nullptr;
+    explicit MirrorScope(wo_planet* pl) : p(pl) {}
+    MirrorScope(const MirrorScope&) = delete;
+    void point_at_mirror(float* e, float* e2) {
+        auto& M = p->mirror;
+        p->d_off = M.off; p->d_adj = M.adj; p->d_dist = M.dist; p->d_xyz = M.xyz; p->d_e = e; p->d_e2 = e2; p->d_ocean = M.ocean; p->d_coast = M.coast;
+    }
+    void point_at_planet() {
+        auto& M = p->mirror;
+        p->d_off = M.o_off; p->d_adj = M.o_adj; p->d_dist = M.o_dist; p->d_xyz = M.o_xyz; p->d_e = M.o_e; p->d_e2 = M.o_e2; p->d_ocean = M.o_ocean; p->d_coast = M.o_coast;
+    }
+    // field and ocean mask into the mirror, the planet's pointers onto it
+    void enter() {
+        if (!mirror_wanted(p) || p->mirror.active) return;
+        mirror_build(p);
+        auto& M = p->mirror;
+        const int32_t N = p->N;
+        launch(p, FAM_MISC, k_mirror_gather_f32, blocks_for(N, 4096), WO_BLOCK, (const float*)p->d_e, (const int32_t*)M.perm, M.e, N);
+        launch(p, FAM_MISC, k_mirror_gather_u8, blocks_for(N, 4096), WO_BLOCK, (const uint8_t*)p->d_ocean, (const int32_t*)M.perm, M.ocean, N);
+        M.o_off = p->d_off; M.o_adj = p->d_adj; M.o_dist = p->d_dist; M.o_xyz = p->d_xyz; M.o_e = p->d_e; M.o_e2 = p->d_e2; M.o_ocean = p->d_ocean; M.o_coast = p->d_coast;
+        point_at_mirror(M.e, M.e2);
+        M.active = on = true;
+    }
+    // the current field back in the planet's own buffer and order, the planet's pointers on its own buffers (flood stage)
+    void suspend() {
+        if (!on) return;
+        auto& M = p->mirror;
+        launch(p, FAM_MISC, k_mirror_scatter_f32, blocks_for(p->N, 4096), WO_BLOCK, (const float*)p->d_e, (const int32_t*)M.perm, M.o_e, p->N);
+        cur = p->d_e; cur2 = p->d_e2;
+        point_at_planet();
+    }
+    void resume() {
+        if (!on) return;
+        auto& M = p->mirror;
+        launch(p, FAM_MISC, k_mirror_gather_f32, blocks_for(p->N, 4096), WO_BLOCK, (const float*)M.o_e, (const int32_t*)M.perm, cur, p->N);
+        point_at_mirror(cur, cur2);
+    }
+    void finish() {
+        if (!on) return;
+        suspend();
+        p->mirror.active = on = false;
+    }
+    ~MirrorScope() { if (on) { point_at_planet(); p->mirror.active = false; } }      // error path: pointers only, the planet's field is what it was at the last suspend
+};
+
 // erodeComposite on the resident field (js/terrain-post.js:369-707)
 static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talus,
                             double kThermal, int32_t gIters, double gStrength) {
@@ -471,17 +558,34 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     double floodHostMs = 0;
 
     clk.begin("setup");
+    refresh_host_ocean(p);          // the planet's own mask, before the pointers move
+    MirrorScope mir(p);
+    mir.enter();
     coast_flags(p);
     // landCells in ascending r (js/terrain-post.js:384-390): host-side compaction of the ocean mask
-    refresh_host_ocean(p);
     {
         int32_t* hl = reinterpret_cast<int32_t*>(p->h_pinned);
         int32_t L = 0;
         for (int32_t r = 0; r < N; ++r) if (!p->h_ocean[r]) hl[L++] = r;
         p->L = L;
         if (L == 0) { clk.end(); clk.finish(); return; }
-        WO_HIP(hipMemcpyAsync(p->d_landIdx, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        WO_HIP(hipMemcpyAsync(p->d_land[0], p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (mir.on) {
+            // initial landCells: the same cells in the same (ascending-r) order, under their mirror names
+            WO_HIP(hipMemcpyAsync(p->d_listA, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            launch(p, FAM_MISC, k_mirror_map_i32, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_listA, (const int32_t*)p->mirror.inv, p->d_land[0], L);
+            WO_HIP(hipStreamSynchronize(s));
+            // the list the index-order passes iterate: land cells in ascending mirror id
+            const int32_t* perm = p->mirror.h_perm.data();
+            const uint8_t* oc = p->h_ocean.data();
+            std::vector<int64_t> cnt(host_threads() + 2, 0);
+            parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t i = b; i < e; ++i) c += oc[perm[i]] ? 0 : 1; cnt[t + 1] = c; });
+            for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+            parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t o = cnt[t]; for (int64_t i = b; i < e; ++i) if (!oc[perm[i]]) hl[o++] = (int32_t)i; });
+            WO_HIP(hipMemcpyAsync(p->d_landIdx, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        } else {
+            WO_HIP(hipMemcpyAsync(p->d_landIdx, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            WO_HIP(hipMemcpyAsync(p->d_land[0], p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        }
         WO_HIP(hipStreamSynchronize(s));       // h_pinned is reused by the flood stage
         p->landCur = 0;
         launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
@@ -492,7 +596,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (!p->flood.staticValid || p->flood.staticN != N)
                 flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood);
             if (p->patchVersion != p->flood.staticVersion) {
-                WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->flood.landCell.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                if (mir.on) WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));   // ascending mirror id IS Morton order
+                else WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->flood.landCell.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
                 launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_slotOf, -1, N);
                 launch(p, FAM_MISC, k_slot_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_patchOrder, p->d_slotOf, L);
                 WO_HIP(hipStreamSynchronize(s));
@@ -518,7 +623,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     auto flood = [&](double cs) {
         clk.begin("priority_flood");
         auto t0 = std::chrono::steady_clock::now();
+        mir.suspend();
         flood_stage(p, cs, floodRun);
+        mir.resume();
         floodHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         clk.end();
     };
@@ -693,6 +800,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         swap_elev(p);
         clk.end();
     }
+    if (mir.on) { clk.begin("setup"); mir.finish(); clk.end(); }
     clk.finish();
     p->erodeStats = {{"land_cells", (double)L}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
@@ -876,6 +984,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     flood_gpu_free(p->fgpu);
     river_free(p);
+    mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);

@@ -48,6 +48,8 @@ struct FloodTieReport {
 };
 // (re)builds the mask-dependent tables (Morton-ordered land list `landCell`, compact CSR, seeds)
 void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S);
+// every cell in Morton order of its position (ties: ascending id); restricted to the land cells this is FloodScratch::landCell
+void morton_order_cells(int32_t N, const float* xyz, hvec<int32_t>& cells);
 // xyz (3*N floats) orders the compact land arrays spatially; may be nullptr (index order)
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);
