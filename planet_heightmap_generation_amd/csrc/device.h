@@ -119,7 +119,7 @@ struct wo_planet {
     float *d_glac = nullptr, *d_iceFlow = nullptr;
     int32_t *d_iceTarget = nullptr, *d_arank = nullptr;
     uint8_t* d_iceUp = nullptr;
-    int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
+    int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
     uint32_t* d_riverA[2] = {nullptr, nullptr}; int32_t* d_riverJ[2] = {nullptr, nullptr}; int32_t* d_riverIdx = nullptr;   // river.hip
     uint32_t *d_riverRootSize = nullptr, *d_riverRootBase = nullptr; int32_t* d_riverFlag = nullptr; int64_t riverRefreshes = 0;
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
@@ -134,7 +134,7 @@ struct wo_planet {
     struct Mirror {
         bool built = false, active = false;
         int32_t *perm = nullptr, *inv = nullptr, *off = nullptr, *adj = nullptr;       // perm: mirror id -> cell id
-        float *dist = nullptr, *xyz = nullptr, *e = nullptr, *e2 = nullptr;
+        float *dist = nullptr, *xyz = nullptr, *e = nullptr, *e2 = nullptr, *hot = nullptr;
         uint8_t *ocean = nullptr, *coast = nullptr;
         wo::hvec<int32_t> h_perm;
         int32_t *o_off = nullptr, *o_adj = nullptr; float *o_dist = nullptr, *o_xyz = nullptr, *o_e = nullptr, *o_e2 = nullptr;

@@ -491,7 +491,7 @@ static void mirror_build(wo_planet* p) {
 }
 static void mirror_free(wo_planet* p) {
     auto& M = p->mirror;
-    dfree(M.perm); dfree(M.inv); dfree(M.off); dfree(M.adj); dfree(M.dist); dfree(M.xyz); dfree(M.e); dfree(M.e2); dfree(M.ocean); dfree(M.coast);
+    dfree(M.perm); dfree(M.inv); dfree(M.off); dfree(M.adj); dfree(M.dist); dfree(M.xyz); dfree(M.e); dfree(M.e2); dfree(M.ocean); dfree(M.coast); dfree(M.hot);
     M.built = false;
 }
 struct MirrorScope {
@@ -595,7 +595,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         if (hIters > 0 && !p->h_xyz.empty() && std::getenv("WO_NO_SOLVE_PATCH") == nullptr) {
             if (!p->flood.staticValid || p->flood.staticN != N)
                 flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood);
-            if (p->patchVersion != p->flood.staticVersion) {
+            if (p->patchVersion != p->flood.staticVersion || p->patchMirror != mir.on) {
+                p->patchMirror = mir.on;
                 if (mir.on) WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));   // ascending mirror id IS Morton order
                 else WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->flood.landCell.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
                 launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_slotOf, -1, N);
@@ -800,9 +801,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         swap_elev(p);
         clk.end();
     }
+    const bool mirrored = mir.on;
     if (mir.on) { clk.begin("setup"); mir.finish(); clk.end(); }
     clk.finish();
-    p->erodeStats = {{"land_cells", (double)L}, {"iterations", (double)total}, {"sorts", (double)sorts},
+    p->erodeStats = {{"land_cells", (double)L}, {"mirror_layout", mirrored ? 1.0 : 0.0}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
@@ -843,9 +845,21 @@ static void warp(wo_planet* p, double seed, double strength, bool useHot) {
     if (!(strength > 0)) return;          // js/terrain-post.js:234
     upload_tables(p, seed + 9999);
     const double maxAmp = 0.12 * strength, bias = 0.25 + 0.5 * strength;
+    // the greedy walk reads rows and positions of cells along its path, nothing that depends on a cell's name: it runs on the
+    // patch-major mirror as well (10 M cells: 15 -> 5 ms)
+    MirrorScope mir(p);
+    mir.enter();
+    const float* hot = useHot ? (const float*)p->d_hot : (const float*)nullptr;
+    if (mir.on && useHot) {
+        auto& M = p->mirror;
+        if (!M.hot) M.hot = dalloc<float>(p->N);
+        launch(p, FAM_MISC, k_mirror_gather_f32, blocks_for(p->N, 4096), WO_BLOCK, (const float*)p->d_hot, (const int32_t*)M.perm, M.hot, p->N);
+        hot = M.hot;
+    }
     launch(p, FAM_WARP, k_warp, xcd_grid(p->N), WO_BLOCK, p->fields(), (const uint8_t*)p->d_tables, (const float*)p->d_e, p->d_e2,
-           maxAmp, bias, useHot ? (const float*)p->d_hot : (const float*)nullptr);
+           maxAmp, bias, hot);
     swap_elev(p);
+    mir.finish();
 }
 
 }  // namespace wo

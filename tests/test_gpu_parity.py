@@ -328,6 +328,43 @@ def test_planets_in_flight_match_sequential(TP):
         EnsembleRunner(mesh, xyz, nd, in_flight=2).map(lambda pl, s: 1 // 0, [1, 2, 3])
 
 
+def test_mirror_layout_is_invisible(TP, oracle, monkeypatch):
+    """erodeComposite runs on a patch-major renaming of the cells (csrc/planet.hip, MirrorScope; WO_LAYOUT=index switches it
+    off).  Names enter the reference only through the initial landCells order (js/terrain-post.js:384-390) and cellNoise(r) in
+    the flood (:98-105), both kept: with glacial iterations, both floods and quantised (tie-heavy) terrain the field must be
+    the index-order run's bit for bit, and the oracle's without the libm passes."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(300000, 0.75, 5)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(5)
+    e0, oc = pl.download(), pl.download_ocean()
+    eq = (np.round(e0 * 64) / 64).astype(np.float32)          # long runs of equal heights: stable-sort history, flats, pits
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    for field, args in ((e0, (12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 4, 0.5)), (eq, (8, 3e-4, 0.5, 1.0, 8, 1.16, 0.015, 0, 0.0)),
+                        (e0, (0, 3e-4, 0.5, 1.0, 5, 1.16, 0.015, 0, 0.0))):
+        res = {}
+        for layout in ("mirror", "index"):
+            if layout == "index":
+                monkeypatch.setenv("WO_LAYOUT", "index")
+            else:
+                monkeypatch.delenv("WO_LAYOUT", raising=False)
+            got = field.copy()
+            ocm = (field <= 0).astype(np.uint8)
+            pl.erode_composite(got, ocm, *args)
+            assert pl.last_erode_stats()["mirror_layout"] == (1.0 if layout == "mirror" else 0.0)
+            res[layout] = got
+        monkeypatch.delenv("WO_LAYOUT", raising=False)
+        assert np.array_equal(res["mirror"], res["index"]), args
+        if args[7] == 0:
+            ref = oracle.erode_composite(om, field, xyz, (field <= 0).astype(np.uint8), *args, nd)
+            assert np.array_equal(res["mirror"], ref), args
+    # the call leaves the planet in its own order: a Jacobi pass after it sees the same field either way
+    a = e0.copy(); pl.erode_composite(a, oc, 3, 3e-4, 0.5, 1.0, 3, 1.16, 0.015, 0, 0.0); pl.apply_soil_creep(a, oc, 2, 0.1)
+    b = oracle.soil_creep(om, oracle.erode_composite(om, e0, xyz, oc, 3, 3e-4, 0.5, 1.0, 3, 1.16, 0.015, 0, 0.0, nd), oc, 2, 0.1)
+    assert np.array_equal(a, b)
+    pl.close()
+
+
 def test_flood_routes_agree(TP, oracle, monkeypatch):
     """The host flood's three routes — one heap per landmass pipelined with passes 2/3 (default), the same in two phases,
     and the single serial heap walk (WO_FLOOD_HOST) — are read once per process, so each runs in its own interpreter;
