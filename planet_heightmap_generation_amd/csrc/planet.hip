@@ -738,7 +738,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 int32_t* c = p->d_counters;
                 hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
                 const int32_t* in = p->d_landIdx;
-                for (int k = 1; k <= WO_FLOW_RAKE_ROUNDS; ++k) {
+                static const int rakeRounds = getenv("WO_FLOW_RAKE") ? std::max(1, atoi(getenv("WO_FLOW_RAKE"))) : WO_FLOW_RAKE_ROUNDS;
+                for (int k = 1; k <= rakeRounds; ++k) {
                     int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
                     launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
                            k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
@@ -821,6 +822,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
     if (iterations <= 0) return;
+    MirrorScope mir(p);                     // Jacobi passes read rows and neighbour values only: any naming of the cells gives the same field
+    if (iterations >= 2) mir.enter();       // (moving the field in and out costs about one pass)
     coast_flags(p);
     const int gridN = xcd_grid(p->N);
     hipStream_t s = p->ctx->stream;
@@ -832,6 +835,7 @@ static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) 
         else launch(p, FAM_CREEP, k_creep, gridN, WO_BLOCK, F, (const float*)p->d_e, p->d_e2, strength);
         swap_elev(p);
     }
+    mir.finish();
 }
 
 static void upload_tables(wo_planet* p, double seed) {
