@@ -126,12 +126,35 @@ WO_HD inline double nd_or_eps(float d) { return (d == 0.0f || d != d) ? 1e-6 : (
 // than WO_ROW (0.1 % of the cells of a jittered Fibonacci sphere) take the plain loops.  Slots past the degree hold the
 // cell itself: a valid index whose value is never used.
 constexpr int WO_ROW = 8;
+// On the device a row comes in as two 16-byte loads instead of eight 4-byte ones (rows are 4-byte aligned; the mesh arrays are
+// allocated WO_ROW entries longer than E, so the tail of the last rows stays inside the allocation): a quarter of the load
+// instructions and address computations per wave for the same lines.
+struct alignas(4) RowI4 { int32_t v[4]; };
+struct alignas(4) RowF4 { float v[4]; };
 WO_HD inline int load_row(const Fields& F, int32_t r, int32_t& b, int32_t (&nb)[WO_ROW]) {
     b = F.off[r];
     const int deg = F.off[r + 1] - b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WO_ROW == 8, "two RowI4 per row");
+    const RowI4 lo = *reinterpret_cast<const RowI4*>(F.adj + b), hi = *reinterpret_cast<const RowI4*>(F.adj + b + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { nb[k] = (k < deg) ? lo.v[k] : r; nb[k + 4] = (k + 4 < deg) ? hi.v[k] : r; }
+#else
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) nb[k] = (k < deg) ? F.adj[b + k] : r;
+#endif
     return deg;
+}
+// neighborDist of the row starting at b (entries beyond deg: 1.0f, never used)
+WO_HD inline void load_row_dist(const Fields& F, int32_t b, int deg, float (&dd)[WO_ROW]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const RowF4 lo = *reinterpret_cast<const RowF4*>(F.dist + b), hi = *reinterpret_cast<const RowF4*>(F.dist + b + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { dd[k] = (k < deg) ? lo.v[k] : 1.0f; dd[k + 4] = (k + 4 < deg) ? hi.v[k] : 1.0f; }
+#else
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) dd[k] = (k < deg) ? F.dist[b + k] : 1.0f;
+#endif
 }
 
 // js/climate-util.js:13-21 smoothField: (self + neighbours) / (1 + degree), double sum in adjacency order, f32 store
@@ -648,7 +671,8 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
         if (deg <= WO_ROW) {
             float mh[WO_ROW], dd[WO_ROW];
 #pragma unroll
-            for (int k = 0; k < WO_ROW; ++k) { mh[k] = F.me[nbs[k]]; dd[k] = (k < deg) ? F.dist[b + k] : 1.0f; }
+            for (int k = 0; k < WO_ROW; ++k) mh[k] = F.me[nbs[k]];
+            load_row_dist(F, b, deg, dd);
 #pragma unroll
             for (int k = 0; k < WO_ROW; ++k) {
                 const double nh = mh[k];
@@ -682,7 +706,8 @@ WO_HD inline float thermal_apply_row(const Fields& F, double h, int32_t myRank, 
     float mh[WO_ROW], dd[WO_ROW];
     double tx[WO_ROW]; int32_t rk[WO_ROW]; bool snd[WO_ROW];
 #pragma unroll
-    for (int k = 0; k < WO_ROW; ++k) { mh[k] = F.me[nbs[k]]; dd[k] = (k < deg) ? F.dist[b + k] : 1.0f; }
+    for (int k = 0; k < WO_ROW; ++k) mh[k] = F.me[nbs[k]];
+    load_row_dist(F, b, deg, dd);
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) {
         const double nh = mh[k], d = nd_or_eps(dd[k]);

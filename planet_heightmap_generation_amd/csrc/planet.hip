@@ -478,8 +478,9 @@ static void mirror_build(wo_planet* p) {
     hvec<int32_t> moff((size_t)N + 1);
     moff[0] = 0;
     for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_perm[i]; moff[i + 1] = moff[i] + (p->h_off[r + 1] - p->h_off[r]); }
-    M.perm = dalloc<int32_t>(N); M.inv = dalloc<int32_t>(N); M.off = dalloc<int32_t>((size_t)N + 1); M.adj = dalloc<int32_t>(E);
-    M.dist = dalloc<float>(E); M.xyz = dalloc<float>(3 * (size_t)N); M.e = dalloc<float>(N); M.e2 = dalloc<float>(N);
+    M.perm = dalloc<int32_t>(N); M.inv = dalloc<int32_t>(N); M.off = dalloc<int32_t>((size_t)N + 1); M.adj = dalloc<int32_t>(E + WO_ROW);
+    M.dist = dalloc<float>(E + WO_ROW);
+    WO_HIP(hipMemsetAsync(M.adj + E, 0, WO_ROW * sizeof(int32_t), s)); WO_HIP(hipMemsetAsync(M.dist + E, 0, WO_ROW * sizeof(float), s)); M.xyz = dalloc<float>(3 * (size_t)N); M.e = dalloc<float>(N); M.e2 = dalloc<float>(N);
     M.ocean = dalloc<uint8_t>(N); M.coast = dalloc<uint8_t>(N);
     WO_HIP(hipMemcpyAsync(M.perm, M.h_perm.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
     WO_HIP(hipMemcpyAsync(M.off, moff.data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice, s));
@@ -967,7 +968,8 @@ wo_planet* wo_planet_create(wo_ctx* ctx, int32_t numRegions, const int32_t* adjO
         p->h_adj.assign(adjList, adjList + E);
         p->h_xyz.assign(r_xyz, r_xyz + 3 * (size_t)N);
         hipStream_t s = ctx->stream;
-        p->d_off = dalloc<int32_t>(N + 1); p->d_adj = dalloc<int32_t>(E); p->d_dist = dalloc<float>(E); p->d_xyz = dalloc<float>(3 * (size_t)N);
+        p->d_off = dalloc<int32_t>(N + 1); p->d_adj = dalloc<int32_t>((size_t)E + WO_ROW); p->d_dist = dalloc<float>((size_t)E + WO_ROW); p->d_xyz = dalloc<float>(3 * (size_t)N);   // + WO_ROW: load_row reads whole 16-byte pieces
+        WO_HIP(hipMemsetAsync(p->d_adj + E, 0, WO_ROW * sizeof(int32_t), s)); WO_HIP(hipMemsetAsync(p->d_dist + E, 0, WO_ROW * sizeof(float), s));
         p->d_e = dalloc<float>(N); p->d_e2 = dalloc<float>(N); p->d_hot = dalloc<float>(N); p->d_orig = dalloc<float>(N);
         p->d_ocean = dalloc<uint8_t>(N); p->d_coast = dalloc<uint8_t>(N); p->d_tables = dalloc<uint8_t>(1024);
         WO_HIP(hipHostMalloc((void**)&p->h_pinned, std::max<size_t>((size_t)N * sizeof(float), 64)));
