@@ -246,6 +246,29 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_rake(Fields F, int32_t* donor
         block_append4(cnt, vals, out, outCount);
     }
 }
+// The rake as ONE launch (WO_FLOW_CLIMB=<cap>): every leaf hands its total to its receiver, and the thread whose hand-over
+// completes a receiver (last donor in) carries on with that receiver, at most `cap` cells up; what is left goes to the pointer
+// doubling as before.  Integer sums: any order is exact.  Ordering between threads: a donor's add to acc[j] is a RETURNING
+// atomic whose result is consumed before the donor counts itself into donorCnt[j], so it has been performed when the count
+// becomes visible; the thread that sees the count complete reads acc[j] with an agent-scope atomic load.
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_climb(Fields F, int32_t* donorCnt, int32_t cap) {
+    WO_XCD_LAND(i, r) {
+        int32_t d = r;
+        if (!((donorCnt[d] & 0xffff) == 0 && F.jumpA[d] >= 0)) continue;
+        uint32_t v = F.accA[d];
+        for (int32_t step = 0; step < cap; ++step) {
+            const int32_t j = F.jumpA[d];
+            const uint32_t before = atomicAdd(&F.accA[j], v);
+            asm volatile("" ::"v"(before) : "memory");          // the add has returned (performed) before anything below is issued
+            F.jumpA[d] = -2;                                      // retired
+            const int32_t old = atomicAdd(&donorCnt[j], 0x10000);
+            if ((old >> 16) + 1 != (old & 0xffff)) break;         // other donors of j are still out
+            if (F.jumpA[j] < 0) break;                            // a root keeps the sum
+            d = j;
+            v = __hip_atomic_load(&F.accA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount) {
     const int32_t groups = (L + 3) / 4;
     WO_BLOCK_STRIDE(g, valid, groups) {

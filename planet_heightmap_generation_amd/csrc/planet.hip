@@ -47,7 +47,11 @@ template <class T> static T* dalloc(size_t n) { void* q = nullptr; WO_HIP(hipMal
 template <class T> static void dfree(T*& q) { if (q) { (void)hipFree(q); q = nullptr; } }
 
 constexpr int WO_PATCH_TOTAL_SLOTS = 4096;         // pending-total slots of the patch solve (one per launch, reused modulo)
-constexpr int WO_FLOW_RAKE_ROUNDS = 8;             // rake rounds before the pointer doubling of the flow accumulation
+constexpr int WO_FLOW_RAKE_ROUNDS = 8;             // rake rounds before the pointer doubling of the flow accumulation (WO_FLOW_CLIMB=0)
+// The rake as one launch in which the thread that completes a receiver carries on with it, at most this many cells up
+// (k_flow_climb).  10 M cells, per step: 8 rake launches 67 ms -> one launch 42 ms, flow stage 110 -> 86 ms; cap 4 / 8 / 16 / 48:
+// flow stage 94 / 86 / 86 / 102 ms (profiles/r02r_flow_climb.txt).  0 = the synchronous rake rounds.
+constexpr int WO_FLOW_CLIMB_CAP = 12;
 
 static void ensure_scratch(wo_planet* p) {
     if (p->scratch) return;
@@ -117,15 +121,20 @@ static int32_t read_count(wo_planet* p, const int32_t* d_ptr) {
 // ---------------------------------------------------------------------------------------------------
 template <class LaunchRound>
 static int64_t run_rounds(wo_planet* p, const int32_t* firstList, int32_t firstCount, bool countOnDevice, int batch,
-                          LaunchRound launchRound) {
+                          LaunchRound launchRound, int32_t* firstCountHint = nullptr) {
     int32_t* c = p->d_counters;
     hipStream_t s = p->ctx->stream;
+    bool hinted = false;
     if (countOnDevice) {
         // caller left the count in c[3]; move it to c[1], clear c[0], c[2]
         WO_HIP(hipMemcpyAsync(c + 1, c + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         WO_HIP(hipMemsetAsync(c, 0, sizeof(int32_t), s));
         WO_HIP(hipMemsetAsync(c + 2, 0, sizeof(int32_t), s));
-        firstCount = read_count(p, c + 1);
+        // The count only sizes the grid (the kernels read it on the device and stride over their list): a caller whose first
+        // list barely changes between calls passes last call's count instead of paying a stream synchronisation for this one;
+        // the true count comes back with the first batch's read-back.
+        if (firstCountHint && *firstCountHint > 0) { firstCount = *firstCountHint + *firstCountHint / 4 + 1024; hinted = true; }
+        else firstCount = read_count(p, c + 1);
     } else {
         hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, firstCount, 0, 0);
     }
@@ -140,10 +149,17 @@ static int64_t run_rounds(wo_planet* p, const int32_t* firstList, int32_t firstC
             in = out;
             out = (out == p->d_listA) ? p->d_listB : p->d_listA;
         }
-        const int32_t next = read_count(p, c + (k % 3));
+        int32_t next;
+        if (firstCountHint && countOnDevice) {               // c[3] still holds the first list's count
+            WO_HIP(hipMemcpyAsync(p->h_count, c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            WO_HIP(hipStreamSynchronize(s));
+            next = p->h_count[k % 3];
+            *firstCountHint = p->h_count[3];
+        } else next = read_count(p, c + (k % 3));
         if (k > 4 * (int64_t)p->N + 1024) throw HipError{"dependency rounds do not converge"};
         count = next;
     }
+    (void)hinted;
     return k - 1;
 }
 
@@ -567,7 +583,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     {
         int32_t* hl = reinterpret_cast<int32_t*>(p->h_pinned);
         int32_t L = 0;
-        for (int32_t r = 0; r < N; ++r) if (!p->h_ocean[r]) hl[L++] = r;
+        {
+            const uint8_t* oc = p->h_ocean.data();
+            std::vector<int64_t> cnt(host_threads() + 2, 0);
+            parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t r = b; r < e; ++r) c += oc[r] ? 0 : 1; cnt[t + 1] = c; });
+            for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+            parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t o = cnt[t]; for (int64_t r = b; r < e; ++r) if (!oc[r]) hl[o++] = (int32_t)r; });
+            L = (int32_t)cnt.back();
+        }
         p->L = L;
         if (L == 0) { clk.end(); clk.finish(); return; }
         if (mir.on) {
@@ -645,6 +668,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     // and a list that is one pass old already needs 28 launches (profiles/r02c_river_patch_experiment.txt).
     static const int riverEvery = getenv("WO_RIVER_PATCHES") ? atoi(getenv("WO_RIVER_PATCHES")) : 0;
     int sinceRiver = -1;
+    int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
     for (int32_t iter = 0; iter < total; ++iter) {
         if (!midDone && iter >= midIter) { midDone = true; flood(0.85); sinceRiver = -1; }
@@ -740,7 +764,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
                 const int32_t* in = p->d_landIdx;
                 static const int rakeRounds = getenv("WO_FLOW_RAKE") ? std::max(1, atoi(getenv("WO_FLOW_RAKE"))) : WO_FLOW_RAKE_ROUNDS;
-                for (int k = 1; k <= rakeRounds; ++k) {
+                static const int climbCap = getenv("WO_FLOW_CLIMB") ? std::max(0, atoi(getenv("WO_FLOW_CLIMB"))) : WO_FLOW_CLIMB_CAP;
+                if (climbCap > 0) launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, p->d_flowCnt, (int32_t)climbCap);
+                for (int k = 1; k <= rakeRounds && climbCap == 0; ++k) {
                     int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
                     launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
                            k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
@@ -750,12 +776,15 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3);
             }
             // pointer doubling on what is left (the cells queued for the next rake round included)
-            flowRounds += run_rounds(p, p->d_listB, 0, true, 4,
+            // 8 doubling rounds per read-back: at 10 M cells a pass needs 8 (the skeleton's paths are < 256 cells after the rake),
+            // and a stream synchronisation costs as much as several empty rounds (flow stage 87 -> 80 ms per step)
+            static const int flowBatch = getenv("WO_FLOW_BATCH") ? std::max(1, atoi(getenv("WO_FLOW_BATCH"))) : 8;
+            flowRounds += run_rounds(p, p->d_listB, 0, true, flowBatch,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
                     launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
                            (const int32_t*)p->d_nj, out, outC, zeroC);
-                });
+                }, getenv("WO_FLOW_NO_HINT") ? nullptr : &flowCountHint);
             launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, F, p->d_flowCnt);
             clk.end();
             clk.begin("solve");
