@@ -95,6 +95,7 @@ struct Fields {
     float* cellDist;           // [N]
     float* flow;               // [N]
     uint32_t* accA; uint32_t* accB;     // pointer-doubling accumulators [N]
+    unsigned long long* accCnt;         // rake (k_flow_climb): {donors arrived, running total} of a cell in one word [N]
     int32_t* jumpA; int32_t* jumpB;     // pointer-doubling ancestors [N]
     // solve dataflow
     SolveTask* task;                    // per-land-cell task record built by solve_setup [N], at the store index

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         const int32_t t = receiver_cell(F, r);
         int32_t j = -1; const uint32_t a = 1;
         if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
-        F.accA[r] = a; F.jumpA[r] = j;
+        F.accA[r] = a; F.jumpA[r] = j; F.accCnt[r] = 1ull;
         if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
     }
 }
@@ -248,34 +248,41 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_rake(Fields F, int32_t* donor
 }
 // The rake as ONE launch (WO_FLOW_CLIMB=<cap>): every leaf hands its total to its receiver, and the thread whose hand-over
 // completes a receiver (last donor in) carries on with that receiver, at most `cap` cells up; what is left goes to the pointer
-// doubling as before.  Integer sums: any order is exact.  Ordering between threads: a donor's add to acc[j] is a RETURNING
-// atomic whose result is consumed before the donor counts itself into donorCnt[j], so it has been performed when the count
-// becomes visible; the thread that sees the count complete reads acc[j] with an agent-scope atomic load.
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_climb(Fields F, int32_t* donorCnt, int32_t cap) {
+// doubling as before.  Integer sums: any order is exact.  A cell's running total and the number of donors that have arrived
+// share one 64-bit word (accCnt), so ONE returning atomic both delivers a total and tells the deliverer whether it was the
+// last — then old total + its own contribution IS the cell's total: no ordering between two atomics to arrange, one memory
+// round trip per step.  k_flow_remaining copies the totals of the cells that stay into accA for the pointer doubling.
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_climb(Fields F, const int32_t* donorCnt, int32_t cap) {
     WO_XCD_LAND(i, r) {
         int32_t d = r;
-        if (!((donorCnt[d] & 0xffff) == 0 && F.jumpA[d] >= 0)) continue;
-        uint32_t v = F.accA[d];
+        if (!(donorCnt[d] == 0 && F.jumpA[d] >= 0)) continue;
+        unsigned long long v = 1;                                 // a leaf's total
         for (int32_t step = 0; step < cap; ++step) {
             const int32_t j = F.jumpA[d];
-            const uint32_t before = atomicAdd(&F.accA[j], v);
-            asm volatile("" ::"v"(before) : "memory");          // the add has returned (performed) before anything below is issued
+            const int32_t donors = donorCnt[j];                   // fixed since the receivers pass
+            const unsigned long long old = atomicAdd(&F.accCnt[j], (1ull << 32) | v);
             F.jumpA[d] = -2;                                      // retired
-            const int32_t old = atomicAdd(&donorCnt[j], 0x10000);
-            if ((old >> 16) + 1 != (old & 0xffff)) break;         // other donors of j are still out
+            if ((int32_t)(old >> 32) + 1 != donors) break;        // other donors of j are still out
             if (F.jumpA[j] < 0) break;                            // a root keeps the sum
             d = j;
-            v = __hip_atomic_load(&F.accA[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = (old & 0xffffffffull) + v;
         }
     }
 }
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount) {
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount, int32_t fromClimb) {
     const int32_t groups = (L + 3) / 4;
     WO_BLOCK_STRIDE(g, valid, groups) {
         int32_t vals[4]; int cnt = 0;
         if (valid) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int32_t i = 4 * g + q; if (i < L) { const int32_t r = land[i]; if (F.jumpA[r] >= 0) vals[cnt++] = r; } }
+            for (int q = 0; q < 4; ++q) {
+                const int32_t i = 4 * g + q;
+                if (i < L) {
+                    const int32_t r = land[i];
+                    if (fromClimb) F.accA[r] = (uint32_t)F.accCnt[r];          // totals after k_flow_climb (retired cells: no longer read)
+                    if (F.jumpA[r] >= 0) vals[cnt++] = r;
+                }
+            }
         }
         block_append4(cnt, vals, out, outCount);
     }

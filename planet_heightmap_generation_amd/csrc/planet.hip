@@ -60,7 +60,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
     p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_ev = dalloc<EventList>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
-    p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
+    p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_accCnt = dalloc<unsigned long long>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
@@ -81,7 +81,7 @@ wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = (getenv("WO_NO_EVENT_LISTS") == nullptr) ? d_ev : nullptr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
-    F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.jumpA = d_jump; F.jumpB = nullptr;
+    F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
     return F;
@@ -736,6 +736,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     k = (int64_t)p->h_count[0] + 1;
                     count = 0;
                 }
+                // (one burst sized by the previous glacial iteration instead of a read-back per 16 rounds: slower, 102 -> 110 ms per step —
+                // the read-back is also what shrinks the grid with the list)
                 while (count > 0) {
                     const int grid = blocks_for(count, 2048);
                     for (int b = 0; b < 16; ++b, ++k) {
@@ -773,7 +775,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     in = out;
                 }
                 WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
-                launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3);
+                launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3, (int32_t)(climbCap > 0));
             }
             // pointer doubling on what is left (the cells queued for the next rake round included)
             // 8 doubling rounds per read-back: at 10 M cells a pass needs 8 (the skeleton's paths are < 256 cells after the rake),
@@ -1036,7 +1038,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

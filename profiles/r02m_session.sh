@@ -15,11 +15,3 @@ for l in open(sys.argv[1]):
         print('  stages', {k: round(v) for k, v in st.items()})
         print('  families', {k: round(v['ms'],1) for k, v in fam.items() if v['ms'] > 3})
 P
-WO_FLOW_NO_HINT=1 timeout 600 python bench.py --no-cpu --in-flight 0 --steps 2 --warmup 1 > $O/bench_nohint.log 2>&1
-python - $O/bench_nohint.log <<'P'
-import json,sys
-for l in open(sys.argv[1]):
-    if l.startswith('{'):
-        d=json.loads(l); st=d['stage_ms_last_step']
-        print('no hint: ms/step %.0f'%d['ms_per_step'], 'crc', d['parity']['parity_crc_ok'], 'flow %.1f'%st['flow'])
-P
