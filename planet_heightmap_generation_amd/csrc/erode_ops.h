@@ -362,8 +362,11 @@ WO_HD inline void event_insert(EventList& E, int& n, bool& over, int32_t cell, i
         cell = up ? c2 : cell; rank = up ? r2 : rank;
     }
 }
+// forward total of a cell after the flow accumulation: the packed {arrived, total} word when the one-launch rake retired every
+// cell (Fields::accCnt set by the driver), else the pointer doubling's accumulator
+WO_HD inline uint32_t flow_total(const Fields& F, int32_t c) { return F.accCnt ? (uint32_t)F.accCnt[c] : F.accA[c]; }
 WO_HD inline void flow_final_cell(const Fields& F, int32_t c) {
-    uint32_t f = F.accA[c];
+    uint32_t f = flow_total(F, c);
     const TargetRank trc = F.tr[c];
     const int32_t rc = trc.rank;
     EventList E;
@@ -380,7 +383,7 @@ WO_HD inline void flow_final_cell(const Fields& F, int32_t c) {
 #pragma unroll
         for (int k = 0; k < WO_ROW; ++k) {
             if (k < deg && q[k].target == c) {
-                if (q[k].rank > rc) f += F.accA[nbs[k]];                              // late donor, un-forwarded
+                if (q[k].rank > rc) f += flow_total(F, nbs[k]);                              // late donor, un-forwarded
                 event_insert(E, n, over, nbs[k], q[k].rank);
             }
         }
@@ -389,7 +392,7 @@ WO_HD inline void flow_final_cell(const Fields& F, int32_t c) {
             const int32_t nb = F.adj[j];
             const TargetRank v = F.tr[nb];
             if (v.target != c) continue;
-            if (v.rank > rc) f += F.accA[nb];
+            if (v.rank > rc) f += flow_total(F, nb);
             event_insert(E, n, over, nb, v.rank);
         }
     }

@@ -48,10 +48,7 @@ template <class T> static void dfree(T*& q) { if (q) { (void)hipFree(q); q = nul
 
 constexpr int WO_PATCH_TOTAL_SLOTS = 4096;         // pending-total slots of the patch solve (one per launch, reused modulo)
 constexpr int WO_FLOW_RAKE_ROUNDS = 8;             // rake rounds before the pointer doubling of the flow accumulation (WO_FLOW_CLIMB=0)
-// The rake as one launch in which the thread that completes a receiver carries on with it, at most this many cells up
-// (k_flow_climb).  10 M cells, per step: 8 rake launches 67 ms -> one launch 42 ms, flow stage 110 -> 86 ms; cap 4 / 8 / 16 / 48:
-// flow stage 94 / 86 / 86 / 102 ms (profiles/r02r_flow_climb.txt).  0 = the synchronous rake rounds.
-constexpr int WO_FLOW_CLIMB_CAP = 12;
+
 
 static void ensure_scratch(wo_planet* p) {
     if (p->scratch) return;
@@ -761,33 +758,48 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();
             clk.begin("flow");
-            {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
-                int32_t* c = p->d_counters;
-                hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
-                const int32_t* in = p->d_landIdx;
-                static const int rakeRounds = getenv("WO_FLOW_RAKE") ? std::max(1, atoi(getenv("WO_FLOW_RAKE"))) : WO_FLOW_RAKE_ROUNDS;
-                static const int climbCap = getenv("WO_FLOW_CLIMB") ? std::max(0, atoi(getenv("WO_FLOW_CLIMB"))) : WO_FLOW_CLIMB_CAP;
-                if (climbCap > 0) launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, p->d_flowCnt, (int32_t)climbCap);
-                for (int k = 1; k <= rakeRounds && climbCap == 0; ++k) {
-                    int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
-                    launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
-                           k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
-                    in = out;
+            // Flow accumulation = subtree sizes of the forward forest (integers: any order of the additions is exact).
+            //  default           one launch: every leaf hands its total to its receiver and the thread that completes a receiver
+            //                    carries on with it (k_flow_climb).  Every cell with a forward receiver is retired this way, so
+            //                    nothing is left for the pointer doubling; k_flow_final reads the packed totals.
+            //  WO_FLOW_CLIMB=n   a thread carries on for at most n cells; the rest by pointer doubling (cross-check / terrain with
+            //                    very long unbranched chains, where one thread's walk would bound the launch)
+            //  WO_FLOW_CLIMB=0   the synchronous rake rounds + pointer doubling of earlier builds
+            // 10 M cells, flow stage per step: rake rounds 108 ms, cap 12: 69, cap 128: 60, cap 256: 59, no cap: 45 (profiles/r02r_*).
+            const char* climbEnv = getenv("WO_FLOW_CLIMB");
+            const int climbCap = climbEnv ? std::max(0, atoi(climbEnv)) : 0x7fffffff;
+            const bool climbAll = climbCap == 0x7fffffff;
+            if (climbCap > 0) launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, (const int32_t*)p->d_flowCnt, (int32_t)climbCap);
+            if (!climbAll) {
+                {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
+                    int32_t* c = p->d_counters;
+                    hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
+                    const int32_t* in = p->d_landIdx;
+                    static const int rakeRounds = getenv("WO_FLOW_RAKE") ? std::max(1, atoi(getenv("WO_FLOW_RAKE"))) : WO_FLOW_RAKE_ROUNDS;
+                    for (int k = 1; k <= rakeRounds && climbCap == 0; ++k) {
+                        int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
+                        launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
+                               k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
+                        in = out;
+                    }
+                    WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
+                    launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3, (int32_t)(climbCap > 0));
                 }
-                WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
-                launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3, (int32_t)(climbCap > 0));
+                // pointer doubling on what is left (the cells queued for the next rake round included); 8 rounds per read-back: a
+                // stream synchronisation costs as much as several empty rounds
+                static const int flowBatch = getenv("WO_FLOW_BATCH") ? std::max(1, atoi(getenv("WO_FLOW_BATCH"))) : 8;
+                flowRounds += run_rounds(p, p->d_listB, 0, true, flowBatch,
+                    [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
+                        launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
+                        launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
+                               (const int32_t*)p->d_nj, out, outC, zeroC);
+                    }, getenv("WO_FLOW_NO_HINT") ? nullptr : &flowCountHint);
             }
-            // pointer doubling on what is left (the cells queued for the next rake round included)
-            // 8 doubling rounds per read-back: at 10 M cells a pass needs 8 (the skeleton's paths are < 256 cells after the rake),
-            // and a stream synchronisation costs as much as several empty rounds (flow stage 87 -> 80 ms per step)
-            static const int flowBatch = getenv("WO_FLOW_BATCH") ? std::max(1, atoi(getenv("WO_FLOW_BATCH"))) : 8;
-            flowRounds += run_rounds(p, p->d_listB, 0, true, flowBatch,
-                [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
-                    launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
-                    launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
-                           (const int32_t*)p->d_nj, out, outC, zeroC);
-                }, getenv("WO_FLOW_NO_HINT") ? nullptr : &flowCountHint);
-            launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, F, p->d_flowCnt);
+            {
+                Fields Ff = F;
+                if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
+                launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt);
+            }
             clk.end();
             clk.begin("solve");
             // the solve's patch list follows the drainage forest (river.hip); the forest drifts slowly, so the list is

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Flow accumulation: the 8 rake launches against one "last donor carries on" launch (WO_FLOW_CLIMB=<cap>), 10 M cells x 200 iterations
+# Flow accumulation: cap of the one-launch rake (k_flow_climb, packed count+total), 10 M cells x 200 iterations
 set -u
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -11,12 +11,12 @@ for l in open(sys.argv[1]):
     if l.startswith('{'):
         ok=True
         d=json.loads(l); st=d['stage_ms_last_step']; es=d['erode_stats']; fam=d['roofline']['families']
-        print(sys.argv[2], 'ms/step %.0f'%d['ms_per_step'], 'crc', d['parity']['parity_crc_ok'], 'flow %.1f'%st['flow'], 'rake/snap %.1f (%d launches)'%(fam['flow_snap']['ms'], fam['flow_snap']['launches']), 'apply %.1f'%fam['flow_apply']['ms'], 'flow rounds', es['flow_rounds_total'])
+        print(sys.argv[2], 'ms/step %.0f'%d['ms_per_step'], 'crc', d['parity']['parity_crc_ok'], 'flow %.1f'%st['flow'], 'climb+snap %.1f (%d launches)'%(fam['flow_snap']['ms'], fam['flow_snap']['launches']), 'apply %.1f'%fam['flow_apply']['ms'], 'flow rounds', es['flow_rounds_total'])
 if not ok: print(open(sys.argv[1]).read()[-1500:])
 P
 }
-run default12 WO_X=1
-run rake_rounds WO_FLOW_CLIMB=0
-run batch8 WO_FLOW_BATCH=8
-run batch6 WO_FLOW_BATCH=6
-
+run cap128 WO_FLOW_CLIMB=128
+run cap256 WO_FLOW_CLIMB=256
+run cap1024 WO_FLOW_CLIMB=1024
+run cap1M WO_FLOW_CLIMB=1000000
+run cap128_again WO_FLOW_CLIMB=128

@@ -365,6 +365,39 @@ def test_mirror_layout_is_invisible(TP, oracle, monkeypatch):
     pl.close()
 
 
+def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
+    """Flow accumulation (js/terrain-post.js:604-611) = subtree sizes of the drainage forest.  Default: one launch in which the
+    thread that completes a receiver carries on with it (k_flow_climb); WO_FLOW_CLIMB=n caps a thread's walk and leaves the rest
+    to the pointer doubling; WO_FLOW_CLIMB=0 is the synchronous rake + pointer doubling.  Integer sums: all routes must give the
+    oracle's field bit for bit, on ordinary and on quantised (flat-heavy: long unbranched chains) terrain."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(250000, 0.75, 9)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(9)
+    e0 = pl.download()
+    eq = (np.round(e0 * 32) / 32).astype(np.float32)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    args = (10, 3e-4, 0.5, 1.0, 4, 1.16, 0.015, 0, 0.0)
+    for field in (e0, eq):
+        oc = (field <= 0).astype(np.uint8)
+        ref = oracle.erode_composite(om, field, xyz, oc, *args, nd)
+        for route in (None, "3", "40", "0"):
+            if route is None:
+                monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+            else:
+                monkeypatch.setenv("WO_FLOW_CLIMB", route)
+            got = field.copy()
+            pl.erode_composite(got, oc, *args)
+            st = pl.last_erode_stats()
+            assert np.array_equal(got, ref), (route, int((got != ref).sum()))
+            if route is None:
+                assert st["flow_rounds_total"] == 0, st["flow_rounds_total"]          # nothing left for the pointer doubling
+            elif route in ("3", "0"):
+                assert st["flow_rounds_total"] > 0, (route, st["flow_rounds_total"])  # the doubling really ran
+    monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+    pl.close()
+
+
 def test_flood_routes_agree(TP, oracle, monkeypatch):
     """The host flood's three routes — one heap per landmass pipelined with passes 2/3 (default), the same in two phases,
     and the single serial heap walk (WO_FLOOD_HOST) — are read once per process, so each runs in its own interpreter;
