@@ -45,7 +45,7 @@ ALGO_BYTES = {
     "rank_scatter": (8.0, 0.0),
     "receivers": (68.0, 4.0),              # own elev, adjOffset, adjList, nb elev, dist, writes + target fill
     "flow_init": (8.0, 4.0),
-    "flow_snap": (16.0, 0.0),              # flow family: 16 B/land cell per pass
+    "flow_snap": (16.0, 0.0),              # flow family: 16 B/land cell per pass (this family holds k_flow_climb, the one-launch accumulation)
     "flow_apply": (16.0, 0.0),
     "flow_final": (16.0, 4.0),
     "solve_setup": (45.0, 0.0),            # solve family: 45 B/land cell per pass
