@@ -29,6 +29,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #include "noise.h"
 
@@ -49,10 +50,12 @@ struct alignas(WO_TASK_ALIGN) SolveTask {
     int32_t predSelf, predT, predT2;   // granule index 2*store + (0: that task's own turn, 1: its deposit on its receiver), -1: none
     uint32_t flags;                    // bit0: target is ocean, bit1: t2 is ocean, bit2: has a target, bit3: has a t2
     float e0r, e0t, e0t2;              // heights before the pass (used where there is no predecessor event)
-    float flow;                        // flow[r]
-    float cellDist, cellDistT;         // cellDist[r], cellDist[target]
+    float cellDistT;                   // cellDist[target]
+    double factor;                     // K * flow[r]^m * dt / cellDist[r] (js/terrain-post.js:621-622): depends on nothing the pass changes, so
+                                       // solve_setup works it out once per task instead of every visit of the task's patch before it may poll
     int32_t pad_[2];
 };
+static_assert(sizeof(SolveTask) == 48, "one 48-byte record per task");
 #ifndef WO_PATCH_CELLS
 #define WO_PATCH_CELLS 1024
 #endif
@@ -101,6 +104,7 @@ struct Fields {
     SolveTask* task;                    // per-land-cell task record built by solve_setup [N], at the store index
     const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean [N]; nullptr: store index = cell
     SolveOut* out;                      // per-task event outputs {own turn, deposit on receiver} [N], at the store index
+    double solveK, solveM, solveDt;     // the pass's constants (K, m, dt): solve_setup folds them into SolveTask::factor
     int32_t* blk;                       // patch solve: granule that was seen unresolved when the task last failed, or -1 [N], at the store index
     EventList* ev;                      // events per location [N] (land entries written by flow_final_cell); nullptr: row scans
     int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]
@@ -444,6 +448,11 @@ WO_HD inline int32_t store_index(const Fields& F, int32_t cell) { return F.slotO
 // granule index of the event task p leaves on location x (p == x: own turn, else deposit)
 WO_HD inline int32_t granule_index(const Fields& F, int32_t x, int32_t p) { return p < 0 ? -1 : 2 * store_index(F, p) + (p == x ? 0 : 1); }
 
+WO_HD inline double solve_factor_of(float flow, float cellDist, double K, double m, double dt) {
+    const double fl = flow;
+    const double pw = (m == 0.5) ? sqrt(fl) : pow(fl, m);
+    return K * pw * dt / (double)cellDist;
+}
 WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r);
 WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r);
 // setup from the event lists (flow_final_cell); any list involved overflowed -> the row scans
@@ -469,7 +478,7 @@ WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
     T.predSelf = granule_index(F, r, event_before(Er, r, rr));
     T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
     T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
-    T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
+    T.factor = solve_factor_of(F.flow[r], F.cellDist[r], F.solveK, F.solveM, F.solveDt);
     if (t >= 0) {
         T.flags |= 4u;
         T.e0t = F.e[t];
@@ -523,7 +532,7 @@ WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r) {
     T.predSelf = granule_index(F, r, latest_event_before_row(r, r, rr, trr, nbR, qR, degR));
     T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
     T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
-    T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
+    T.factor = solve_factor_of(F.flow[r], F.cellDist[r], F.solveK, F.solveM, F.solveDt);
     if (t >= 0) {
         T.flags |= 4u;
         T.e0t = F.e[t];
@@ -552,7 +561,7 @@ WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     T.predSelf = granule_index(F, r, latest_event_before(F, r, r));
     T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
     T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
-    T.flow = F.flow[r]; T.cellDist = F.cellDist[r];
+    T.factor = solve_factor_of(F.flow[r], F.cellDist[r], F.solveK, F.solveM, F.solveDt);
     if (t >= 0) {
         T.flags |= 4u;
         T.e0t = F.e[t];
@@ -577,28 +586,79 @@ WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
 }
 
-// one turn of the implicit solve + deposition (js/terrain-post.js:616-640) given its three inputs.
-// solve_factor is the part that does not depend on the predecessors (callers on a dependency chain hoist it).
-WO_HD inline double solve_factor(const SolveTask& T, double K, double m, double dt) {
-    const double fl = T.flow;
-    const double pw = (m == 0.5) ? sqrt(fl) : pow(fl, m);
-    return K * pw * dt / (double)T.cellDist;
+// ---- divisions by per-task constants, taken off the dependency chain ----
+// The compiler expands an f64 division x / y into: v_div_scale of both operands, v_rcp of the divisor, two Newton steps on the
+// reciprocal (4 fma), then q0 = x * r, e = fma(-y, q0, x), q = fma(e, r, q0) (v_div_fmas) and v_div_fixup for the special
+// cases.  When neither operand needs scaling (both far from the ends of the exponent range) the scales are identities, the
+// v_div_fmas is a plain fma and the fix-up passes q through, so everything before q0 depends on the divisor alone:
+// div_prepare() runs that part once per task, before the task starts to wait for its predecessors, and div_by_prepared()
+// is the three-instruction tail: the same instructions on the same values as the full sequence, hence the same bits (the
+// parity tests and the CRC of the benched field compare the result with the oracle's plain divisions).  Operands outside the
+// safe window take the plain division.  MEASURED SLOWER (10 M cells, 200 iterations: patch solve 345 ms with plain divisions, 361 ms
+// with the first divisor prepared, 391 ms with both; results identical, profiles/r02x_prepared_division_ab.txt): a visit pays the
+// preparation for every task it hands out, and that sits before the first poll.  Compiled only with -DWO_PREPARED_DIV.
+struct PreparedDivisor { double y, r; bool ok; };
+WO_HD inline bool div_safe_exponent(double v) {             // 2^-500 <= |v| < 2^501: no scaling in v_div_scale, quotient normal
+    unsigned long long b; memcpy(&b, &v, 8);
+    return (uint32_t)((uint32_t)(b >> 52) & 0x7ffu) - 523u <= 1000u;
 }
-WO_HD inline SolveOut solve_apply(const SolveTask& T, double factor, double er, double et, double et2, int32_t tag) {
+WO_HD inline PreparedDivisor div_prepare(double y) {
+    PreparedDivisor P; P.y = y; P.r = 0; P.ok = false;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WO_PREPARED_DIV)
+    P.ok = y > 0 && div_safe_exponent(y);
+    const double r0 = __builtin_amdgcn_rcp(y);
+    const double f0 = __builtin_fma(-y, r0, 1.0);
+    const double r1 = __builtin_fma(r0, f0, r0);
+    const double f1 = __builtin_fma(-y, r1, 1.0);
+    P.r = __builtin_fma(r1, f1, r1);
+#endif
+    return P;
+}
+WO_HD inline double div_by_prepared(double x, const PreparedDivisor& P) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(WO_PREPARED_DIV)
+    unsigned long long b; memcpy(&b, &x, 8);
+    if (P.ok && (long long)b >= 0) {                         // sign bit clear (-0, negative x: plain division)
+        if (b == 0) return 0.0;                              // +0 / y, y > 0
+        if ((uint32_t)(b >> 52) - 523u <= 1000u) {           // 2^-500 <= x < 2^501 (inf / NaN fall outside)
+            const double q0 = x * P.r;
+            const double e = __builtin_fma(-P.y, q0, x);
+            return __builtin_fma(e, P.r, q0);
+        }
+    }
+#endif
+    return x / P.y;
+}
+
+// one turn of the implicit solve + deposition (js/terrain-post.js:616-640) given its three inputs.
+// solve_prepare is the part that does not depend on the predecessors (callers on a dependency chain hoist it).
+struct SolvePrepared { double factor; PreparedDivisor onePlusFactor, cellDistT; };
+WO_HD inline double solve_factor(const SolveTask& T, double, double, double) { return T.factor; }
+WO_HD inline SolvePrepared solve_prepare(const SolveTask& T, double K, double m, double dt) {
+    SolvePrepared S;
+    S.factor = solve_factor(T, K, m, dt);
+    S.onePlusFactor = div_prepare(1 + S.factor);
+#ifdef WO_DIV_FIRST_ONLY
+    S.cellDistT.y = (double)T.cellDistT; S.cellDistT.r = 0; S.cellDistT.ok = false;
+#else
+    S.cellDistT = div_prepare((double)T.cellDistT);
+#endif
+    return S;
+}
+WO_HD inline SolveOut solve_apply(const SolveTask& T, const SolvePrepared& S, double er, double et, double et2, int32_t tag) {
     SolveOut o;
     o.self.tag = tag; o.dep.tag = tag;
     if (!(T.flags & 4u)) {       // isolated cell: the serial loop skips it (cellDist is > 0 by construction otherwise)
         o.self.v = (float)er; o.dep.v = 0; return o;
     }
     const double hr = et > 0 ? et : 0;
-    double hn = (er + factor * hr) / (1 + factor);
+    double hn = div_by_prepared(er + S.factor * hr, S.onePlusFactor);
     if (hn < hr) hn = hr;
     if (hn < 0) hn = 0;
     const double eroded = er - hn;
     float tval = (float)et;
     if (eroded > 0 && !(T.flags & 1u)) {
         double slope = 0;
-        if (T.flags & 8u) slope = fabs(et - et2) / (double)T.cellDistT;
+        if (T.flags & 8u) slope = div_by_prepared(fabs(et - et2), S.cellDistT);
         const double depositFrac = 0.5 / (1 + slope * 50);
         const double deposit = eroded * depositFrac;
         tval = (float)(et + deposit);
@@ -608,7 +668,7 @@ WO_HD inline SolveOut solve_apply(const SolveTask& T, double factor, double er, 
     return o;
 }
 WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, double et2, int32_t tag, double K, double m, double dt) {
-    return solve_apply(T, solve_factor(T, K, m, dt), er, et, et2, tag);
+    return solve_apply(T, solve_prepare(T, K, m, dt), er, et, et2, tag);
 }
 
 // Returns true when the task ran (all predecessors were produced in rounds < round).  Level-round schedule only

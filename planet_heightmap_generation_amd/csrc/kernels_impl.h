@@ -499,7 +499,8 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
     const unsigned long long BLOCKED = 0xffffffff00000000ull;              // tag -1
     volatile unsigned long long* vs = reinterpret_cast<volatile unsigned long long*>(s_out);
     SolveTask T;
-    double er = 0, et = 0, et2 = 0, factor = 0;
+    double er = 0, et = 0, et2 = 0;
+    SolvePrepared pre;
     bool unresolved = tid < ncand;
     int32_t t = 0, s = 0, ran = 0;
     if (unresolved) {
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
         if (T.predT >= 0 && !is_local(T.predT) && !ext_ready(T.predT, et)) fail = T.predT;
         if (T.predT2 >= 0 && !is_local(T.predT2) && !ext_ready(T.predT2, et2)) fail = T.predT2;
         if (fail >= 0) { F.blk[s] = fail; unresolved = false; vs[2 * t] = BLOCKED; vs[2 * t + 1] = BLOCKED; }
-        else factor = solve_factor(T, K, m, dt);
+        else pre = solve_prepare(T, K, m, dt);
     }
     // ---- run: poll the patch-local predecessors
     auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
             F.blk[s] = fail;
             unresolved = false;
         } else if (!open) {
-            const SolveOut o = solve_apply(T, factor, a, b, c, launchTag);
+            const SolveOut o = solve_apply(T, pre, a, b, c, launchTag);
             vs[2 * t] = pack(o.self); vs[2 * t + 1] = pack(o.dep);
             F.out[s] = o;
             unresolved = false; ran = 1;

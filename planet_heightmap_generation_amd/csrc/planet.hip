@@ -754,6 +754,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         if (hNow) {
             if (gNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
+            F.solveK = K; F.solveM = m; F.solveDt = dt;
             clk.begin("receivers");
             launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();

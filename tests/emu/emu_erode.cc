@@ -220,6 +220,7 @@ extern "C" int emu_erode_composite(int32_t N, const int32_t* off, const int32_t*
                 if (ocean[c]) { F.flow[c] = 0; continue; }
                 flow_final_cell(F, c);                      // flow + the event list of c (k_flow_final)
             }
+            F.solveK = K; F.solveM = m; F.solveDt = dt;          // folded into the task records by solve_setup
             for (int32_t r = 0; r < N; ++r) solve_setup_cell(F, r);
             int64_t n3 = usePatches ? run_solve_patches_emu(E, F.L, K, m, dt) : run_solve_rounds_pred(E, level, K, m, dt);
             if (n3 < 0) rc = 12;
