@@ -515,11 +515,12 @@ def test_config3_checksum_of_the_benched_field(TP):
     pl.close()
 
 
-@pytest.mark.parametrize("world,cells,iters", [(3, 200000, (8, 8, 3)), (2, 1000000, (6, 6, 2))])
-def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells, iters):
+@pytest.mark.parametrize("world,cells,iters,engine", [(3, 200000, (8, 8, 3), "planet"), (2, 1000000, (6, 6, 2), "planet"), (3, 200000, (8, 8, 3), "planet-device")])
+def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells, iters, engine):
     """One planet eroded by `world` ranks (processes sharing this box's GPU, gloo for the merge): every rank runs the HIP
     stack with the other ranks' landmasses masked as ocean, the land elevations are merged through the C ABI's pack /
-    unpack kernels.  Partitioned == unpartitioned, bit for bit, on every rank."""
+    unpack kernels.  Partitioned == unpartitioned, bit for bit, on every rank.  Engine "planet-device": the exchange takes the
+    device-tensor branch of a RCCL run (pack / unpack through device pointers), with the collective stood in for by gloo."""
     import os
     import subprocess
     import sys
@@ -539,7 +540,7 @@ def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells
     pl.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                    "--master-port", str(29700 + world), str(REPO / "tests" / "decomposed_worker.py"), str(tmp_path), "planet"],
+                    "--master-port", str(29700 + world), str(REPO / "tests" / "decomposed_worker.py"), str(tmp_path), engine],
                    check=True, env=env, timeout=1200)
     for r in range(world):
         out = np.load(tmp_path / f"result_{r}.npy")
