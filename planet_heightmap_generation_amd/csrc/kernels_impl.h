@@ -436,7 +436,10 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
 // ---------------------------------------------------------------------------------------------------------
 constexpr int WO_PATCH_THREADS = WO_PATCH;                 // one task per thread
 constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;               // settle loop bound (never reached: every chain ends at a settled task)
-constexpr int WO_PATCH_SPIN_CAP = 16;                      // default spinCap
+constexpr int WO_PATCH_SPIN_CAP = 12;                      // default spinCap (sweep with the log-depth settle: 8 / 12 / 16 / 20 / 24 -> 307 / 298 / 303 / 312 / 321 ms)
+#ifndef WO_SETTLE_JUMP
+#define WO_SETTLE_JUMP 1
+#endif
 #ifndef WO_PATCH_SLEEP
 #define WO_PATCH_SLEEP 1
 #endif
@@ -447,6 +450,9 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
     __shared__ Granule s_out[2 * WO_PATCH];
     __shared__ int32_t s_st[WO_PATCH];                      // 0 unsettled, 1 certainly blocked, 2 candidate or done
     __shared__ int32_t s_cand[WO_PATCH];
+#if WO_SETTLE_JUMP
+    __shared__ int32_t s_wait[WO_PATCH];                    // settle: the local task whose state this one is waiting for
+#endif
     __shared__ int32_t s_ncand, s_pend, s_done, s_fin;
     const int p = blockIdx.x, tid = threadIdx.x;
     if (patchPending[p] == 0) return;                       // block-uniform
@@ -473,14 +479,30 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
             else { double unused; st = ext_ready(b, unused) ? 2 : 1; }
         }
         s_st[tid] = st;
+#if WO_SETTLE_JUMP
+        s_wait[tid] = waitOn;
+#endif
         s_out[2 * tid] = mine.self; s_out[2 * tid + 1] = mine.dep;
         __syncthreads();
         volatile int32_t* vst = s_st;
+#if WO_SETTLE_JUMP
+        // a task's state is the state of the head of its chain of remembered blockers; a task that finds its blocker unsettled
+        // takes over the blocker's own blocker (any ancestor will do), so a chain of d tasks settles in ~log2 d polls, not d
+        volatile int32_t* vw = s_wait;
+        for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
+            if (st == 0) {
+                const int32_t w = vst[waitOn];
+                if (w != 0) { st = w; vst[tid] = w; }
+                else { const int32_t up = vw[waitOn]; if (up >= 0) { waitOn = up; vw[tid] = up; } }
+            }
+        }
+#else
         for (int spin = 0; spin < WO_PATCH_SPIN_LIMIT && __any(st == 0); ++spin) {
             if (st == 0) { const int32_t w = vst[waitOn]; if (w != 0) { st = w; vst[tid] = w; } }
         }
+#endif
         if (pending) {
-            if (st == 2) s_cand[atomicAdd(&s_ncand, 1)] = tid;
+            if (st == 2) s_cand[atomicAdd(&s_ncand, 1)] = tid;      // (one atomic per wave through a ballot: measured 1.5 % slower)
             else { s_out[2 * tid].tag = -1; s_out[2 * tid + 1].tag = -1; }
         }
         const unsigned long long pm = __ballot(pending);
