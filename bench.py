@@ -60,7 +60,7 @@ ALGO_BYTES = {
 }
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel, collected on the 10M-cell workload (separate passes, committed under
 # profiles/); used to fill roofline.traffic for the dominant kernel when bench.py runs that workload.
-PMC_FILE = REPO / "profiles" / "r02zz_pmc_fetch_write_per_kernel_10m.json"
+PMC_FILE = REPO / "profiles" / "r02w_pmc_fetch_write_per_kernel_10m.json"
 FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": "wo::k_solve_setup",
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers",
                  "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "carve_round": "wo::k_carve_round",
