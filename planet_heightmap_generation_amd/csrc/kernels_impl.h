@@ -437,6 +437,10 @@ __global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const 
 constexpr int WO_PATCH_THREADS = WO_PATCH;                 // one task per thread
 constexpr int WO_PATCH_SPIN_LIMIT = 1 << 16;               // settle loop bound (never reached: every chain ends at a settled task)
 constexpr int WO_PATCH_SPIN_CAP = 12;                      // default spinCap (sweep with the log-depth settle: 8 / 12 / 16 / 20 / 24 -> 307 / 298 / 303 / 312 / 321 ms)
+#ifndef WO_PATCH_LATE_FROM
+#define WO_PATCH_LATE_FROM (1 << 30)      // launch of a pass from which the polling cap is WO_PATCH_LATE_SPIN_CAP
+#define WO_PATCH_LATE_SPIN_CAP 12
+#endif
 #ifndef WO_SETTLE_JUMP
 #define WO_SETTLE_JUMP 1
 #endif

@@ -251,6 +251,9 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
     // WO_SOLVE_SPINS: polling passes per visit (kernels_impl.h).  WO_SOLVE_STATS=<n>: per-launch counters of the n-th solve
     // pass of the planet -> stderr (diagnostic).
     static const int spinCap = getenv("WO_SOLVE_SPINS") ? std::max(1, atoi(getenv("WO_SOLVE_SPINS"))) : WO_PATCH_SPIN_CAP;
+    // launches from lateFrom on (few patches still open: no queue of visits behind a long one) may poll longer
+    static const int lateFrom = getenv("WO_SOLVE_LATE_FROM") ? atoi(getenv("WO_SOLVE_LATE_FROM")) : WO_PATCH_LATE_FROM;
+    static const int lateCap = getenv("WO_SOLVE_LATE_SPINS") ? std::max(1, atoi(getenv("WO_SOLVE_LATE_SPINS"))) : WO_PATCH_LATE_SPIN_CAP;
     static const int statsIter = getenv("WO_SOLVE_STATS") ? atoi(getenv("WO_SOLVE_STATS")) : -1;
     constexpr int DBG_W = 8, DBG_N = 512;
     int32_t* dbg = nullptr;
@@ -265,7 +268,7 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         for (int b = 0; b < burst; ++b, ++tag) {
             if (tag % WO_PATCH_TOTAL_SLOTS == 0) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: slots are free again (stream order)
             launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
-                   dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)spinCap);
+                   dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)(tag >= lateFrom ? lateCap : spinCap));
             ++launches;
         }
         static_assert(WO_PATCH_TOTAL_SLOTS <= WO_MAX_LEVEL + 2, "h_levelStart doubles as the read-back buffer of the pending totals");
