@@ -279,7 +279,7 @@ class VirtualShares:
                          "(what this one GPU did), the projection is unpartitioned / slowest share")
 
 
-def ensemble_in_flight(TP, mesh, xyz, nd, seed, params, B: int, device: int):
+def ensemble_in_flight(TP, mesh, xyz, nd, seed, params, B: int, device: int, expect_crc=None):
     """Supplementary figure, NOT `value`: B independent planets in flight on one GPU (one host thread, context and
     stream per planet; BASELINE config 5 runs 8 planets per GPU).  The dependency-bound kernels of one planet leave
     most of the chip idle and its host flood leaves the GPU idle, so planets overlap; `value` above stays the
@@ -304,11 +304,15 @@ def ensemble_in_flight(TP, mesh, xyz, nd, seed, params, B: int, device: int):
     for t in th:
         t.join()
     wall = time.perf_counter() - t0
+    import zlib
+    crcs = sorted({int(zlib.crc32(q.download().tobytes())) for q in planets})      # same seed: every planet must end on the same field
     for q in planets:
         q.close()
     iters = max(params["hIters"], params["tIters"], params["gIters"])
     return dict(planets_in_flight=B, value=mesh.numRegions * iters * B / wall / 1e6, unit="Mcells·iter/s", wall_ms=wall * 1e3,
-                ms_per_planet=wall * 1e3 / B, note="throughput of B concurrent independent planets on this GPU; not the headline value")
+                ms_per_planet=wall * 1e3 / B, crc32_of_the_fields=crcs,
+                fields_equal_the_headline_field=(crcs == [expect_crc]) if expect_crc is not None else None,
+                note="throughput of B concurrent independent planets on this GPU; not the headline value")
 
 
 def cpu_baseline(mesh, xyz, nd, seed, budget_iters: int, iters: int):
@@ -511,7 +515,7 @@ def main():
                                          frac=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9 / HBM_PEAK_GBS))
     ensemble = None
     if rank == 0 and world == 1 and args.in_flight > 1 and not virt:
-        ensemble = ensemble_in_flight(TP, mesh, xyz, nd, seed, params, args.in_flight, local_rank)
+        ensemble = ensemble_in_flight(TP, mesh, xyz, nd, seed, params, args.in_flight, local_rank, expect_crc=crc["crc32"] if crc else None)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and not virt:
