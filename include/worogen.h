@@ -160,7 +160,11 @@ int wo_wind_convergence(wo_planet* planet, const float* r_wind3dX, const float* 
 /* advectMoisture(mesh, r_xyz, r_heightKm, r_isLand, r_windE, r_windN, r_wind3dX, r_wind3dY, r_wind3dZ, r_oceanWarmth,
  *                r_coastDistLand, maxHops, avgEdgeKm)                                js/precipitation.js:59-195
  * Start moisture per cell, then maxHops upwind-gather sweeps (ping-pong buffers); avgEdgeKm is not read by the
- * reference's body and is not part of this entry point.  r_oceanWarmth may be NULL. */
+ * reference's body and is not part of this entry point.  r_oceanWarmth may be NULL.
+ * Exactness: the depletion base 1 - pow(0.78, 1/maxHops) (js/precipitation.js:113) is evaluated with the host libm's pow,
+ * which agrees with V8's Math.pow bit for bit for maxHops 1..26 — this covers the reference's own clamp of maxHops to
+ * 8..20 (js/precipitation.js:210) — and differs by 1 ulp at maxHops = 27, 98, 169 (checked for 1..200).  Bit-exact results
+ * are guaranteed for the reference's range only. */
 int wo_advect_moisture(wo_planet* planet, const float* r_heightKm, const uint8_t* r_isLand, const float* r_windE, const float* r_windN,
                        const float* r_wind3dX, const float* r_wind3dY, const float* r_wind3dZ, const float* r_oceanWarmth,
                        const int32_t* r_coastDistLand, int32_t maxHops, float* out);

@@ -266,7 +266,12 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         const int32_t first = tag;
         const int burst = (tag == 1) ? std::max<int>(1, (int)std::min<int64_t>(p->lastPatchLaunches, WO_PATCH_TOTAL_SLOTS / 2)) : 3;
         for (int b = 0; b < burst; ++b, ++tag) {
-            if (tag % WO_PATCH_TOTAL_SLOTS == 0) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: slots are free again (stream order)
+            // A burst never spans a wrap of the slot ring: the wrap's memset would clear the slots of the burst's earlier
+            // tags before they are read back (they would read as 0 = "nothing pending").  The wrap starts the next burst.
+            if (tag % WO_PATCH_TOTAL_SLOTS == 0) {
+                if (b > 0) break;
+                WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: every earlier slot has been read back
+            }
             launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
                    dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)(tag >= lateFrom ? lateCap : spinCap));
             ++launches;

@@ -145,9 +145,15 @@ class ResidentLandmass:
         plan, rank = self.plan, self.rank
         sizes = [int(c.size) for c in plan.cells]
         if device is not None:
-            send = torch.zeros(self.n_max, dtype=torch.float32, device=device)
+            # torch.empty, not torch.zeros: a fill kernel queued on torch's stream is not ordered against the pack, which
+            # runs on the planet's own (non-blocking) stream and could be overwritten by a late fill.  The pack is
+            # synchronous on the planet's stream; only the unused tail is zeroed, after it, on torch's stream.
+            send = torch.empty(self.n_max, dtype=torch.float32, device=device)
+            torch.cuda.current_stream(device).synchronize()
             if sizes[rank]:
                 self.planet.pack_halo(device_ptr=send.data_ptr())          # synchronises the planet's stream
+            if sizes[rank] < self.n_max:
+                send[sizes[rank]:].zero_()
             out = torch.empty(plan.world * self.n_max, dtype=torch.float32, device=device)
             dist.all_gather_into_tensor(out, send)
             parts = [out[j * self.n_max: j * self.n_max + sizes[j]] for j in range(plan.world) if j != rank and sizes[j]]
