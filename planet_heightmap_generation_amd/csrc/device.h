@@ -56,7 +56,7 @@ enum Family : int {
     FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
     FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
     FAM_LEVEL_SORT, FAM_SOLVE_TAIL, FAM_SOLVE_PATCH, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_PLATE_GRID, FAM_PLATE_PROJECT, FAM_SMOOTH_FIELD,
-    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_CLIMATE, FAM_RIVER, FAM_MISC, FAM_COUNT
+    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_CLIMATE, FAM_RIVER, FAM_BASIN, FAM_BASIN_SORT, FAM_SOLVE_BASIN, FAM_MISC, FAM_COUNT
 };
 extern const char* const kFamilyNames[FAM_COUNT];
 
@@ -122,6 +122,7 @@ struct wo_planet {
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
     uint32_t* d_riverA[2] = {nullptr, nullptr}; int32_t* d_riverJ[2] = {nullptr, nullptr}; int32_t* d_riverIdx = nullptr;   // river.hip
     uint32_t *d_riverRootSize = nullptr, *d_riverRootBase = nullptr; int32_t* d_riverFlag = nullptr; int64_t riverRefreshes = 0;
+    int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr;   // basin.hip: component roots (Morton slot space), group-major store order of the pass
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
     int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
     void* d_sortTemp = nullptr; size_t sortTempBytes = 0;
@@ -197,5 +198,9 @@ void sort_by_level(wo_planet* p);
 // river.hip: patch list of the solve ordered along the drainage forest (d_patchOrder / d_slotOf)
 void river_patch_slots(wo_planet* p);
 void river_free(wo_planet* p);
+// basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it
+void basin_layout(wo_planet* p);
+void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending);
+void basin_free(wo_planet* p);
 
 }  // namespace wo

@@ -26,7 +26,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort(hipcub)", "solve_basin", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -240,10 +240,12 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
 }
 
 // Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
-static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt) {
+// basin: the store order is the group-major one of basin_layout() and the first launch of the pass is k_solve_basin, which
+// normally leaves nothing pending; whatever it does leave (layout off: see basin.hip) is finished by k_solve_patch launches.
+static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin) {
     hipStream_t s = p->ctx->stream;
     const int np = p->numPatches;
-    launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, 1, (int32_t)np);
+    launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, basin ? 0 : 1, (int32_t)np);
     // one pending-total slot per launch, cleared once per pass (a memset per launch was 13.6 k fill kernels per step)
     int32_t* tot = p->d_patchTotals;
     WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
@@ -272,6 +274,8 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
                 if (b > 0) break;
                 WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: every earlier slot has been read back
             }
+            if (basin && tag == 1) basin_solve_launch(p, F, tag, tot + 1);
+            else
             launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
                    dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)(tag >= lateFrom ? lateCap : spinCap));
             ++launches;
@@ -290,7 +294,7 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         fprintf(stderr, "solve stats: %d patches of %d, %d tasks, %lld launches, spin cap %d\nlaunch idle_visits running_visits runnable completed max_passes\n", np, WO_PATCH, p->L, (long long)launches, spinCap);
         for (int t = 1; t <= std::min<int64_t>(launches, DBG_N - 1); ++t) { const int32_t* q = &h[DBG_W * t]; fprintf(stderr, "%d %d %d %d %d %d\n", t, q[0], q[1], q[2], q[3], q[4]); }
     }
-    p->lastPatchLaunches = need + 1;
+    p->lastPatchLaunches = basin ? need : need + 1;      // basin: the first burst is exactly what the last pass needed (one launch)
     return need;
 }
 
@@ -673,6 +677,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     // and a list that is one pass old already needs 28 launches (profiles/r02c_river_patch_experiment.txt).
     static const int riverEvery = getenv("WO_RIVER_PATCHES") ? atoi(getenv("WO_RIVER_PATCHES")) : 0;
     int sinceRiver = -1;
+    // WO_BASIN=0: the Morton patches of round 2 (k_solve_patch from the first launch on) instead of the basin-local solve
+    static const bool basinSolve = !(getenv("WO_BASIN") && atoi(getenv("WO_BASIN")) == 0);
+    int64_t basinPasses = 0, basinLeftoverPasses = 0;
     int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
     for (int32_t iter = 0; iter < total; ++iter) {
@@ -819,9 +826,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 sinceRiver = 0; ++p->riverRefreshes;
             }
             ++sinceRiver;
+            // basin-local solve (basin.hip): this pass's store order groups every drainage component with everything it depends on
+            const bool basin = basinSolve && p->patchVersion >= 0 && riverEvery <= 0;
+            if (basin) { basin_layout(p); F.slotOf = p->d_basinSlot; }
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
-                const int64_t r = run_solve_patches(p, F, K, m, dt);
+                const int64_t r = run_solve_patches(p, F, K, m, dt, basin);
+                if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
                 if (getenv("WO_SOLVE_TRACE")) fprintf(stderr, "iter %d: %lld patch launches\n", iter, (long long)r);
             } else {
@@ -861,6 +872,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     p->erodeStats = {{"land_cells", (double)L}, {"mirror_layout", mirrored ? 1.0 : 0.0}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
+                     {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
                      {"carve_rounds_total", (double)carveRounds}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
@@ -1056,6 +1068,7 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     flood_gpu_free(p->fgpu);
     river_free(p);
+    basin_free(p);
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
