@@ -122,7 +122,7 @@ struct wo_planet {
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
     uint32_t* d_riverA[2] = {nullptr, nullptr}; int32_t* d_riverJ[2] = {nullptr, nullptr}; int32_t* d_riverIdx = nullptr;   // river.hip
     uint32_t *d_riverRootSize = nullptr, *d_riverRootBase = nullptr; int32_t* d_riverFlag = nullptr; int64_t riverRefreshes = 0;
-    int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr;   // basin.hip: component roots (Morton slot space), group-major store order of the pass
+    uint32_t* d_basinKey = nullptr; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; int64_t basinLaunches = 0;   // basin.hip: component roots (Morton slot space), group-major store order of the pass
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
     int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
     void* d_sortTemp = nullptr; size_t sortTempBytes = 0;

@@ -9,7 +9,7 @@ per = defaultdict(list)
 for f in glob.glob(f"{root}/**/*kernel_trace.csv", recursive=True):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     for r in rows:
-        per[r["Kernel_Name"].split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        per[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 out = {}
 for name, v in per.items():
     if len(v) < iters or len(v) > 3 * iters + 16 or name == "wo::k_solve_patch": continue      # once-per-iteration kernels only (a cold step may precede the timed one)
