@@ -83,6 +83,9 @@ struct KeyHeap {
             for (;;) {
                 const size_t l = 2 * i + 1;
                 if (l >= n) break;
+                // the item sinks ~log2(n) levels and below the cached top every level is a miss on the dependency chain: the 16
+                // possible positions four levels down are one contiguous 128-byte stretch, asked for now
+                { const size_t f = 16 * i + 15; if (f < n) { __builtin_prefetch(&h[f]); __builtin_prefetch(&h[f + 8]); __builtin_prefetch(&h[f + 15]); } }
                 const size_t s = l + (h[l + 1].key < h[l].key ? 1 : 0);
                 if (!(h[s].key < kc)) break;
                 h[i] = h[s];
@@ -741,11 +744,121 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Equal keys that DO matter: the replay.  When two tied cells (or their cascades) reach the same cell and the result depends
+// on who is first, only the reference's single heap knows — its choice between equal keys is a function of the array's whole
+// history, every landmass included.  What the separate heaps did establish is everything else: in a landmass without such a
+// cell ("clean") every cell's claimant, surface and key are the single heap's, whatever it does with ties.  So the single
+// heap is run again over the whole planet, but as a bare heap: a clean cell pushes the children it is already known to
+// claim, with their known keys, in adjacency order (a contiguous list, no graph walk, no state), and only the landmasses
+// with an open decision ("dirty") are walked for real inside it.  The heap sees exactly the pushes and pops of the
+// reference's, in the same order, so its array — and with it every choice between equal keys — is the reference's.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+void replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e) {
+    const double EPS = 1e-7;
+    FloodTimer T;
+    const int32_t L = S.L;
+    const int32_t* landCell = S.landCell.data();
+    const int32_t* offL = S.offL.data();
+    const int32_t* adjL = S.adjL.data();
+    float* eL = S.eL.data();
+    FloodCell* st = S.state.data();
+    S.replayDirty.resize(L);
+    uint8_t* dirty = S.replayDirty.data();
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(dirty + b, 0, (size_t)(en - b)); });
+    const int32_t nComp = (int32_t)S.compSize.size();
+    for (int32_t k = 0; k < nComp; ++k) {
+        if (!dirtyComp[k]) continue;
+        const int32_t* cells = S.compCells.data() + S.compCellStart[k];
+        const int32_t n = S.compCellStart[k + 1] - S.compCellStart[k];
+        parallel_ranges(n, [&](int64_t b, int64_t en, int) {
+            for (int64_t q = b; q < en; ++q) {                       // back to the start state of pass 1 (flood_gather)
+                const int32_t i = cells[q];
+                dirty[i] = 1;
+                const float v = e[landCell[i]];
+                eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1;
+            }
+        });
+    }
+    // children of the clean cells, in the order their claimant pushed them (adjacency order), with their keys
+    S.childStart.resize((size_t)L + 1);
+    int32_t* cs = S.childStart.data();
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; ++i) {
+            int32_t c = 0;
+            if (!dirty[i] && st[i].drain != UNVISITED) for (int32_t j = offL[i]; j < offL[i + 1]; ++j) c += st[adjL[j]].drain == (int32_t)i ? 1 : 0;
+            cs[i + 1] = c;
+        }
+    });
+    {   // exclusive scan, in parallel: per-range sums, then offsets
+        const int nt = host_threads();
+        std::vector<int64_t> part(nt + 2, 0);
+        parallel_ranges(L, [&](int64_t b, int64_t en, int t) { int64_t a = 0; for (int64_t i = b; i < en; ++i) a += cs[i + 1]; part[t + 1] = a; });
+        for (int t = 1; t <= nt + 1; ++t) part[t] += part[t - 1];
+        cs[0] = 0;
+        parallel_ranges(L, [&](int64_t b, int64_t en, int t) { int64_t run = part[t]; for (int64_t i = b; i < en; ++i) { run += cs[i + 1]; cs[i + 1] = (int32_t)run; } });
+    }
+    S.childItem.resize((size_t)cs[L] + 1);
+    FloodHeapItem* ci = S.childItem.data();
+    parallel_ranges(L, [&](int64_t b, int64_t en, int) {
+        for (int64_t i = b; i < en; ++i) {
+            if (cs[i + 1] == cs[i]) continue;
+            int32_t o = cs[i];
+            for (int32_t j = offL[i]; j < offL[i + 1]; ++j) {
+                const int32_t nb = adjL[j];
+                if (st[nb].drain == (int32_t)i) ci[o++] = FloodHeapItem{(float)((double)st[nb].surface + cell_noise(landCell[nb])), nb};
+            }
+        }
+    });
+    T.lap("replay prep");
+    if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
+    KeyHeap heap(S.heapStore);
+    for (size_t s = 0; s < S.seedCell.size(); ++s) {        // :118-128, ascending r: every seed of the planet
+        const int32_t i = S.seedCell[s];
+        if (dirty[i]) { st[i].drain = TO_OCEAN; st[i].root = (int32_t)s; }
+        heap.push(i, (float)((double)st[i].e + cell_noise(landCell[i])));    // a seed's surface is its height at the start of the call (state copy: eL of a clean landmass is carved by now)
+    }
+    int64_t realPops = 0;
+    while (heap.n > 0) {
+        const int32_t c = heap.pop();
+        {
+            const FloodHeapItem* hp = S.heapStore.data();
+            const size_t lim2 = heap.n < 7 ? heap.n : 7;
+            for (size_t q = 0; q < lim2; ++q) { const int32_t cc = hp[q].cell; __builtin_prefetch(&cs[cc]); __builtin_prefetch(&dirty[cc]); }
+            if (heap.n > 0) __builtin_prefetch(&ci[cs[hp[0].cell]]);
+        }
+        if (!dirty[c]) {
+            for (int32_t j = cs[c]; j < cs[c + 1]; ++j) heap.push(ci[j].cell, ci[j].key);
+            continue;
+        }
+        ++realPops;
+        const double lim = (double)st[c].surface + EPS;
+        const int32_t rootC = st[c].root;
+        for (int32_t i = offL[c]; i < offL[c + 1]; ++i) {
+            const int32_t nb = adjL[i];
+            FloodCell& sn = st[nb];
+            if (sn.drain != UNVISITED) continue;
+            sn.drain = c;
+            sn.root = rootC;
+            float k;
+            if ((double)sn.e < lim) { sn.surface = (float)lim; k = (float)((double)sn.surface + cell_noise(landCell[nb])); }
+            else k = (float)((double)sn.e + cell_noise(landCell[nb]));
+            heap.push(nb, k);
+        }
+    }
+    T.lap("replay");
+    if (T.on) std::fprintf(stderr, "[flood] replay: %lld cells walked for real of %d\n", (long long)realPops, L);
+}
+}  // namespace
+
 // Pass 1 + passes 2/3, pipelined per landmass.  A landmass's trees, carve paths and fix-ups stay inside it, so its passes
 // 2/3 need only its own pass 1.  Workers take landmasses largest first; after the walk of one they resolve its contested
 // cells, group its cells by tree and run the trees — a big landmass hands its trees out in chunks so that every worker
 // that has run out of landmasses helps.  While the largest landmass (14 % of the land on the bench planet) is still in
-// its walk, the carving of all the others is already done.
+// its walk, the carving of all the others is already done.  Landmasses whose walk met an equal-key decision that matters
+// are left out of the first round, re-walked inside the replay of the single heap (above) and carved in a second round.
+// On return e holds the reference's result; FloodScratch is consumed (the caller gathers again before another call).
 bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo) {
     const double EPS = 1e-7;
     FloodTimer T;
@@ -767,118 +880,147 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         int32_t k = -1; std::vector<int32_t> cnt, chunkStart; bool track = false;
         std::atomic<int> ready{0}; std::atomic<size_t> nextChunk{0}, doneChunks{0};
     };
-    int32_t nBig = 0;
-    while (nBig < nComp && S.compSize[nBig] >= BIG) ++nBig;               // landmasses are in descending size
-    std::vector<BigJob> big(nBig);
-    std::atomic<int32_t> next{0}, bigLeft{nBig};
-    std::atomic<bool> abort{false};
-    struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; };
+    struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; std::vector<int32_t> altComp; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; };
     std::vector<Local> loc(nt);
-    auto run_chunks = [&](BigJob& J, std::vector<int32_t>& path) {
-        const TreeCtx ctx{st, eL, nullptr, carveStrength, J.track ? S.onPath.data() : nullptr};
-        const size_t nChunks = J.chunkStart.size() - 1;
-        const int32_t base = S.compCellStart[J.k];
-        for (;;) {
-            const size_t c = J.nextChunk.fetch_add(1);
-            if (c >= nChunks) break;
-            int64_t a = 0, b = 0;
-            for (int32_t t = J.chunkStart[c]; t < J.chunkStart[c + 1]; ++t)
-                if (J.cnt[t + 1] > J.cnt[t]) tree_pass23(ctx, list2 + base + J.cnt[t], J.cnt[t + 1] - J.cnt[t], path, a, b);
-            if (J.doneChunks.fetch_add(1) + 1 == nChunks) bigLeft.fetch_sub(1);
-        }
-    };
-    auto worker = [&](int w) {
-        Local& me = loc[w];
-        std::vector<int32_t> path, cnt;
-        for (;;) {
-            const int32_t k = next.fetch_add(1);
-            if (k >= nComp || abort.load(std::memory_order_relaxed)) break;
-            // --- pass 1 of landmass k
-            me.contests.clear();
-            walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
-            bool track = false;
-            for (const Contest& ct : me.contests) {
-                ++me.contested;
-                bool open = false;
-                if (ct.other >= 0) {
-                    const FloodCell& x = st[ct.cell];
-                    const float kx = (float)((double)x.surface + cell_noise(S.landCell[ct.cell]));
-                    const double limO = (double)st[ct.other].surface + EPS;
-                    const float altSurface = ((double)x.e < limO) ? (float)limO : x.e;
-                    const bool sameSurface = std::memcmp(&altSurface, &x.surface, 4) == 0;
-                    const bool ordered = x.drain >= 0 && st[x.drain].surface < x.surface && st[ct.other].surface < x.surface;
-                    open = kx > ct.level && sameSurface && ordered;
-                    if (!open && T.on) std::fprintf(stderr, "[flood] unresolved contested cell %d (other %d): %s%s%s level %.9g key %.9g surface %.9g / %.9g e %.9g\n", S.landCell[ct.cell], S.landCell[ct.other],
-                                                    kx > ct.level ? "" : "cascades-inside-the-group ", sameSurface ? "" : "surface-differs ", ordered ? "" : "pass3-order ", (double)ct.level, (double)kx,
-                                                    (double)x.surface, (double)altSurface, (double)x.e);
-                }
-                if (open) { me.alt.push_back({ct.cell, ct.other}); track = true; }
-                else { ++me.unresolved; abort.store(true); }
-            }
-            if (abort.load(std::memory_order_relaxed)) break;
-            // --- its cells grouped by tree (stable: ascending original id inside a tree)
-            const int32_t base = S.compCellStart[k], n = S.compCellStart[k + 1] - base, nTrees = S.compSeedStart[k + 1] - S.compSeedStart[k];
-            const int32_t* cells = S.compCells.data() + base;
-            std::vector<int32_t>& c = (k < nBig) ? big[k].cnt : cnt;
-            c.assign((size_t)nTrees + 1, 0);
-            for (int32_t q = 0; q < n; ++q) ++c[S.seedLocal[st[cells[q]].root] + 1];
-            for (int32_t t = 0; t < nTrees; ++t) c[t + 1] += c[t];
-            {
-                static thread_local std::vector<int32_t> pos;
-                pos.assign(c.begin(), c.end() - 1);
-                for (int32_t q = 0; q < n; ++q) { const int32_t i = cells[q]; list2[base + pos[S.seedLocal[st[i].root]]++] = i; }
-            }
-            if (k < nBig) {                                  // hand the trees out in chunks
-                BigJob& J = big[k];
-                J.k = k; J.track = track;
-                J.chunkStart.clear(); J.chunkStart.push_back(0);
-                for (int32_t t = 0, last = 0; t < nTrees; ++t) if (c[t + 1] - c[last] >= CHUNK) { J.chunkStart.push_back(t + 1); last = t + 1; }
-                if (J.chunkStart.back() != nTrees) J.chunkStart.push_back(nTrees);
-                J.ready.store(1, std::memory_order_release);
-                run_chunks(J, path);
-            } else {
-                const TreeCtx ctx{st, eL, nullptr, carveStrength, track ? S.onPath.data() : nullptr};
+    std::vector<uint8_t> dirty(std::max(nComp, 1), 0);
+    const int forceDirty = [] { const char* v = std::getenv("WO_FLOOD_FORCE_DIRTY"); return v ? std::atoi(v) : -1; }();     // test hook (read per call): treat this landmass (by rank in size) as undecided
+    // One round over a list of landmasses.  walked: pass 1 of these landmasses is already there (the replay's).
+    auto run_round = [&](const std::vector<int32_t>& list, bool walked) {
+        const int32_t nList = (int32_t)list.size();
+        int32_t nBig = 0;
+        while (nBig < nList && S.compSize[list[nBig]] >= BIG) ++nBig;             // lists are in descending size
+        std::vector<BigJob> big(nBig);
+        std::atomic<int32_t> next{0}, bigLeft{nBig};
+        auto run_chunks = [&](BigJob& J, std::vector<int32_t>& path) {
+            const TreeCtx ctx{st, eL, nullptr, carveStrength, J.track ? S.onPath.data() : nullptr};
+            const size_t nChunks = J.chunkStart.size() - 1;
+            const int32_t base = S.compCellStart[J.k];
+            for (;;) {
+                const size_t c = J.nextChunk.fetch_add(1);
+                if (c >= nChunks) break;
                 int64_t a = 0, b = 0;
-                for (int32_t t = 0; t < nTrees; ++t) if (c[t + 1] > c[t]) tree_pass23(ctx, list2 + base + c[t], c[t + 1] - c[t], path, a, b);
+                for (int32_t t = J.chunkStart[c]; t < J.chunkStart[c + 1]; ++t)
+                    if (J.cnt[t + 1] > J.cnt[t]) tree_pass23(ctx, list2 + base + J.cnt[t], J.cnt[t + 1] - J.cnt[t], path, a, b);
+                if (J.doneChunks.fetch_add(1) + 1 == nChunks) bigLeft.fetch_sub(1);
             }
-        }
-        // --- no landmass left to start: help with the big ones until all of them are through
-        while (bigLeft.load() > 0 && !abort.load(std::memory_order_relaxed)) {
-            bool did = false;
-            for (int32_t k = 0; k < nBig; ++k) {
-                BigJob& J = big[k];
-                if (J.ready.load(std::memory_order_acquire) && J.nextChunk.load() < J.chunkStart.size() - 1) { run_chunks(J, path); did = true; }
+        };
+        auto worker = [&](int w) {
+            Local& me = loc[w];
+            std::vector<int32_t> path, cnt;
+            for (;;) {
+                const int32_t q = next.fetch_add(1);
+                if (q >= nList) break;
+                const int32_t k = list[q];
+                bool track = false, undecided = false;
+                if (!walked) {
+                    // --- pass 1 of landmass k
+                    me.contests.clear();
+                    walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
+                    const size_t alt0 = me.alt.size();
+                    for (const Contest& ct : me.contests) {
+                        ++me.contested;
+                        bool open = false;
+                        if (ct.other >= 0) {
+                            const FloodCell& x = st[ct.cell];
+                            const float kx = (float)((double)x.surface + cell_noise(S.landCell[ct.cell]));
+                            const double limO = (double)st[ct.other].surface + EPS;
+                            const float altSurface = ((double)x.e < limO) ? (float)limO : x.e;
+                            const bool sameSurface = std::memcmp(&altSurface, &x.surface, 4) == 0;
+                            const bool ordered = x.drain >= 0 && st[x.drain].surface < x.surface && st[ct.other].surface < x.surface;
+                            open = kx > ct.level && sameSurface && ordered;
+                            if (!open && T.on) std::fprintf(stderr, "[flood] undecided contested cell %d (other %d): %s%s%s level %.9g key %.9g surface %.9g / %.9g e %.9g\n", S.landCell[ct.cell], S.landCell[ct.other],
+                                                            kx > ct.level ? "" : "cascades-inside-the-group ", sameSurface ? "" : "surface-differs ", ordered ? "" : "pass3-order ", (double)ct.level, (double)kx,
+                                                            (double)x.surface, (double)altSurface, (double)x.e);
+                        }
+                        if (open) { me.alt.push_back({ct.cell, ct.other}); me.altComp.push_back(k); track = true; }
+                        else { ++me.unresolved; undecided = true; }
+                    }
+                    if (q == forceDirty) undecided = true;
+                    if (undecided) { me.alt.resize(alt0); me.altComp.resize(alt0); dirty[k] = 1; }
+                }
+                // --- its cells grouped by tree (stable: ascending original id inside a tree); an undecided landmass waits for the replay
+                const bool isBig = q < nBig;
+                const int32_t base = S.compCellStart[k], n = S.compCellStart[k + 1] - base, nTrees = S.compSeedStart[k + 1] - S.compSeedStart[k];
+                std::vector<int32_t>& c = isBig ? big[q].cnt : cnt;
+                if (undecided) {
+                    if (isBig) { BigJob& J = big[q]; J.k = k; J.chunkStart.assign(1, 0); J.ready.store(1, std::memory_order_release); bigLeft.fetch_sub(1); }
+                    continue;
+                }
+                const int32_t* cells = S.compCells.data() + base;
+                c.assign((size_t)nTrees + 1, 0);
+                for (int32_t qq = 0; qq < n; ++qq) ++c[S.seedLocal[st[cells[qq]].root] + 1];
+                for (int32_t t = 0; t < nTrees; ++t) c[t + 1] += c[t];
+                {
+                    static thread_local std::vector<int32_t> pos;
+                    pos.assign(c.begin(), c.end() - 1);
+                    for (int32_t qq = 0; qq < n; ++qq) { const int32_t i = cells[qq]; list2[base + pos[S.seedLocal[st[i].root]]++] = i; }
+                }
+                if (isBig) {                                  // hand the trees out in chunks
+                    BigJob& J = big[q];
+                    J.k = k; J.track = track;
+                    J.chunkStart.clear(); J.chunkStart.push_back(0);
+                    for (int32_t t = 0, last = 0; t < nTrees; ++t) if (c[t + 1] - c[last] >= CHUNK) { J.chunkStart.push_back(t + 1); last = t + 1; }
+                    if (J.chunkStart.back() != nTrees) J.chunkStart.push_back(nTrees);
+                    J.ready.store(1, std::memory_order_release);
+                    run_chunks(J, path);
+                } else {
+                    const TreeCtx ctx{st, eL, nullptr, carveStrength, track ? S.onPath.data() : nullptr};
+                    int64_t a = 0, b = 0;
+                    for (int32_t t = 0; t < nTrees; ++t) if (c[t + 1] > c[t]) tree_pass23(ctx, list2 + base + c[t], c[t + 1] - c[t], path, a, b);
+                }
             }
-            if (!did) std::this_thread::sleep_for(std::chrono::microseconds(25));      // not a busy wait: the walk of the largest landmass is the critical path and may share a core
+            // --- no landmass left to start: help with the big ones until all of them are through
+            while (bigLeft.load() > 0) {
+                bool did = false;
+                for (int32_t q = 0; q < nBig; ++q) {
+                    BigJob& J = big[q];
+                    if (J.ready.load(std::memory_order_acquire) && J.nextChunk.load() < J.chunkStart.size() - 1) { run_chunks(J, path); did = true; }
+                }
+                if (!did) std::this_thread::sleep_for(std::chrono::microseconds(25));      // not a busy wait: the walk of the largest landmass is the critical path and may share a core
+            }
+        };
+        const int use = std::min(nt, std::max(1, nList));
+        if (use == 1 && nBig == 0) worker(0);
+        else {
+            const int th_n = nBig > 0 ? nt : use;                  // chunks of a big landmass are worth every worker
+            std::vector<std::thread> th;
+            for (int w = 0; w < th_n; ++w) th.emplace_back(worker, w);
+            for (auto& t : th) t.join();
         }
     };
-    if (nt == 1) worker(0);
-    else {
-        std::vector<std::thread> th;
-        for (int w = 0; w < nt; ++w) th.emplace_back(worker, w);
-        for (auto& t : th) t.join();
-    }
-    for (const Local& l : loc) { rep.groups += l.groups; rep.nested += l.nested; rep.contested += l.contested; rep.unresolved += l.unresolved; rep.openParents += (int64_t)l.alt.size(); }
+    std::vector<int32_t> all(nComp);
+    for (int32_t k = 0; k < nComp; ++k) all[k] = k;
+    run_round(all, false);
     T.lap("pipeline");
-    if (T.on) std::fprintf(stderr, "[flood] landmasses %d (%d big), workers %d, tie groups %lld (nested %lld), contested %lld, open parents %lld, unresolved %lld\n",
-                           rep.landmasses, nBig, rep.workers, (long long)rep.groups, (long long)rep.nested, (long long)rep.contested, (long long)rep.openParents, (long long)rep.unresolved);
-    if (abort.load()) return false;
-    // open parents (see flood_pass23_host): the elevations must not depend on the choice
+    // open parents (see flood_pass23_host): the elevations must not depend on the choice; a landmass where they do is undecided after all
     for (const Local& l : loc)
-        for (const auto& oa : l.alt) {
-            const int32_t x = oa.first, p0 = st[x].drain, p1 = oa.second;
+        for (size_t a = 0; a < l.alt.size(); ++a) {
+            const int32_t x = l.alt[a].first, p0 = st[x].drain, p1 = l.alt[a].second;
             const bool untouched = !S.onPath[x] && std::memcmp(&eL[x], &st[x].e, 4) == 0;
             const double h = (double)st[x].e;
-            if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) { ++pathRedo; return false; }
+            if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) { if (!dirty[l.altComp[a]]) { dirty[l.altComp[a]] = 1; ++pathRedo; } }
         }
+    for (const Local& l : loc) { rep.groups += l.groups; rep.nested += l.nested; rep.contested += l.contested; rep.unresolved += l.unresolved; rep.openParents += (int64_t)l.alt.size(); }
+    std::vector<int32_t> redo;
+    for (int32_t k = 0; k < nComp; ++k) if (dirty[k]) redo.push_back(k);
+    rep.replayed = (int32_t)redo.size();
+    if (T.on) std::fprintf(stderr, "[flood] landmasses %d, workers %d, tie groups %lld (nested %lld), contested %lld, open parents %lld, undecided %lld -> %d landmasses through the replay\n",
+                           rep.landmasses, rep.workers, (long long)rep.groups, (long long)rep.nested, (long long)rep.contested, (long long)rep.openParents, (long long)rep.unresolved, rep.replayed);
+    if (!redo.empty()) {
+        replay_dirty_landmasses(S, dirty, e);
+        run_round(redo, true);
+        T.lap("round 2");
+    }
     const int32_t* landCell = S.landCell.data();
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
 }
 
-// gather + pass 1 + passes 2/3 on the host.  Pass 1 runs one heap per landmass on the tree workers; when that cannot
-// vouch for the single heap's result (FloodTieReport) the serial walk redoes it.  WO_FLOOD_HOST=serial skips the attempt.
+// gather + pass 1 + passes 2/3 on the host.  Pass 1 runs one heap per landmass on the tree workers; landmasses where that
+// cannot vouch for the single heap's result (FloodTieReport) are decided by the replay of the single heap
+// (replay_dirty_landmasses).  WO_FLOOD_HOST=serial: the plain serial walk; =two-phase: all walks, then all trees, serial
+// walk when undecided (round 2's form, kept for comparison).
 void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHostStats* stats) {
     static const bool serialOnly = [] { const char* v = std::getenv("WO_FLOOD_HOST"); return v && std::string(v) == "serial"; }();
     using clock = std::chrono::steady_clock;
@@ -904,6 +1046,7 @@ void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHos
         } else {
             done = flood_landmass_pipeline(e, carveStrength, S, rep, st.pathRedo);
             st.pass1Ms += ms(t0, clock::now());             // pass 1 and passes 2/3 overlap: one figure
+            if (rep.replayed) { ++st.replays; st.replayedLandmasses += rep.replayed; }
         }
         st.tieGroups += rep.groups; st.contested += rep.contested; st.openParents += rep.openParents; st.unresolved += rep.unresolved;
         if (!done) flood_gather(e, S);

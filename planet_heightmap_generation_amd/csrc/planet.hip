@@ -881,7 +881,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"flood_host_calls", (double)floodRun.host.calls}, {"flood_host_serial_pass1", (double)floodRun.host.serialPass1},
                      {"flood_host_tie_groups", (double)floodRun.host.tieGroups}, {"flood_host_contested", (double)floodRun.host.contested},
                      {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
-                     {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
+                     {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_replays", (double)floodRun.host.replays}, {"flood_host_replayed_landmasses", (double)floodRun.host.replayedLandmasses}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
                      {"flood_host_pass23_ms", floodRun.host.pass23Ms}};
 }
 

@@ -37,13 +37,17 @@ struct FloodScratch {
     hvec<int32_t> stamp;                     // tie-family id of the claim that reached a cell (0 = outside any tie group)
     hvec<uint8_t> onPath;                    // pass 2: the cell lay on a carve path (only tracked when pass 1 left open parents)
     std::vector<hvec<FloodHeapItem>> workerHeaps;
+    // replay of the single heap (flood_host.cc: replay_dirty_landmasses)
+    hvec<uint8_t> replayDirty;               // the cell belongs to a landmass that is walked again inside the replay
+    hvec<int32_t> childStart;                // per clean cell: its claimed children in childItem, in the order it pushed them
+    hvec<FloodHeapItem> childItem;
 };
 // What the landmass-parallel pass 1 reports.  A cell is "contested" when two cells with EQUAL keys that sat in the heap
 // together (and their sub-key cascades) both reached it: which one claims it is decided by the array history of the
 // reference's single heap, which separate heaps cannot know.
 struct FloodTieReport {
     int64_t groups = 0, nested = 0, contested = 0, openParents = 0, unresolved = 0;
-    int32_t landmasses = 0, workers = 0;
+    int32_t landmasses = 0, workers = 0, replayed = 0;   // replayed: landmasses decided by the replay of the single heap
     std::vector<std::pair<int32_t, int32_t>> alt;      // (cell, alternative parent) where only drainTo is undecided
 };
 // (re)builds the mask-dependent tables (Morton-ordered land list `landCell`, compact CSR, seeds)
@@ -61,11 +65,13 @@ void flood_pass1_host(FloodScratch& S);                               // serial 
 // detected (FloodTieReport).  Returns false when one of them changes surfaces/keys: the caller redoes pass 1 serially.
 bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep);
 // The same per landmass, with passes 2/3 of a landmass starting as soon as its own pass 1 is over (the largest landmass
-// bounds pass 1; the others' carving runs beside it).  Returns false — nothing written to e — when an equal-key decision
-// could matter (caller: serial walk).
+// bounds pass 1; the others' carving runs beside it).  Landmasses where an equal-key decision matters are walked again
+// inside a replay of the reference's single heap (bare heap operations for everything else) and carved afterwards, so the
+// call always ends with the reference's result in e.  FloodScratch's per-call arrays are consumed: flood_gather() before
+// the next use.
 bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo);
 // pass 1 (landmass-parallel when exact, else the serial walk) + passes 2/3; stats: see flood_host.cc
-struct FloodHostStats { int64_t calls = 0, serialPass1 = 0, tieGroups = 0, contested = 0, openParents = 0, unresolved = 0, pathRedo = 0; double pass1Ms = 0, pass23Ms = 0; };
+struct FloodHostStats { int64_t calls = 0, serialPass1 = 0, tieGroups = 0, contested = 0, openParents = 0, unresolved = 0, pathRedo = 0, replays = 0, replayedLandmasses = 0; double pass1Ms = 0, pass23Ms = 0; };
 void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHostStats* stats);
 void flood_import_pass1(const int32_t* par, const float* surface, const int32_t* root, FloodScratch& S);
 // openAlt: cells whose parent pass 1 could not decide between equal keys (same surface either way); returns false when

@@ -282,7 +282,7 @@ extern "C" void emu_warp(int32_t N, const int32_t* off, const int32_t* adj, floa
 
 // priorityFloodCarve through the host stage's two pass-1 routes.  mode 0: the serial heap walk; mode 1: one heap per
 // landmass with the tie-group checks (falls back to the serial walk when it cannot vouch for the result).
-// stats: [calls, serialPass1, tieGroups, contested, openParents, unresolved, pathRedo, pass1Ms, pass23Ms]
+// stats: [calls, serialPass1, tieGroups, contested, openParents, unresolved, pathRedo, pass1Ms, pass23Ms] (mode + 10: two more slots, [replays, replayedLandmasses])
 extern "C" void emu_flood_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, const uint8_t* ocean, double cs,
                                int32_t mode, int32_t repeats, double* stats) {
     FloodScratch S;
@@ -292,13 +292,14 @@ extern "C" void emu_flood_host(int32_t N, const int32_t* off, const int32_t* adj
     std::vector<float> e0(e, e + N);
     for (int32_t k = 0; k < (repeats < 1 ? 1 : repeats); ++k) {
         std::memcpy(e, e0.data(), sizeof(float) * (size_t)N);
-        if (mode == 0) { ++hs.calls; ++hs.serialPass1; flood_gather(e, S); flood_pass1_host(S); flood_pass23_host(e, cs, S); }
+        if (mode % 10 == 0) { ++hs.calls; ++hs.serialPass1; flood_gather(e, S); flood_pass1_host(S); flood_pass23_host(e, cs, S); }
         else flood_host_passes(e, cs, S, &hs);
     }
     if (stats) {
-        const double v[9] = {(double)hs.calls, (double)hs.serialPass1, (double)hs.tieGroups, (double)hs.contested, (double)hs.openParents,
-                             (double)hs.unresolved, (double)hs.pathRedo, hs.pass1Ms, hs.pass23Ms};
-        for (int i = 0; i < 9; ++i) stats[i] = v[i];
+        // (the first nine are what older callers size their buffer for; WO_EMU_FLOOD_STATS11 callers pass eleven slots)
+        const double v[11] = {(double)hs.calls, (double)hs.serialPass1, (double)hs.tieGroups, (double)hs.contested, (double)hs.openParents,
+                              (double)hs.unresolved, (double)hs.pathRedo, hs.pass1Ms, hs.pass23Ms, (double)hs.replays, (double)hs.replayedLandmasses};
+        for (int i = 0; i < (mode >= 10 ? 11 : 9); ++i) stats[i] = v[i];
     }
 }
 

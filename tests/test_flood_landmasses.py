@@ -16,7 +16,7 @@ from conftest import POST_TAGS, REPO, golden_cases, load_golden
 
 EMU_DIR = REPO / "tests" / "emu"
 
-STAT_NAMES = "calls serialPass1 tieGroups contested openParents unresolved pathRedo pass1Ms pass23Ms".split()
+STAT_NAMES = "calls serialPass1 tieGroups contested openParents unresolved pathRedo pass1Ms pass23Ms replays replayedLandmasses".split()
 
 
 @pytest.fixture(scope="module")
@@ -34,8 +34,8 @@ def P(a):
 
 def flood(emu, mesh_off, mesh_adj, xyz, e0, oc, cs, mode):
     e = e0.copy()
-    st = np.zeros(9)
-    emu.emu_flood_host(mesh_off.size - 1, P(mesh_off), P(mesh_adj), P(xyz), P(e), P(oc), cs, mode, 1, P(st))
+    st = np.zeros(11)
+    emu.emu_flood_host(mesh_off.size - 1, P(mesh_off), P(mesh_adj), P(xyz), P(e), P(oc), cs, mode + 10, 1, P(st))      # + 10: all eleven statistics
     return e, dict(zip(STAT_NAMES, st.tolist()))
 
 
@@ -83,7 +83,28 @@ def test_landmass_flood_under_key_collisions(emu, oracle, quant):
     ref = oracle.priority_flood_carve(om, eq, oc, 0.5)
     e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, eq, oc, 0.5, 1)
     assert np.array_equal(e, ref), (quant, int((e != ref).sum()), st)
+    assert st["serialPass1"] == 0, st              # undecided landmasses go through the replay of the single heap, never the serial walk
     print(quant, st)
+
+
+@pytest.mark.parametrize("cells,seed", [(60000, 4), (200000, 1)])
+def test_replay_of_the_single_heap(emu, oracle, monkeypatch, cells, seed):
+    """The decision procedure for equal keys that matter (flood_host.cc: replay_dirty_landmasses): the landmass given by
+    WO_FLOOD_FORCE_DIRTY is treated as undecided, i.e. walked again inside a replay of the reference's single heap in which
+    every other landmass only repeats its known pushes.  Whichever landmass is redone that way — the largest, a middle one,
+    a tiny one — the elevations are the oracle's, and nothing falls back to the serial walk."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(cells, 0.75, seed)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    e0 = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, seed), xyz, seed, 0.75)
+    oc = (e0 <= 0).astype(np.uint8)
+    ref = oracle.priority_flood_carve(om, e0, oc, 0.5)
+    for k in (0, 1, 5, 40):
+        monkeypatch.setenv("WO_FLOOD_FORCE_DIRTY", str(k))
+        e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, 0.5, 1)
+        assert np.array_equal(e, ref), (k, int((e != ref).sum()), st)
+        assert st["serialPass1"] == 0 and st["replays"] == 1 and st["replayedLandmasses"] >= 1, (k, st)
+    monkeypatch.delenv("WO_FLOOD_FORCE_DIRTY")
 
 
 def test_landmass_flood_constructed_equal_keys(emu, oracle):
@@ -101,7 +122,7 @@ def test_landmass_flood_constructed_equal_keys(emu, oracle):
     h = np.mod(x * 73244475.0, 4294967296.0).astype(np.int64).astype(np.uint32)
     h = (h >> np.uint32(16)) ^ h
     noise = h.astype(np.float64) / 4294967295.0 * 0.01
-    total = 0
+    total = replays = 0
     for level in (0.05, 0.3):
         e0 = np.where(base > 0, np.float32(level) - noise.astype(np.float32), np.float32(-0.1)).astype(np.float32)
         e0 = np.where((base > 0) & (e0 <= 0), np.float32(1e-3), e0).astype(np.float32)
@@ -109,8 +130,11 @@ def test_landmass_flood_constructed_equal_keys(emu, oracle):
         ref = oracle.priority_flood_carve(om, e0, oc, 0.5)
         e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, 0.5, 1)
         assert np.array_equal(e, ref), (level, int((e != ref).sum()), st)
+        assert st["serialPass1"] == 0, st
         total += st["tieGroups"]
-    assert total > 0
+        replays += st["replays"]
+        print(level, st)
+    assert total > 0 and replays > 0          # thousands of contested cells: decided by the replay of the single heap
 
 
 def _cell_noise(r):

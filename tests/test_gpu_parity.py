@@ -515,6 +515,50 @@ def test_config3_checksum_of_the_benched_field(TP):
     pl.close()
 
 
+def _checksum_case(TP, key, cells, seed, iters, g):
+    """warp 0.75 -> isOcean -> erodeComposite(iters, ..., iters, ..., g, 0.5) -> creep x3 on a fixed-seed sphere, resident on the
+    device; the CRC of the result against the oracle's (tests/golden/crc_config3.json, oracle/ref_harness/make_crc_config3.py)."""
+    import json
+    import zlib
+    from conftest import GOLDEN
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    gold = json.loads((GOLDEN / "crc_config3.json").read_text())[key]
+    assert (gold["cells"], gold["seed"], gold["iterations"], gold["gIters"]) == (cells, seed, iters, g)
+    mesh, xyz, nd = S.build_sphere(cells, 0.75, seed)
+    assert int(zlib.crc32(mesh.adjList.tobytes())) == gold["crc32_mesh"]
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(seed)
+    assert int(zlib.crc32(pl.download().tobytes())) == gold["crc32_input"]
+    pl.warp_terrain_resident(seed, 0.75)
+    pl.ocean_from_elevation()
+    pl.erode_composite_resident(iters, 3e-4, 0.5, 1.0, iters, 1.16, 0.015, g, 0.5)
+    stats = pl.last_erode_stats()
+    pl.apply_soil_creep_resident(3, 0.1125)
+    out = pl.download()
+    pl.close()
+    assert abs(float(out.astype(np.float64).sum()) - gold["sum"]) < 1e-5 * out.size      # RMS-scale guard before the exact check
+    assert int(zlib.crc32(out.tobytes())) == gold["crc32"], "field differs from the oracle's"
+    return stats
+
+
+def test_config4_size_checksum_on_one_gpu(TP):
+    """BASELINE config 4's planet (40 M cells, seed 1) on one GPU, 20 composite iterations (1 glacial): CRC == the oracle's.
+    At this size both flood calls meet equal keys whose order matters (13 contested cells per step in round 2, which sent the
+    call to the serial heap walk): they are decided by the replay of the single heap (flood_host.cc), never the serial walk."""
+    stats = _checksum_case(TP, "40000000", 40_000_000, 1, 20, 1)
+    print({k: v for k, v in stats.items() if k.startswith("flood_host")})
+    assert stats["flood_host_serial_pass1"] == 0
+    assert stats["solve_basin_passes_with_leftovers"] == 0
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_config5_seeds_checksum(TP, seed):
+    """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 and 3, 20 composite iterations (1 glacial),
+    CRC == the oracle's (seed 1 at the full 200 iterations: test_config3_checksum_of_the_benched_field)."""
+    stats = _checksum_case(TP, f"10000000_seed{seed}_iters20", 10_000_000, seed, 20, 1)
+    assert stats["flood_host_serial_pass1"] == 0
+
+
 @pytest.mark.parametrize("world,cells,iters,engine", [(3, 200000, (8, 8, 3), "planet"), (2, 1000000, (6, 6, 2), "planet"), (3, 200000, (8, 8, 3), "planet-device")])
 def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells, iters, engine):
     """One planet eroded by `world` ranks (processes sharing this box's GPU, gloo for the merge): every rank runs the HIP
