@@ -37,34 +37,33 @@ import numpy as np
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
-# SURVEY 8(d) algorithmic bytes per pass, per kernel family (L = land cells, N = numRegions, d = 6).
-# value = (bytes per land cell, bytes per cell); launches_per_pass comes from the measured launch counts.
-ALGO_BYTES = {
-    "sort_radix(hipcub)": (8.0, 0.0),      # key in + rank out
-    "sort_keys": (8.0, 0.0),
-    "rank_scatter": (8.0, 0.0),
-    "receivers": (68.0, 4.0),              # own elev, adjOffset, adjList, nb elev, dist, writes + target fill
-    "flow_init": (8.0, 4.0),
-    "flow_snap": (16.0, 0.0),              # flow family: 16 B/land cell per pass (this family holds k_flow_climb, the one-launch accumulation)
-    "flow_apply": (16.0, 0.0),
-    "flow_final": (16.0, 4.0),
-    "solve_setup": (45.0, 0.0),            # solve family: 45 B/land cell per pass
-    "solve_round": (45.0, 0.0),
-    "solve_tail": (45.0, 0.0),
-    "solve_patch": (45.0, 0.0),
-    "solve_final": (8.0, 4.0),
-    "thermal_excess": (62.0, 4.0),         # thermal: 106 B/land cell + 4 B/cell split over its two passes
-    "thermal_apply": (106.0, 4.0),
-    "soil_creep": (82.0 * 0.8, 4.0),       # 82 B per interior-land cell and iteration
-    "warp_terrain": (0.0, 20.0 + 100.0 * 24),   # ~20 + 100*hops B/cell, ~24 hops at 10M
+# algorithmic bytes of one composite iteration = 243 B x land cells + 12 B x cells, made of five passes.  Every
+# pass's budget is split over the kernels that implement it, so that the per-kernel figures ADD UP to the pass budget (a kernel
+# that only exists because of how the pass is implemented here — the basin layout, its sort — gets 0 bytes: its time still
+# counts in the pass).  (per land cell, per cell) per launch of the pass.
+PASSES = {
+    "sort":      {"budget": (8.0, 0.0),   "kernels": {"sort_keys": (2.0, 0.0), "sort_radix(hipcub)": (4.0, 0.0), "rank_scatter": (2.0, 0.0)}},
+    "receivers": {"budget": (68.0, 4.0),  "kernels": {"receivers": (68.0, 4.0)}},
+    "flow":      {"budget": (16.0, 4.0),  "kernels": {"flow_snap": (8.0, 0.0), "flow_final": (8.0, 4.0), "flow_init": (0.0, 0.0), "flow_apply": (0.0, 0.0)}},
+    "solve":     {"budget": (45.0, 0.0),  "kernels": {"solve_setup": (33.0, 0.0), "solve_basin": (8.0, 0.0), "solve_patch": (8.0, 0.0), "solve_round": (8.0, 0.0),
+                                                       "solve_tail": (0.0, 0.0), "solve_final": (4.0, 0.0), "basin_layout": (0.0, 0.0), "basin_sort(hipcub)": (0.0, 0.0),
+                                                       "level_sort": (0.0, 0.0), "river_order": (0.0, 0.0)}},
+    "thermal":   {"budget": (106.0, 4.0), "kernels": {"thermal_excess": (45.0, 0.0), "thermal_apply": (61.0, 4.0)}},
 }
-# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel, collected on the 10M-cell workload (separate passes, committed under
-# profiles/); used to fill roofline.traffic for the dominant kernel when bench.py runs that workload.
-PMC_FILE = REPO / "profiles" / "r02w_pmc_fetch_write_per_kernel_10m.json"
+assert sum(v["budget"][0] for v in PASSES.values()) == 243.0 and sum(v["budget"][1] for v in PASSES.values()) == 12.0
+for _p in PASSES.values():
+    assert (sum(k[0] for k in _p["kernels"].values() if k) - sum(_p["kernels"][k][0] for k in ("solve_patch", "solve_round") if k in _p["kernels"]),
+            max(k[1] for k in _p["kernels"].values())) == _p["budget"], _p      # (solve_basin / solve_patch / solve_round are alternatives: one of them runs)
+# one-off stages and the glacial iterations: bytes per launch of the whole stage
+ONE_OFF = {"soil_creep": (82.0 * 0.8, 4.0), "warp_terrain": (0.0, 20.0 + 100.0 * 24)}      # creep: 82 B per interior-land cell; warp: ~20 + 100 x hops B/cell, ~24 hops at 10M
+GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend")
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload at the full iteration count (separate passes;
+# profiles/collect_pmc.sh); used for roofline.traffic of the dominant kernel unless WO_BENCH_PMC=1 asks for a live collection.
+PMC_FILE = REPO / "profiles" / "r03_pmc_fetch_write_per_kernel_10m_200iters.json"
 FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": "wo::k_solve_setup",
-                 "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers",
-                 "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "carve_round": "wo::k_carve_round",
-                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final"}
+                 "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
+                 "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_snap": "wo::k_flow_climb", "carve_round": "wo::k_carve_round_pairs",
+                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": "wo::k_solve_stream"}
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5)
@@ -315,35 +314,77 @@ def ensemble_in_flight(TP, mesh, xyz, nd, seed, params, B: int, device: int, exp
                 note="throughput of B concurrent independent planets on this GPU; not the headline value")
 
 
-def cpu_baseline(mesh, xyz, nd, seed, budget_iters: int, iters: int):
-    """CPU oracle (oracle/*.c, single thread) on the same planet and stack, bounded: the one-off stages (warp, one
-    priority flood, creep) are timed on their own and erodeComposite is run for `budget_iters` composite iterations;
-    the per-iteration cost taken from that run (its two floods subtracted) is scaled to the `iters`-iteration workload
-    the GPU figure is quoted on, so the one-off stages are amortised over the same iteration count on both sides.
-    `value` is that extrapolation; the raw sample rate is reported next to it."""
+def cpu_baseline(mesh, xyz, nd, seed, budget_iters: int, iters: int, pl=None):
+    """CPU oracle (oracle/*.c, single thread) on the same planet and stack, bounded (~30 s of CPU work).  The one-off stages
+    (warp, creep) are timed on their own.  The per-iteration cost drifts over a run as the terrain settles (round 2's
+    extrapolation from the first 4 iterations was off by 16 %), so erodeComposite is sampled at two points: 2 iterations from
+    the warped field (with the glacial step) and 2 iterations from the field at 3/4 of the run — where the reference runs its
+    second flood — produced by the HIP path (`pl`), which is bit-identical to the oracle.  A sample call of 2 iterations
+    runs exactly one flood (the mid-run one needs iteration >= round(0.75 x 2) = 2); the flood is timed on the same state on
+    its own and subtracted, and those two flood times are the two floods of the full run.  value = cells x iters / (warp +
+    flood at 0 + flood at 3/4 + the per-iteration cost interpolated between the samples, summed over the iterations, + creep)."""
     from oracle import pyoracle as O
     om = O.Mesh(mesh.adjOffset, mesh.adjList)
     e0 = O.synthetic_terrain(xyz, seed)
     t0 = time.time(); e = O.warp_terrain(om, e0, xyz, seed, WARP); t_warp = time.time() - t0
     oc = (e <= 0).astype(np.uint8)
-    t0 = time.time(); O.priority_flood_carve(om, e, oc, 0.5); t_flood = time.time() - t0
-    g = max(1, min(PARAMS["gIters"], budget_iters // 2))
-    t0 = time.time()
-    e2 = O.erode_composite(om, e, xyz, oc, budget_iters, PARAMS["K"], PARAMS["m"], PARAMS["dt"], budget_iters, PARAMS["talusSlope"],
-                           PARAMS["kThermal"], g, PARAMS["glacialStrength"], nd)
-    t_erode = time.time() - t0
-    t0 = time.time(); O.soil_creep(om, e2, oc, *CREEP); t_creep = time.time() - t0
-    per_iter = max(1e-9, (t_erode - 2 * t_flood) / budget_iters)
-    est = t_warp + 2 * t_flood + per_iter * iters + t_creep
-    total = t_warp + t_flood + t_erode + t_creep
+    P = PARAMS
+    points = [0] + ([int(round(iters * 0.75))] if (pl is not None and iters >= 40) else [])
+    costs, floods, e_last, t_cpu = [], [], e, t_warp
+    for at in points:
+        if at == 0:
+            state = e
+        else:                                   # the HIP path's field after `at` iterations of this stack (bit-identical to the oracle's)
+            pl.restore_state(); pl.warp_terrain_resident(seed, WARP); pl.ocean_from_elevation()
+            pl.erode_composite_resident(at, P["K"], P["m"], P["dt"], at, P["talusSlope"], P["kThermal"], min(P["gIters"], at), P["glacialStrength"])
+            state = pl.download()
+        t0 = time.time(); O.priority_flood_carve(om, state, oc, 0.5 if at == 0 else 0.85); t_flood = time.time() - t0
+        t0 = time.time()
+        e_last = O.erode_composite(om, state, xyz, oc, 2, P["K"], P["m"], P["dt"], 2, P["talusSlope"], P["kThermal"], 2 if at == 0 else 0, P["glacialStrength"], nd)
+        t_call = time.time() - t0
+        floods.append(t_flood); costs.append(max(1e-9, (t_call - t_flood) / 2)); t_cpu += t_flood + t_call
+    t0 = time.time(); O.soil_creep(om, e_last, oc, *CREEP); t_creep = time.time() - t0
+    t_cpu += t_creep
+    per_iter_sum = float(np.interp(np.arange(iters), points, costs).sum()) if len(points) > 1 else costs[0] * iters
+    est = t_warp + floods[0] + floods[-1] + per_iter_sum + t_creep
     return dict(value=mesh.numRegions * iters / est / 1e6, unit="Mcells·iter/s", cores=1, kind="port",
-                raw_sample_value=mesh.numRegions * budget_iters / (t_warp + t_erode + t_creep) / 1e6,
-                seconds=dict(warp=round(t_warp, 2), one_flood=round(t_flood, 2), erode_sample=round(t_erode, 2), creep=round(t_creep, 2),
-                             per_iteration=round(per_iter, 3), estimated_full_workload=round(est, 1)),
-                sample=f"same {mesh.numRegions}-cell planet and stack on one host core, {total:.1f} s of CPU work: warp, one priority flood and creep timed "
-                       f"separately, erodeComposite for {budget_iters} composite iterations (g={g}); value = cells x {iters} / (warp + 2 floods + "
-                       f"{iters} x per-iteration + creep). The complete {iters}-iteration oracle run, made once in the build container, is recorded "
-                       f"in tests/golden/crc_config3.json (oracle_seconds).")
+                seconds=dict(warp=round(t_warp, 2), flood_at={str(a): round(f, 2) for a, f in zip(points, floods)}, creep=round(t_creep, 2),
+                             per_iteration_at={str(a): round(c, 3) for a, c in zip(points, costs)}, estimated_full_workload=round(est, 1)),
+                sample=f"same {mesh.numRegions}-cell planet and stack on one host core, {t_cpu:.1f} s of CPU work: warp and creep timed on their own; at iteration "
+                       f"{' and '.join(str(a) for a in points)} of the run: the priority flood, and erodeComposite for 2 composite iterations (the first sample with the glacial "
+                       f"step; the later state produced by the HIP path, bit-identical to the oracle's); value = cells x {iters} / (warp + the two floods + the per-iteration "
+                       f"cost interpolated between the samples, summed over {iters} iterations, + creep).  The complete {iters}-iteration oracle run, made once in the build "
+                       f"container, is recorded in tests/golden/crc_config3.json (oracle_seconds).")
+
+
+def collect_pmc_live(args):
+    """WO_BENCH_PMC=1: FETCH_SIZE and WRITE_SIZE per kernel from two child runs of this script under rocprofv3 --pmc (the
+    counters do not fit one pass; counter runs use no trace domains).  Returns {kernel: {COUNTER_KB: {launches, total, per_launch}}}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    if shutil.which("rocprofv3") is None:
+        return None
+    out = defaultdict(dict)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="wo_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, str(REPO / "bench.py"), "--no-cpu", "--no-profile",
+               "--in-flight", "0", "--steps", "1", "--warmup", "0", "--cells", str(args.cells), "--iters", str(args.iters)]
+        env = dict(os.environ); env.pop("WO_BENCH_PMC", None)
+        subprocess.run(cmd, check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, cwd=os.environ.get("TMPDIR", "/tmp"), timeout=1800)
+        acc = defaultdict(lambda: [0, 0.0])
+        for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == counter:
+                    a = acc[row["Kernel_Name"].split("(")[0] if not row["Kernel_Name"].startswith("wo::(anonymous") else row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]]
+                    a[0] += 1; a[1] += float(row["Counter_Value"])
+        for name, (n, tot) in acc.items():
+            out[name][counter + "_KB"] = {"launches": n, "total": tot, "per_launch": tot / max(1, n)}
+        shutil.rmtree(d, ignore_errors=True)
+    return dict(out) or None
 
 
 def d2d_bandwidth_GBs(device: int) -> float:
@@ -478,38 +519,74 @@ def main():
         one_step(pl, seed, params)
         pl.profile_enable(False)
         rep = pl.profile_report()
-        fam, (ms, launches) = max(rep.items(), key=lambda kv: kv[1][0])
-        per_land, per_cell = ALGO_BYTES.get(fam, (0.0, 0.0))
-        passes = max(1, iters if fam not in ("soil_creep", "warp_terrain") else (3 if fam == "soil_creep" else 1))
-        if fam.startswith("sort"):
-            passes = int(stats.get("sorts", iters))
-        bytes_per_pass = per_land * L + per_cell * N
-        launches_per_pass = launches / passes
-        avg_launch_s = ms / 1e3 / launches
-        achieved = bytes_per_pass / launches_per_pass / avg_launch_s / 1e9
-        # per-family view: achieved GB/s on the algorithmic bytes of SURVEY 8(d) (whole passes: bytes / summed launch time)
+        sorts = int(stats.get("sorts", iters))
+        g_iters = params["gIters"]
+
+        def passes_of(pass_name):
+            return sorts if pass_name == "sort" else iters
+
+        # per pass: budget bytes over the summed time of every kernel of the pass (overhead kernels included)
+        kernel_pass = {k: pn for pn, pv in PASSES.items() for k in pv["kernels"]}
+        per_pass = {}
+        for pn, pv in PASSES.items():
+            ms_sum = sum(rep[k][0] for k in pv["kernels"] if k in rep)
+            if ms_sum <= 0:
+                continue
+            gb = (pv["budget"][0] * L + pv["budget"][1] * N) * passes_of(pn) / 1e9
+            per_pass[pn] = dict(ms=round(ms_sum, 3), algorithmic_GB=round(gb, 3), achieved_GBs=round(gb / (ms_sum / 1e3), 1), frac=round(gb / (ms_sum / 1e3) / HBM_PEAK_GBS, 5),
+                                kernels=[k for k in pv["kernels"] if k in rep])
+        # glacial iterations: 86 B x land + 123 B x active carve cells + 27 B x cells per glacial iteration
+        g_ms = sum(rep[k][0] for k in GLACIAL_KERNELS if k in rep)
+        carve_active = float(stats.get("carve_active_total", 0.0))
+        if g_ms > 0 and g_iters > 0:
+            gb = ((86.0 * L + 27.0 * N) * g_iters + 123.0 * carve_active) / 1e9
+            per_pass["glacial"] = dict(ms=round(g_ms, 3), algorithmic_GB=round(gb, 3), achieved_GBs=round(gb / (g_ms / 1e3), 1), frac=round(gb / (g_ms / 1e3) / HBM_PEAK_GBS, 5),
+                                       kernels=[k for k in GLACIAL_KERNELS if k in rep], glacial_iterations=g_iters, active_carve_cells_total=carve_active)
+
+        def kernel_bytes_total(k):
+            """algorithmic bytes of all launches of kernel family k over the step (its share of its pass's budget), or None"""
+            if k in kernel_pass:
+                pl_, pc_ = PASSES[kernel_pass[k]]["kernels"][k]
+                return (pl_ * L + pc_ * N) * passes_of(kernel_pass[k])
+            if k in ONE_OFF:
+                pl_, pc_ = ONE_OFF[k]
+                return (pl_ * L + pc_ * N) * (3 if k == "soil_creep" else 1)
+            if k == "carve_round":
+                return 123.0 * carve_active
+            return None
         fams = {}
         for k, (kms, kl) in sorted(rep.items(), key=lambda kv: -kv[1][0]):
             ent = {"ms": round(kms, 3), "launches": kl}
-            if k in ALGO_BYTES and kms > 0:
-                pl_, pc_ = ALGO_BYTES[k]
-                np_ = int(stats.get("sorts", iters)) if k.startswith("sort") or k == "rank_scatter" else (3 if k == "soil_creep" else (1 if k == "warp_terrain" else iters))
-                gb = (pl_ * L + pc_ * N) * np_ / 1e9
-                ent.update(algorithmic_GB=round(gb, 3), achieved_GBs=round(gb / (kms / 1e3), 1), frac=round(gb / (kms / 1e3) / HBM_PEAK_GBS, 5))
+            kb = kernel_bytes_total(k)
+            if kb is not None and kms > 0:
+                ent.update(**({"pass": kernel_pass[k]} if k in kernel_pass else {}), algorithmic_GB=round(kb / 1e9, 3), achieved_GBs=round(kb / 1e9 / (kms / 1e3), 1),
+                           frac=round(kb / 1e9 / (kms / 1e3) / HBM_PEAK_GBS, 5))
             fams[k] = ent
+        # the dominant kernel: largest total time among the kernels that carry algorithmic bytes
+        fam, (ms, launches) = max(((k, v) for k, v in rep.items() if (kernel_bytes_total(k) or 0) > 0), key=lambda kv: kv[1][0])
+        bytes_per_launch = kernel_bytes_total(fam) / launches
+        avg_launch_s = ms / 1e3 / launches
+        achieved = bytes_per_launch / avg_launch_s / 1e9
         traffic, traffic_note = None, None
-        if PMC_FILE.exists() and args.cells == 10_000_000 and fam in FAMILY_KERNEL:
-            pmc = json.loads(PMC_FILE.read_text()).get(FAMILY_KERNEL[fam])
+        pmc_all = None
+        if os.environ.get("WO_BENCH_PMC") == "1":
+            pmc_all = collect_pmc_live(args)
+            src = "collected by this run (rocprofv3 --pmc, one child process per counter, same workload and iteration count)"
+        elif PMC_FILE.exists() and args.cells == 10_000_000 and iters == 200:
+            pmc_all = json.loads(PMC_FILE.read_text())
+            src = "committed file profiles/" + PMC_FILE.name + " (rocprofv3 --pmc, separate passes per counter, this workload at the full 200 iterations, one planet), not measured in this run"
+        if pmc_all and fam in FAMILY_KERNEL:
+            pmc = next((v for k, v in pmc_all.items() if k.replace("(anonymous namespace)::", "").startswith(FAMILY_KERNEL[fam])), None)
             if pmc and "FETCH_SIZE_KB" in pmc and "WRITE_SIZE_KB" in pmc:
                 traffic = (pmc["FETCH_SIZE_KB"]["per_launch"] + pmc["WRITE_SIZE_KB"]["per_launch"]) * 1024.0
-                traffic_note = ("traffic_source: committed file, not measured in this run; bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB from rocprofv3 --pmc, separate passes, same workload at 6 iterations "
-                                "(profiles/" + PMC_FILE.name + "); FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x and is "
-                                "uncalibrated for 4-byte gathers, so this is a lower bound")
+                traffic_note = ("traffic_source: " + src + "; bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB; FETCH_SIZE on gfx950 under-reports wide coalesced "
+                                "reads by 2x and is uncalibrated for narrow gathers (MI355X_MICROARCH.md), so this is a lower bound")
         roofline = dict(bound="hbm", kernel=fam, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, traffic_note=traffic_note, launches=launches, avg_launch_us=avg_launch_s * 1e6,
-                        algorithmic_bytes_per_launch=bytes_per_pass / launches_per_pass,
-                        note="the solve kernels (solve_patch / solve_round) walk the drainage DAG level by level: bound by dependency latency, not by HBM (DESIGN.md §5)",
-                        families=fams,
+                        algorithmic_bytes_per_launch=bytes_per_launch,
+                        note="algorithmic bytes: the kernel's share of its pass's SURVEY 8(d) budget (the shares of a pass add up to the budget: PASSES in bench.py); "
+                             "the solve walks the drainage DAG in dependency order and is bound by the latency of its chains, not by HBM (DESIGN.md section 5)",
+                        passes=per_pass, families=fams,
                         whole_stack=dict(note="SURVEY 8(d): (243 B x land cells + 12 B x cells) per composite iteration over the wall time of a step",
                                          achieved_GBs=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9,
                                          frac=(243.0 * L + 12.0 * N) * iters / (wall / args.steps) / 1e9 / HBM_PEAK_GBS))
@@ -519,7 +596,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and not virt:
-        cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters, iters)
+        cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters, iters, pl)
 
     if rank == 0:
         value = whole_job_value(N, iters, args.steps, 1 if decomposed_mode else world, wall)

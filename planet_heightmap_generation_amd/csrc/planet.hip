@@ -679,7 +679,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     int sinceRiver = -1;
     // WO_BASIN=0: the Morton patches of round 2 (k_solve_patch from the first launch on) instead of the basin-local solve
     static const bool basinSolve = !(getenv("WO_BASIN") && atoi(getenv("WO_BASIN")) == 0);
-    int64_t basinPasses = 0, basinLeftoverPasses = 0;
+    int64_t basinPasses = 0, basinLeftoverPasses = 0, carveActive = 0;
     int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
     for (int32_t iter = 0; iter < total; ++iter) {
@@ -699,6 +699,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
             {   // dependency lists of the active tasks (once per glacial step)
                 const int32_t active = read_count(p, p->d_counters + 3);
+                carveActive += active;
                 if ((int64_t)active > p->carveCap) {
                     dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]);
                     p->carveCap = (int64_t)active + active / 4 + 1024;
@@ -874,7 +875,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
-                     {"carve_rounds_total", (double)carveRounds}, {"flood_stage_ms", floodHostMs},
+                     {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
                      {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
                      {"flood_pass1_on_host", (floodRun.usedDevice && !floodRun.fellBack) ? 0.0 : 1.0},

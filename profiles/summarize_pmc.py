@@ -15,7 +15,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
-            name = row["Kernel_Name"].split("(")[0]
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             a = acc[name]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
