@@ -74,7 +74,7 @@ struct alignas(8) TargetRank { int32_t target; int32_t rank; };
 // ~1 % of the cells) carry the overflow mark and take the row scans.
 constexpr int WO_EVENTS = 4;
 struct alignas(16) EventList { int32_t cell[WO_EVENTS]; int32_t rank[WO_EVENTS]; };     // unused slots: rank -1; overflow: rank[0] == -2
-constexpr int WO_CARVE_DEPS = 16;       // dependency slots per active carve task
+constexpr int WO_CARVE_DEPS = 24;       // dependency slots per active carve task (a task with more takes the scanning form, and a round lasts as long as its slowest task)
 struct Fields {
     int32_t N;                 // numRegions
     int32_t xcdTile;           // blocks per XCD tile for index-order kernels (device.h: xcd_tile)
@@ -1067,6 +1067,54 @@ WO_HD inline bool carve_task(const Fields& F, int32_t r, int32_t round, double g
         }
     }
     if (F.iceUp[r] >= 2) F.e[r] = (float)((double)F.e[r] - gConvergenceBonus * pow(fl, 0.4));
+    F.doneAt[r] = round;
+    return true;
+}
+
+// The same turn with every load issued before anything is decided: the dependency list, the row, the distances and the
+// task's own inputs first, then the dependencies' round tags together with the neighbours' heights — two levels of dependent
+// loads in all.  A carve round lasts as long as its slowest thread's chain of loads (a round's arithmetic is nothing), and the
+// form above walks list -> tags -> row -> neighbours one after the other.  Values read for a task that turns out not to be
+// ready are dropped; values read for a ready task are current, because everything it depends on finished in an earlier
+// launch.  slot: the task's position in the activation list.  Tasks with more dependencies than fit the list, or a row
+// longer than WO_EAGER_ROW, take the form above.
+constexpr int WO_EAGER_ROW = 12;         // longest row the eager form keeps in registers
+WO_HD inline bool carve_task_eager(const Fields& F, int32_t r, int32_t slot, int32_t round, double gCarveRate, double gConvergenceBonus,
+                                   double glacialStrength) {
+    const int32_t depCnt = F.carveDepCnt[slot];
+    const int32_t jb = F.off[r], deg = F.off[r + 1] - jb;
+    if (depCnt < 0 || deg > WO_EAGER_ROW) return carve_task(F, r, round, gCarveRate, gConvergenceBonus, glacialStrength);
+    const int32_t* deps = F.carveDeps + (size_t)slot * WO_CARVE_DEPS;
+    int32_t dv[WO_CARVE_DEPS], da[WO_CARVE_DEPS];
+#pragma unroll
+    for (int k = 0; k < WO_CARVE_DEPS; ++k) dv[k] = deps[k];
+    int32_t nbs[WO_EAGER_ROW]; float en[WO_EAGER_ROW], dn[WO_EAGER_ROW]; uint8_t on[WO_EAGER_ROW];
+#pragma unroll
+    for (int k = 0; k < WO_EAGER_ROW; ++k) { nbs[k] = k < deg ? F.adj[jb + k] : r; dn[k] = k < deg ? F.dist[jb + k] : 1.0f; }
+    const double fl = F.iceFlow[r];
+    const uint8_t up = F.iceUp[r];
+    const float e0 = F.e[r];
+#pragma unroll
+    for (int k = 0; k < WO_CARVE_DEPS; ++k) da[k] = k < depCnt ? F.doneAt[dv[k]] : -1;
+#pragma unroll
+    for (int k = 0; k < WO_EAGER_ROW; ++k) { on[k] = F.ocean[nbs[k]]; en[k] = F.e[nbs[k]]; }
+    bool ready = true;
+#pragma unroll
+    for (int k = 0; k < WO_CARVE_DEPS; ++k) if (k < depCnt && !(da[k] < round)) ready = false;
+    if (!ready) return false;
+    const double deepening = gCarveRate * pow(fl, 0.6) * glacialStrength;
+    float er = (float)((double)e0 - deepening);
+#pragma unroll
+    for (int k = 0; k < WO_EAGER_ROW; ++k) {
+        if (k >= deg || on[k]) continue;
+        const double d = nd_or_eps(dn[k]);
+        const double slope = fabs((double)er - (double)en[k]) / d;
+        double f = 1 - slope;
+        if (!(f > 0)) f = (f != f) ? f : 0;
+        F.e[nbs[k]] = (float)((double)en[k] - deepening * 0.4 * f);
+    }
+    if (up >= 2) er = (float)((double)er - gConvergenceBonus * pow(fl, 0.4));
+    F.e[r] = er;
     F.doneAt[r] = round;
     return true;
 }

@@ -701,6 +701,22 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_pairs(Fields F, const 
         block_append2(pending, ent, out, outCount);
     }
 }
+// Carve rounds over the STATIC activation list: one thread per active task in every round, no pending lists, no counters on the
+// chain.  A finished task leaves after one load; an open one issues all its loads at once (carve_task_eager) and runs when its
+// dependencies finished in earlier launches.  done: tasks finished so far (one atomic per wave that finished any), read back
+// by the driver every few rounds.
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t round,
+                                                                  double gCarve, double gConv, double gStrength, int32_t* done) {
+    const int32_t n = *count;
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ran = false;
+    if (i < n) {
+        const int32_t r = list[i];
+        if (F.doneAt[r] == WO_NOT_DONE) ran = carve_task_eager(F, r, i, round, gCarve, gConv, gStrength);
+    }
+    const unsigned long long m = __ballot(ran);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(done, __popcll(m));
+}
 // All carve rounds of a glacial step in ONE cooperative launch: the rounds are ~325 dependent steps of a few thousand
 // tasks each, and as separate launches each cost ~37 us (launch + drain) for ~10 us of dependent loads.  Here a grid that
 // is resident as a whole walks the rounds itself, with a grid barrier where the kernel boundary was: same lists, same

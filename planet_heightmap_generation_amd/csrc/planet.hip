@@ -749,8 +749,27 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     k = (int64_t)p->h_count[0] + 1;
                     count = 0;
                 }
-                // (one burst sized by the previous glacial iteration instead of a read-back per 16 rounds: slower, 102 -> 110 ms per step —
-                // the read-back is also what shrinks the grid with the list)
+                // default: rounds over the static activation list (k_carve_round_static): every launch covers all active tasks, a
+                // finished one leaves after one load, an open one issues its loads at once; the number of finished tasks is read
+                // back after a burst (first burst: what the previous glacial iteration needed).  WO_CARVE_ROUNDS=lists: the pending
+                // lists of round 2 (k_carve_round_pairs) below.
+                static const bool staticRounds = !(getenv("WO_CARVE_ROUNDS") && std::string(getenv("WO_CARVE_ROUNDS")) == "lists");
+                if (count > 0 && staticRounds && F.carveDeps) {
+                    const int32_t active = count;
+                    int32_t* done = c + 4;
+                    WO_HIP(hipMemsetAsync(done, 0, sizeof(int32_t), s));
+                    const int grid = blocks_for(active);
+                    // the depth of the carve DAG falls from one glacial iteration to the next (the ice smooths its bed), so the count of
+                    // finished tasks is read back every 32 rounds (a read-back costs about as much as three empty rounds)
+                    static const int burst = getenv("WO_CARVE_BURST") ? std::max(1, atoi(getenv("WO_CARVE_BURST"))) : 32;
+                    for (;;) {
+                        for (int b = 0; b < burst; ++b, ++k)
+                            launch(p, FAM_CARVE_ROUND, k_carve_round_static, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), (int32_t)k, gCarve, gConv, gStrength, done);
+                        if (read_count(p, done) >= active) break;
+                        if (k > 4 * (int64_t)p->N + 1024) throw HipError{"carve rounds do not converge"};
+                    }
+                    count = 0;
+                }
                 while (count > 0) {
                     const int grid = blocks_for(count, 2048);
                     for (int b = 0; b < 16; ++b, ++k) {
