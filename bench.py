@@ -182,8 +182,8 @@ def one_step(pl, seed, params, iters_scale=None):
 class Decomposition:
     """Per-rank state of the landmass decomposition: the plan is a function of the ocean mask (recomputed when it changes)."""
 
-    def __init__(self, mesh, pl, rank, world, dist, device):
-        self.mesh, self.pl, self.rank, self.world, self.dist, self.device = mesh, pl, rank, world, dist, device
+    def __init__(self, mesh, pl, rank, world, dist, device, comm=None):
+        self.mesh, self.pl, self.rank, self.world, self.dist, self.device, self.comm = mesh, pl, rank, world, dist, device, comm
         self.plan, self.mask, self.true_oc, self.link, self.exchange_ms, self.plan_ms = None, None, None, None, 0.0, 0.0
 
     def apply_mask(self):
@@ -200,7 +200,7 @@ class Decomposition:
 
     def merge(self):
         t0 = time.perf_counter()
-        self.link.exchange(self.dist, self.device)
+        self.link.exchange(self.dist, self.device, self.comm)
         self.pl.sync()
         self.exchange_ms = (time.perf_counter() - t0) * 1e3
 
@@ -209,7 +209,8 @@ class Decomposition:
         return dict(landmasses=self.plan.num_landmasses, largest_landmass_fraction=round(self.plan.largest / L, 4),
                     land_cells_per_rank=[int(v) for v in self.plan.load], speedup_bound_by_cell_count=round(L / max(1, int(self.plan.load.max())), 2),
                     plan_ms_when_mask_changes=round(self.plan_ms, 1), exchange_ms_last_step=round(self.exchange_ms, 2),
-                    exchange="all-gather of 4 B per land cell per step (RCCL); no exchange inside the iteration loop")
+                    exchange="all-gather of 4 B per land cell per step (RCCL); no exchange inside the iteration loop",
+                    exchange_path="C ABI (wo_planet_exchange_allgather: pack, ncclAllGather, unpack on the planet's stream)" if self.comm is not None else "torch.distributed")
 
 
 def one_step_decomposed(pl, seed, params, dec: Decomposition):
@@ -476,7 +477,22 @@ def main():
         torch.cuda.synchronize()
         pl.sync()
 
-    dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}" if args.backend == "nccl" else None) if decomposed_mode else None
+    comm = None
+    if decomposed_mode and args.backend == "nccl" and os.environ.get("WO_BENCH_TORCH_EXCHANGE") != "1":
+        # the exchange behind the C ABI: rank 0's RCCL id goes round through torch.distributed, every rank joins with it
+        try:
+            box = [TP.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = TP.Comm(pl.ctx, box[0], world, rank)
+        except Exception as ex:          # never lose the run over the communicator: torch.distributed carries the exchange then
+            print(f"[bench] rank {rank}: wo_comm unavailable ({ex}); exchanging through torch.distributed", file=sys.stderr)
+            comm = None
+        flags = [comm is not None]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, flags[0])
+        if not all(gathered):
+            comm = None
+    dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}" if args.backend == "nccl" else None, comm) if decomposed_mode else None
     step = (lambda: one_step_decomposed(pl, seed, params, dec)) if decomposed_mode else (lambda: one_step(pl, seed, params))
     virt = VirtualShares(mesh, pl, max(1, args.shares)) if (world == 1 and args.mode == "decomposed") else None
     unpart_ms = None

@@ -169,6 +169,28 @@ int wo_advect_moisture(wo_planet* planet, const float* r_heightKm, const uint8_t
                        const float* r_wind3dX, const float* r_wind3dY, const float* r_wind3dZ, const float* r_oceanWarmth,
                        const int32_t* r_coastDistLand, int32_t maxHops, float* out);
 
+/* ------------------------------------------------ multi-GPU exchange over RCCL --- */
+/* The reference is one single-threaded worker (js/planet-worker.js:944-954): it has no exchange to replace.  A multi-GPU
+ * host runs one process (or worker thread) per GPU; these entry points keep the data path on the devices — RCCL over xGMI on
+ * the planet's own stream.  Rank 0 obtains the 128-byte id, the HOST distributes it by whatever channel it has (a message to
+ * its workers, torch.distributed, a file), every rank creates its communicator with it (collective call).
+ *   wo_planet_exchange_allgather  every rank contributes the values of its send list (wo_planet_set_halo) and receives all
+ *                                 the others' (its receive list = the others' contributions in rank order): the merge of the
+ *                                 landmass decomposition.  counts[j] = length of rank j's send list.  ncclAllGather.
+ *   wo_planet_exchange_neighbors  the first nToPrev entries of the send list go to rank-1, the rest to rank+1; the first
+ *                                 nFromPrev entries of the receive list come from rank-1, the rest from rank+1: the one-ring
+ *                                 halo of a band decomposition.  ncclSend / ncclRecv in one group.
+ * Both return when the received values are in the resident field. */
+#define WO_COMM_ID_BYTES 128
+typedef struct wo_comm wo_comm;
+int wo_comm_unique_id(uint8_t* id);                                                    /* WO_COMM_ID_BYTES bytes out */
+int wo_comm_create(wo_ctx* ctx, const uint8_t* id, int32_t nranks, int32_t rank, wo_comm** out);
+int wo_comm_destroy(wo_comm* comm);
+int wo_comm_rank(const wo_comm* comm);
+int wo_comm_size(const wo_comm* comm);
+int wo_planet_exchange_allgather(wo_planet* planet, wo_comm* comm, const int32_t* counts);
+int wo_planet_exchange_neighbors(wo_planet* planet, wo_comm* comm, int32_t nToPrev, int32_t nFromPrev);
+
 /* ------------------------------------------------ landmass decomposition --------- */
 /* Connected components of the land cells (cells with r_isOcean == 0, joined along mesh edges).  label[r] = smallest
  * region id of r's landmass, -1 for ocean cells.  Every order-defined pass of erodeComposite (js/terrain-post.js:369-707:

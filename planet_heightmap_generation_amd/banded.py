@@ -134,7 +134,16 @@ class ResidentBand:
         cat = lambda xs: np.concatenate(xs).astype(np.int32) if xs else np.empty(0, np.int32)
         planet.set_halo(cat([part.send[j] for j in self.peers]), cat([part.recv[j] for j in self.peers]))
 
-    def exchange(self, dist, device=None) -> None:
+    def exchange(self, dist, device=None, comm=None) -> None:
+        """comm: a terrain_post.Comm — pack, ncclSend / ncclRecv with the two chain neighbours and unpack behind the C ABI
+        (wo_planet_exchange_neighbors).  Index bands only touch rank - 1 and rank + 1; the lists are [to prev | to next]."""
+        if comm is not None:
+            if any(abs(j - self.part.rank) != 1 for j in self.peers):
+                raise ValueError("the C-ABI band exchange talks to rank - 1 and rank + 1 only")
+            to_prev = sum(a for j, a in zip(self.peers, self.send_sizes) if j < self.part.rank)
+            from_prev = sum(b for j, b in zip(self.peers, self.recv_sizes) if j < self.part.rank)
+            self.planet.exchange_neighbors(comm, to_prev, from_prev)
+            return
         import torch
         ns, nr = sum(self.send_sizes), sum(self.recv_sizes)
         if device is not None:
@@ -160,12 +169,12 @@ class ResidentBand:
             else:
                 self.planet.unpack_halo(rbuf.numpy())
 
-    def jacobi(self, step_resident: Callable[[], None], iterations: int, dist, device=None) -> None:
+    def jacobi(self, step_resident: Callable[[], None], iterations: int, dist, device=None, comm=None) -> None:
         """`step_resident()` advances the resident field by ONE iteration (e.g. ``lambda: planet.apply_soil_creep_resident(1, s)``)."""
         for _ in range(iterations):
             step_resident()
-            if dist is not None:
-                self.exchange(dist, device)
+            if dist is not None or comm is not None:
+                self.exchange(dist, device, comm)
 
 
 def gather_owned(plan: BandPlan, rank: int, field_local: np.ndarray, dist) -> np.ndarray | None:

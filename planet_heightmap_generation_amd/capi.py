@@ -63,6 +63,13 @@ SIGNATURES = {
     "wo_planet_set_halo": (C.c_int, [_p, _p, _c_i32, _p, _c_i32]),
     "wo_planet_pack_halo": (C.c_int, [_p, _p, _p]),
     "wo_planet_unpack_halo": (C.c_int, [_p, _p, _p]),
+    "wo_comm_unique_id": (C.c_int, [_p]),
+    "wo_comm_create": (C.c_int, [_p, _p, _c_i32, _c_i32, _p]),
+    "wo_comm_destroy": (C.c_int, [_p]),
+    "wo_comm_rank": (C.c_int, [_p]),
+    "wo_comm_size": (C.c_int, [_p]),
+    "wo_planet_exchange_allgather": (C.c_int, [_p, _p, _p]),
+    "wo_planet_exchange_neighbors": (C.c_int, [_p, _p, _c_i32, _c_i32]),
     "wo_planet_ocean_from_elevation": (C.c_int, [_p]),
     "wo_planet_download_ocean": (C.c_int, [_p, _p]),
     "wo_planet_sync": (C.c_int, [_p]),

@@ -1,0 +1,140 @@
+// Multi-GPU exchange behind the C ABI: one process per GPU, RCCL over xGMI on the planet's own stream.
+//
+// The reference is a single-threaded browser worker (js/planet-worker.js): it has no exchange to replace.  These entry points
+// are what a multi-GPU host — the JS worker pool of INTEGRATION.md or bench.py — needs so that the data path never leaves the
+// devices: the communicator is created from a 128-byte id that rank 0 obtains and the HOST distributes (any channel: a
+// message to the worker threads, torch.distributed, a file), and the two exchange shapes are
+//   * wo_planet_exchange_allgather: every rank contributes the values of its send list (wo_planet_set_halo), every rank
+//     receives all the others' — the merge of the landmass decomposition (decomposed.py), ncclAllGather;
+//   * wo_planet_exchange_neighbors: the send list goes in two parts to the previous / next rank of a chain and the receive
+//     list comes from them — the one-ring halo of a band decomposition (banded.py), ncclSend / ncclRecv in one group.
+// Pack and unpack are the kernels of wo_planet_pack_halo / unpack_halo; everything is enqueued on the planet's stream.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+
+#include "../../include/worogen.h"
+#include "device.h"
+
+struct wo_comm {
+    ncclComm_t comm = nullptr;
+    int32_t nranks = 0, rank = 0, device = 0;
+    float* gather = nullptr; size_t gatherCap = 0;      // [nranks][maxPerRank] landing buffer of the all-gather
+    float* send = nullptr; size_t sendCap = 0;
+};
+
+namespace {
+__global__ __launch_bounds__(wo::WO_BLOCK) void k_comm_pack(const float* __restrict__ e, const int32_t* __restrict__ idx, int32_t n, float* __restrict__ out) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = e[idx[i]];
+}
+__global__ __launch_bounds__(wo::WO_BLOCK) void k_comm_unpack(float* __restrict__ e, const int32_t* __restrict__ idx, int32_t n, const float* __restrict__ in) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) e[idx[i]] = in[i];
+}
+
+bool nccl_ok(ncclResult_t r, const char* what) {
+    if (r == ncclSuccess) return true;
+    wo::set_error(std::string(what) + ": " + ncclGetErrorString(r));
+    return false;
+}
+template <class T> void grow(T*& p, size_t& cap, size_t need) {
+    if (need <= cap) return;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    if (hipMalloc((void**)&p, need * sizeof(T)) == hipSuccess) cap = need;
+}
+}  // namespace
+
+extern "C" {
+
+int wo_comm_unique_id(uint8_t* id) {
+    if (!id) { wo::set_error("wo_comm_unique_id: null output"); return 1; }
+    static_assert(sizeof(ncclUniqueId) == WO_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    if (!nccl_ok(ncclGetUniqueId(&u), "ncclGetUniqueId")) return 1;
+    std::memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int wo_comm_create(wo_ctx* ctx, const uint8_t* id, int32_t nranks, int32_t rank, wo_comm** out) {
+    if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) { wo::set_error("wo_comm_create: bad arguments"); return 1; }
+    if (hipSetDevice(ctx->device) != hipSuccess) { wo::set_error("wo_comm_create: cannot select the context's device"); return 1; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    wo_comm* c = new wo_comm;
+    c->nranks = nranks; c->rank = rank; c->device = ctx->device;
+    if (!nccl_ok(ncclCommInitRank(&c->comm, nranks, u, rank), "ncclCommInitRank")) { delete c; return 1; }
+    *out = c;
+    return 0;
+}
+
+int wo_comm_destroy(wo_comm* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->gather) (void)hipFree(c->gather);
+    if (c->send) (void)hipFree(c->send);
+    delete c;
+    return 0;
+}
+
+int wo_comm_rank(const wo_comm* c) { return c ? c->rank : -1; }
+int wo_comm_size(const wo_comm* c) { return c ? c->nranks : 0; }
+
+// counts[j] = length of rank j's send list (counts[rank] must equal this planet's); the receive list (set_halo) is the
+// concatenation of the other ranks' contributions in rank order.
+int wo_planet_exchange_allgather(wo_planet* p, wo_comm* c, const int32_t* counts) {
+    if (!p || !c || !counts) { wo::set_error("wo_planet_exchange_allgather: bad arguments"); return 1; }
+    int64_t others = 0; int32_t maxCount = 1;
+    for (int32_t j = 0; j < c->nranks; ++j) { if (counts[j] < 0) { wo::set_error("wo_planet_exchange_allgather: negative count"); return 1; } if (j != c->rank) others += counts[j]; maxCount = std::max(maxCount, counts[j]); }
+    if (counts[c->rank] != p->nHaloSend || others != p->nHaloRecv) { wo::set_error("wo_planet_exchange_allgather: counts do not match the planet's halo lists (wo_planet_set_halo)"); return 1; }
+    try {
+        hipStream_t s = p->ctx->stream;
+        grow(c->send, c->sendCap, (size_t)maxCount);
+        grow(c->gather, c->gatherCap, (size_t)maxCount * (size_t)c->nranks);
+        if (!c->send || !c->gather) { wo::set_error("wo_planet_exchange_allgather: out of device memory"); return 1; }
+        if (p->nHaloSend > 0) wo::launch(p, wo::FAM_MISC, k_comm_pack, wo::blocks_for(p->nHaloSend), wo::WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_haloSend, p->nHaloSend, c->send);
+        if (p->nHaloSend < maxCount) WO_HIP(hipMemsetAsync(c->send + p->nHaloSend, 0, (size_t)(maxCount - p->nHaloSend) * sizeof(float), s));
+        if (!nccl_ok(ncclAllGather(c->send, c->gather, (size_t)maxCount, ncclFloat, c->comm, s), "ncclAllGather")) return 1;
+        // the others' parts, compacted in rank order into the unpack buffer
+        size_t at = 0;
+        for (int32_t j = 0; j < c->nranks; ++j) {
+            if (j == c->rank || counts[j] == 0) continue;
+            WO_HIP(hipMemcpyAsync(p->d_haloBuf + at, c->gather + (size_t)j * maxCount, (size_t)counts[j] * sizeof(float), hipMemcpyDeviceToDevice, s));
+            at += (size_t)counts[j];
+        }
+        if (p->nHaloRecv > 0) wo::launch(p, wo::FAM_MISC, k_comm_unpack, wo::blocks_for(p->nHaloRecv), wo::WO_BLOCK, p->d_e, (const int32_t*)p->d_haloRecv, p->nHaloRecv, (const float*)p->d_haloBuf);
+        WO_HIP(hipStreamSynchronize(s));
+        return 0;
+    } catch (const wo::HipError& e) { wo::set_error(std::string("wo_planet_exchange_allgather: ") + e.msg); return 1; }
+}
+
+// Chain neighbours: the first nToPrev entries of the send list go to rank - 1, the rest to rank + 1; the first nFromPrev
+// entries of the receive list come from rank - 1, the rest from rank + 1.  A missing neighbour (ends of the chain) has count 0.
+int wo_planet_exchange_neighbors(wo_planet* p, wo_comm* c, int32_t nToPrev, int32_t nFromPrev) {
+    if (!p || !c) { wo::set_error("wo_planet_exchange_neighbors: bad arguments"); return 1; }
+    const int32_t nToNext = p->nHaloSend - nToPrev, nFromNext = p->nHaloRecv - nFromPrev;
+    const bool hasPrev = c->rank > 0, hasNext = c->rank + 1 < c->nranks;
+    if (nToPrev < 0 || nFromPrev < 0 || nToNext < 0 || nFromNext < 0 || (!hasPrev && (nToPrev || nFromPrev)) || (!hasNext && (nToNext || nFromNext))) {
+        wo::set_error("wo_planet_exchange_neighbors: counts do not match the planet's halo lists / the rank's place in the chain"); return 1;
+    }
+    try {
+        hipStream_t s = p->ctx->stream;
+        grow(c->send, c->sendCap, (size_t)std::max(p->nHaloSend, 1));
+        if (!c->send) { wo::set_error("wo_planet_exchange_neighbors: out of device memory"); return 1; }
+        if (p->nHaloSend > 0) wo::launch(p, wo::FAM_MISC, k_comm_pack, wo::blocks_for(p->nHaloSend), wo::WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_haloSend, p->nHaloSend, c->send);
+        if (!nccl_ok(ncclGroupStart(), "ncclGroupStart")) return 1;
+        bool ok = true;
+        if (hasPrev && nToPrev) ok = ok && nccl_ok(ncclSend(c->send, (size_t)nToPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclSend");
+        if (hasNext && nToNext) ok = ok && nccl_ok(ncclSend(c->send + nToPrev, (size_t)nToNext, ncclFloat, c->rank + 1, c->comm, s), "ncclSend");
+        if (hasPrev && nFromPrev) ok = ok && nccl_ok(ncclRecv(p->d_haloBuf, (size_t)nFromPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclRecv");
+        if (hasNext && nFromNext) ok = ok && nccl_ok(ncclRecv(p->d_haloBuf + nFromPrev, (size_t)nFromNext, ncclFloat, c->rank + 1, c->comm, s), "ncclRecv");
+        if (!nccl_ok(ncclGroupEnd(), "ncclGroupEnd") || !ok) return 1;
+        if (p->nHaloRecv > 0) wo::launch(p, wo::FAM_MISC, k_comm_unpack, wo::blocks_for(p->nHaloRecv), wo::WO_BLOCK, p->d_e, (const int32_t*)p->d_haloRecv, p->nHaloRecv, (const float*)p->d_haloBuf);
+        WO_HIP(hipStreamSynchronize(s));
+        return 0;
+    } catch (const wo::HipError& e) { wo::set_error(std::string("wo_planet_exchange_neighbors: ") + e.msg); return 1; }
+}
+
+}  // extern "C"

@@ -138,12 +138,20 @@ class ResidentLandmass:
         planet.set_halo(plan.cells[rank], recv)
         self.n_max = max(1, plan.max_cells)
 
-    def exchange(self, dist, device=None) -> None:
-        if dist is None or self.plan.world == 1:
+    def exchange(self, dist, device=None, comm=None) -> None:
+        """comm: a terrain_post.Comm — the whole exchange (pack, ncclAllGather, unpack) runs behind the C ABI on the planet's
+        stream (wo_planet_exchange_allgather); otherwise torch.distributed carries it (device tensors over RCCL when `device` is
+        given, pinned host staging under gloo)."""
+        if self.plan.world == 1:
             return
-        import torch
         plan, rank = self.plan, self.rank
         sizes = [int(c.size) for c in plan.cells]
+        if comm is not None:
+            self.planet.exchange_allgather(comm, sizes)
+            return
+        if dist is None:
+            return
+        import torch
         if device is not None:
             # torch.empty, not torch.zeros: a fill kernel queued on torch's stream is not ordered against the pack, which
             # runs on the planet's own (non-blocking) stream and could be overwritten by a late fill.  The pack is

@@ -471,6 +471,47 @@ napi_value SmoothAndReconnectPlates(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// ---- multi-GPU exchange over RCCL (include/worogen.h: wo_comm_*; one worker thread per GPU holds one communicator) -------
+void FinalizeComm(napi_env, void* data, void*) { wo_comm_destroy((wo_comm*)data); }
+napi_value CommUniqueId(napi_env env, napi_callback_info) {                   // () -> Uint8Array(128): rank 0 makes it, the host posts it to every worker
+    void* d; napi_value out = make_ta(env, napi_uint8_array, WO_COMM_ID_BYTES, 1, &d);
+    if (wo_comm_unique_id((uint8_t*)d)) return throw_wo(env, "commUniqueId");
+    return out;
+}
+napi_value CommCreate(napi_env env, napi_callback_info info) {                 // (ctx, id Uint8Array(128), nranks, rank) -> comm handle (collective)
+    Args a(env, info);
+    wo_ctx* c = (wo_ctx*)a.ext(0);
+    size_t n; uint8_t* id = (uint8_t*)a.ta(1, napi_uint8_array, &n); if (!a.ok) return nullptr;
+    if (!c || n != WO_COMM_ID_BYTES) { napi_throw_type_error(env, nullptr, "commCreate: expected (ctx, Uint8Array(128), nranks, rank)"); return nullptr; }
+    wo_comm* cm = nullptr;
+    if (wo_comm_create(c, id, a.i32(2), a.i32(3), &cm)) return throw_wo(env, "commCreate");
+    napi_value v; NAPI_OK(napi_create_external(env, cm, FinalizeComm, nullptr, &v));
+    return v;
+}
+napi_value PlanetSetHalo(napi_env env, napi_callback_info info) {              // (planet, sendIdx Int32Array, recvIdx Int32Array)
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    if (!planet_ok(env, p)) return nullptr;
+    size_t ns, nr; int32_t* s = (int32_t*)a.ta(1, napi_int32_array, &ns); if (!a.ok) return nullptr;
+    int32_t* r = (int32_t*)a.ta(2, napi_int32_array, &nr); if (!a.ok) return nullptr;
+    if (wo_planet_set_halo(p, s, (int32_t)ns, r, (int32_t)nr)) return throw_wo(env, "planetSetHalo");
+    return nullptr;
+}
+napi_value PlanetExchangeAllgather(napi_env env, napi_callback_info info) {    // (planet, comm, counts Int32Array(nranks))
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0); wo_comm* cm = (wo_comm*)a.ext(1);
+    if (!planet_ok(env, p)) return nullptr;
+    size_t n; int32_t* counts = (int32_t*)a.ta(2, napi_int32_array, &n); if (!a.ok) return nullptr;
+    if (!cm || (int)n != wo_comm_size(cm)) { napi_throw_range_error(env, nullptr, "planetExchangeAllgather: one count per rank"); return nullptr; }
+    if (wo_planet_exchange_allgather(p, cm, counts)) return throw_wo(env, "planetExchangeAllgather");
+    return nullptr;
+}
+napi_value PlanetExchangeNeighbors(napi_env env, napi_callback_info info) {    // (planet, comm, nToPrev, nFromPrev)
+    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0); wo_comm* cm = (wo_comm*)a.ext(1);
+    if (!planet_ok(env, p)) return nullptr;
+    if (!cm) { napi_throw_type_error(env, nullptr, "planetExchangeNeighbors: expected a communicator handle"); return nullptr; }
+    if (wo_planet_exchange_neighbors(p, cm, a.i32(2), a.i32(3))) return throw_wo(env, "planetExchangeNeighbors");
+    return nullptr;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"fibSpherePoints", FibSpherePoints}, {"sphereDelaunay", SphereDelaunay}, {"meshCsr", MeshCsr}, {"neighborDist", NeighborDist},
@@ -488,6 +529,8 @@ napi_value Init(napi_env env, napi_value exports) {
         {"projectCoarsePlates", ProjectCoarsePlates}, {"smoothField", SmoothField}, {"smoothAndReconnectPlates", SmoothAndReconnectPlates},
         {"diffuseOceanWarmth", DiffuseOceanWarmth}, {"computeWindConvergence", WindConvergence}, {"advectMoisture", AdvectMoisture},
         {"landComponents", LandComponents},
+        {"commUniqueId", CommUniqueId}, {"commCreate", CommCreate}, {"planetSetHalo", PlanetSetHalo},
+        {"planetExchangeAllgather", PlanetExchangeAllgather}, {"planetExchangeNeighbors", PlanetExchangeNeighbors},
     };
     for (auto& f : fns) {
         napi_value v;

@@ -56,6 +56,37 @@ def _u8(a, n):
     return a
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (include/worogen.h: wo_comm_*): one per rank, created collectively from the 128-byte id
+    that rank 0 obtains with Comm.unique_id() and the host distributes (bench.py: torch.distributed's object broadcast)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = np.zeros(128, np.uint8)
+        capi.check(capi.lib().wo_comm_unique_id(capi.ptr(buf)), "wo_comm_unique_id")
+        return buf.tobytes()
+
+    def __init__(self, ctx: "Context", uid: bytes, size: int, rank: int):
+        import ctypes as C
+        if len(uid) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        idb = np.frombuffer(uid, np.uint8).copy()
+        h = C.c_void_p()
+        capi.check(capi.lib().wo_comm_create(ctx.handle, capi.ptr(idb), int(size), int(rank), C.byref(h)), "wo_comm_create")
+        self.handle, self.size, self.rank, self.ctx = h, int(size), int(rank), ctx
+
+    def close(self):
+        if getattr(self, "handle", None):
+            capi.lib().wo_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Planet:
     """Device-resident planet: CSR mesh + r_xyz + neighborDist, and the current r_elevation / r_isOcean."""
 
@@ -123,6 +154,18 @@ class Planet:
         out = np.empty(self.numRegions, np.float32)
         capi.check(capi.lib().wo_planet_download(self.handle, capi.ptr(out)), "wo_planet_download")
         return out
+
+    # ---- exchange over RCCL behind the C ABI (Comm below) ----
+    def exchange_allgather(self, comm: "Comm", counts) -> None:
+        """Every rank contributes the values of its send list and receives all the others' (set_halo lists): the landmass merge."""
+        c = np.ascontiguousarray(counts, np.int32)
+        if c.size != comm.size:
+            raise ValueError("one count per rank")
+        capi.check(capi.lib().wo_planet_exchange_allgather(self.handle, comm.handle, capi.ptr(c)), "wo_planet_exchange_allgather")
+
+    def exchange_neighbors(self, comm: "Comm", n_to_prev: int, n_from_prev: int) -> None:
+        """One-ring halo swap with rank - 1 / rank + 1 of a band chain (set_halo lists: [to prev | to next], [from prev | from next])."""
+        capi.check(capi.lib().wo_planet_exchange_neighbors(self.handle, comm.handle, int(n_to_prev), int(n_from_prev)), "wo_planet_exchange_neighbors")
 
     # ---- band-decomposed Jacobi passes (banded.py) ----
     def set_halo(self, send_idx, recv_idx):

@@ -589,3 +589,29 @@ def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells
     for r in range(world):
         out = np.load(tmp_path / f"result_{r}.npy")
         assert np.array_equal(out, ref), (r, int((out != ref).sum()))
+
+
+def test_exchange_behind_the_c_abi_single_rank(TP):
+    """wo_comm_* / wo_planet_exchange_*: the RCCL communicator and both exchange shapes on a real device.  RCCL refuses two
+    ranks on one GPU, so a one-GPU box can only run the one-rank communicator: the all-gather then returns the rank's own
+    contribution (nothing to unpack) and the chain has no neighbours — what is checked is that the communicator comes up
+    from the 128-byte id, that ncclAllGather / the send-recv group run on the planet's stream, and that the field is
+    untouched.  The N-rank logic (which cells go where) is covered by the gloo tests (tests/test_decomposed.py,
+    tests/test_banded.py) that drive the same pack / unpack lists."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(20000, 0.75, 1)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(1)
+    before = pl.download()
+    uid = TP.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = TP.Comm(pl.ctx, uid, 1, 0)
+    send = np.arange(0, 5000, 3, dtype=np.int32)
+    pl.set_halo(send, np.empty(0, np.int32))
+    pl.exchange_allgather(comm, [send.size])
+    pl.exchange_neighbors(comm, 0, 0)
+    with pytest.raises(Exception):
+        pl.exchange_allgather(comm, [send.size + 1])          # counts must match the planet's lists
+    assert np.array_equal(pl.download(), before)
+    comm.close()
+    pl.close()
