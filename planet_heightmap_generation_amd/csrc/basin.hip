@@ -421,11 +421,12 @@ static int basin_range() {
 // pass (F.tr) and before k_solve_setup; everything is enqueued on the planet's stream, no host sync.
 void basin_layout(wo_planet* p) {
     const int32_t N = p->N, L = p->L;
-    hipStream_t s = p->ctx->stream;
+    hipStream_t s = cur_stream(p);
     if (!p->d_basinJ) {
         WO_HIP(hipMalloc((void**)&p->d_basinJ, (size_t)N * 4));
         WO_HIP(hipMalloc((void**)&p->d_basinSlot, (size_t)N * 4));
         WO_HIP(hipMalloc((void**)&p->d_basinKey, (size_t)N * 4));
+        WO_HIP(hipMalloc((void**)&p->d_basinVals[0], (size_t)N * 4)); WO_HIP(hipMalloc((void**)&p->d_basinVals[1], (size_t)N * 4));   // own buffers: the layout runs beside the flow accumulation, whose rounds use the planet's lists
         WO_HIP(hipMalloc((void**)&p->d_basinRange, ((size_t)N / 64 + 4) * 4));
         WO_HIP(hipMemsetAsync(p->d_basinSlot, 0xff, (size_t)N * 4, s));
     }
@@ -437,19 +438,19 @@ void basin_layout(wo_planet* p) {
     const int grid = blocks_for(L, 1 << 16);
     launch(p, FAM_BASIN, k_basin_init, grid, WO_BLOCK, F, (const int32_t*)p->d_patchOrder, (const int32_t*)p->d_slotOf, p->d_basinJ, L);
     launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
-    launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_listA);
+    launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0]);
     {
         hipEvent_t a = nullptr, b = nullptr;
         if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
         size_t bytes = p->sortTempBytes;
         WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, (const uint32_t*)p->d_keys[0], p->d_keys[1],
-                                                 (const int32_t*)p->d_listA, p->d_listB, L, 0, bitsL - shift, s));
+                                                 (const int32_t*)p->d_basinVals[0], p->d_basinVals[1], L, 0, bitsL - shift, s));
         if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_BASIN_SORT, a, b}); }
     }
     const int rangeT = basin_range();
     const int nRanges = (int)(((int64_t)L + rangeT - 1) / rangeT);
     WO_HIP(hipMemsetAsync(p->d_basinRange, 0x7f, (size_t)(nRanges + 1) * 4, s));
-    launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_listB, (const uint32_t*)p->d_keys[1], p->d_basinSlot, L, p->d_basinRange, (int32_t)rangeT);
+    launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[1], (const uint32_t*)p->d_keys[1], p->d_basinSlot, L, p->d_basinRange, (int32_t)rangeT);
 }
 
 // the one launch of the pass; F.slotOf must be d_basinSlot, patchPending zeroed
@@ -484,6 +485,7 @@ void basin_free(wo_planet* p) {
     if (p->d_basinJ) (void)hipFree(p->d_basinJ);
     if (p->d_basinSlot) (void)hipFree(p->d_basinSlot);
     if (p->d_basinKey) (void)hipFree(p->d_basinKey);
+    for (auto& v : p->d_basinVals) { if (v) (void)hipFree(v); v = nullptr; }
     if (p->d_basinRange) (void)hipFree(p->d_basinRange);
     p->d_basinJ = nullptr; p->d_basinSlot = nullptr; p->d_basinKey = nullptr; p->d_basinRange = nullptr;
 }

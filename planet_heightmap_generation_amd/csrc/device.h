@@ -122,7 +122,8 @@ struct wo_planet {
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
     uint32_t* d_riverA[2] = {nullptr, nullptr}; int32_t* d_riverJ[2] = {nullptr, nullptr}; int32_t* d_riverIdx = nullptr;   // river.hip
     uint32_t *d_riverRootSize = nullptr, *d_riverRootBase = nullptr; int32_t* d_riverFlag = nullptr; int64_t riverRefreshes = 0;
-    uint32_t* d_basinKey = nullptr; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; int64_t basinLaunches = 0;   // basin.hip: component roots (Morton slot space), group-major store order of the pass
+    hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; bool onSide = false;   // second stream of the planet: the basin layout runs beside the flow accumulation (planet.hip)
+    uint32_t* d_basinKey = nullptr; int32_t* d_basinVals[2] = {nullptr, nullptr}; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; int64_t basinLaunches = 0;   // basin.hip: component roots (Morton slot space), group-major store order of the pass
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
     int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
     void* d_sortTemp = nullptr; size_t sortTempBytes = 0;
@@ -162,9 +163,12 @@ namespace wo {
 hipEvent_t profile_event(wo_planet* p);
 void profile_resolve(wo_planet* p);
 
+// the stream launches of this planet currently go to (its context's stream, or the planet's side stream while onSide is set)
+inline hipStream_t cur_stream(const wo_planet* p) { return (p->onSide && p->side) ? p->side : p->ctx->stream; }
+
 template <class... KArgs, class... Args>
 inline void launch(wo_planet* p, int fam, void (*kernel)(KArgs...), int grid, int block, Args... args) {
-    hipStream_t s = p->ctx->stream;
+    hipStream_t s = cur_stream(p);
     if (p->profiling) {
         hipEvent_t a = profile_event(p), b = profile_event(p);
         WO_HIP(hipEventRecord(a, s));

@@ -35,6 +35,7 @@ hipEvent_t profile_event(wo_planet* p) {
 void profile_resolve(wo_planet* p) {
     if (p->pending.empty()) return;
     WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    if (p->side) WO_HIP(hipStreamSynchronize(p->side));
     for (auto& pe : p->pending) {
         float ms = 0; WO_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
         p->famMs[pe.fam] += ms; p->famLaunches[pe.fam] += 1;
@@ -793,6 +794,24 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.begin("receivers");
             launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();
+            // basin-local solve (basin.hip): this pass's store order groups every drainage component with everything it depends on.
+            // The layout needs the receivers only and touches none of the flow accumulation's arrays, and both are chains of
+            // latency-bound launches that leave most of the chip idle: the layout runs on the planet's side stream beside the flow
+            // accumulation and the solve's setup waits for both (WO_BASIN_OVERLAP=0: one after the other on the main stream).
+            const bool basin = basinSolve && p->patchVersion >= 0 && riverEvery <= 0;
+            static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
+            if (basin && basinOverlap) {
+                if (!p->side) {
+                    WO_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+                    WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
+                }
+                WO_HIP(hipEventRecord(p->evFork, s));
+                WO_HIP(hipStreamWaitEvent(p->side, p->evFork, 0));
+                p->onSide = true;
+                try { basin_layout(p); } catch (...) { p->onSide = false; throw; }
+                p->onSide = false;
+                WO_HIP(hipEventRecord(p->evJoin, p->side));
+            }
             clk.begin("flow");
             // Flow accumulation = subtree sizes of the forward forest (integers: any order of the additions is exact).
             //  default           one launch: every leaf hands its total to its receiver and the thread that completes a receiver
@@ -846,9 +865,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 sinceRiver = 0; ++p->riverRefreshes;
             }
             ++sinceRiver;
-            // basin-local solve (basin.hip): this pass's store order groups every drainage component with everything it depends on
-            const bool basin = basinSolve && p->patchVersion >= 0 && riverEvery <= 0;
-            if (basin) { basin_layout(p); F.slotOf = p->d_basinSlot; }
+            if (basin) {
+                if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p);
+                F.slotOf = p->d_basinSlot;
+            }
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
                 const int64_t r = run_solve_patches(p, F, K, m, dt, basin);
@@ -1089,6 +1109,9 @@ void wo_planet_destroy(wo_planet* p) {
     flood_gpu_free(p->fgpu);
     river_free(p);
     basin_free(p);
+    if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); p->side = nullptr; }
+    if (p->evFork) { (void)hipEventDestroy(p->evFork); p->evFork = nullptr; }
+    if (p->evJoin) { (void)hipEventDestroy(p->evJoin); p->evJoin = nullptr; }
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);

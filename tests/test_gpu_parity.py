@@ -609,9 +609,12 @@ def test_exchange_behind_the_c_abi_single_rank(TP):
     send = np.arange(0, 5000, 3, dtype=np.int32)
     pl.set_halo(send, np.empty(0, np.int32))
     pl.exchange_allgather(comm, [send.size])
-    pl.exchange_neighbors(comm, 0, 0)
     with pytest.raises(Exception):
         pl.exchange_allgather(comm, [send.size + 1])          # counts must match the planet's lists
+    with pytest.raises(Exception):
+        pl.exchange_neighbors(comm, 0, 0)                     # a one-rank chain has nobody to send these to
+    pl.set_halo(np.empty(0, np.int32), np.empty(0, np.int32))
+    pl.exchange_neighbors(comm, 0, 0)
     assert np.array_equal(pl.download(), before)
     comm.close()
     pl.close()
