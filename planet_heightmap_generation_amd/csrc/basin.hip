@@ -409,6 +409,94 @@ __global__ __launch_bounds__(64, 4) void k_solve_stream(Fields F, int32_t L, con
     if (storePrev) F.out[S + ((E - S - 1) / 64) * 64 + lane] = oPrev;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Cooperative streaming form: NW waves per range.  A launch of k_solve_stream lasts as long as its longest range — one wave
+// walking the biggest component alone, 100-330 chunks at ~2.4 us — while the chip is empty.  Here a workgroup of NW waves
+// walks the range in super-chunks of 64 x NW tasks: every lane takes one task and polls the granules of its predecessors
+// that lie in the workgroup's LDS ring (the current super-chunk included) until they carry the slot it waits for; the
+// lowest open slot of a super-chunk always finds its predecessors done, so the polling ends.  One barrier per super-chunk
+// keeps the waves together (ring entries are reused RING slots later).  Loads are pipelined as in k_solve_stream.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 6) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
+                                                            int32_t* patchPending, int32_t* totalPending) {
+    constexpr int SC = 64 * NW;                        // tasks per super-chunk
+    constexpr int RING = 1024;                         // tasks whose granules the workgroup keeps in LDS
+    __shared__ unsigned long long s_ring[2 * RING];
+    const int tid = threadIdx.x;
+    const int32_t S = rangeStart[blockIdx.x];
+    if (S == WO_RANGE_NONE) return;
+    int32_t E = L;
+    for (int32_t j = blockIdx.x + 1; j < nRanges; ++j) { const int32_t v = rangeStart[j]; if (v != WO_RANGE_NONE) { E = v; break; } }
+    const unsigned long long* G = reinterpret_cast<const unsigned long long*>(F.out);
+    // LDS keeps what the last workgroup left: last pass's launch wrote the very tags this one waits for.  Clear the ring first.
+    for (int i = tid; i < 2 * RING; i += SC) s_ring[i] = 0;
+    __syncthreads();
+    // ring word = {value, tag}: tag = slot + 1 once the granule is there, -(slot + 1) when its task is blocked; anything else: not yet
+    auto ring_put = [&](int32_t word, float v, int32_t tag) {
+        __hip_atomic_store(&s_ring[word], (unsigned long long)__float_as_uint(v) | ((unsigned long long)(uint32_t)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto record = [&](int32_t q) { return F.task[q < L ? q : L - 1]; };
+    auto far_index = [&](int32_t g, int32_t cbase) { const int32_t sq = g >> 1; return (g >= 0 && (sq < S || sq < cbase - (RING - SC))) ? g : 0; };
+    SolveTask T1 = record(S + tid), T2 = record(S + SC + tid);
+    unsigned long long a0 = G[far_index(T1.predSelf, S)], a1 = G[far_index(T1.predT, S)], a2 = G[far_index(T1.predT2, S)];
+    SolveOut oPrev; oPrev.self.v = 0; oPrev.self.tag = 0; oPrev.dep.v = 0; oPrev.dep.tag = 0;
+    bool storePrev = false;
+    for (int32_t base = S; base < E; base += SC) {
+        const int32_t q = base + tid;
+        const bool mine = q < E;
+        if (storePrev) F.out[q - SC] = oPrev;                          // a super-chunk late (see k_solve_stream)
+        const SolveTask T = T1;
+        T1 = T2;
+        T2 = record(base + 2 * SC + tid);
+        const unsigned long long n0 = G[far_index(T1.predSelf, base + SC)], n1 = G[far_index(T1.predT, base + SC)], n2 = G[far_index(T1.predT2, base + SC)];
+        double er = T.e0r, et = T.e0t, et2 = T.e0t2;
+        bool blocked = false;
+        int32_t r0 = -1, r1 = -1, r2 = -1, x0 = 0, x1 = 0, x2 = 0;     // ring word and expected tag of the predecessors that come through the ring
+        if (mine) {
+            auto classify = [&](int32_t g, unsigned long long far, double& v, int32_t& rw, int32_t& expect) {
+                if (g < 0) return;
+                const int32_t sq = g >> 1;
+                if (sq >= q) { blocked = true; return; }                                         // not in processing order: the layout is off
+                if (sq >= S && sq >= base - (RING - SC)) { rw = g & (2 * RING - 1); expect = sq + 1; return; }
+                const int32_t tag = (int32_t)(far >> 32);
+                const bool own = sq >= S;                                                        // written by this workgroup, long ago
+                if (tag <= 0 || (!own && tag >= launchTag)) { blocked = true; return; }
+                v = __uint_as_float((uint32_t)far);
+            };
+            classify(T.predSelf, a0, er, r0, x0); classify(T.predT, a1, et, r1, x1); classify(T.predT2, a2, et2, r2, x2);
+        }
+        const SolvePrepared pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
+        const int32_t myWord = (2 * q) & (2 * RING - 1);
+        bool open = mine;
+        SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
+        if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
+        while (__any(open)) {
+            if (open) {
+                auto poll = [&](int32_t& rw, int32_t expect, double& v) {
+                    if (rw < 0) return;
+                    const unsigned long long w = __hip_atomic_load(&s_ring[rw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int32_t tag = (int32_t)(w >> 32);
+                    if (tag == expect) { v = __uint_as_float((uint32_t)w); rw = -1; }
+                    else if (tag == -expect) { blocked = true; }
+                };
+                poll(r0, x0, er); poll(r1, x1, et); poll(r2, x2, et2);
+                if (blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
+                else if (r0 < 0 && r1 < 0 && r2 < 0) {
+                    o = solve_apply(T, pre, er, et, et2, launchTag);
+                    ring_put(myWord, o.self.v, q + 1); ring_put(myWord + 1, o.dep.v, q + 1);
+                    open = false;
+                }
+            }
+        }
+        oPrev = o; storePrev = mine && !blocked;
+        if (mine && blocked) { atomicAdd(&patchPending[q / WO_PATCH], 1); atomicAdd(totalPending, 1); }
+        a0 = n0; a1 = n1; a2 = n2;
+        __syncthreads();
+    }
+    if (storePrev) F.out[S + ((E - S - 1) / SC) * SC + tid] = oPrev;
+}
+
 }  // namespace
 
 // slots per workgroup range (a range = the groups that start in one stretch of this many slots)
@@ -464,7 +552,10 @@ void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_
     if (statsAt >= 0 && p->basinLaunches == statsAt) { WO_HIP(hipMalloc((void**)&dbg, 16 * 8)); WO_HIP(hipMemsetAsync(dbg, 0, 16 * 8, p->ctx->stream)); WO_HIP(hipMemsetAsync(dbg + 13, 0xff, 8, p->ctx->stream)); }
     ++p->basinLaunches;
     static const bool stream = !(getenv("WO_BASIN_KERNEL") && std::string(getenv("WO_BASIN_KERNEL")) == "window");
-    if (stream) launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    static const int coopWaves = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
+    if (stream && coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    else if (stream && coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    else if (stream) launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
     else if (window >= 1024) launch(p, FAM_SOLVE_BASIN, k_solve_basin<1024>, nRanges, 1024, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, dbg);
     else if (window >= 512) launch(p, FAM_SOLVE_BASIN, k_solve_basin<512>, nRanges, 512, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, dbg);
     else launch(p, FAM_SOLVE_BASIN, k_solve_basin<256>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, dbg);
