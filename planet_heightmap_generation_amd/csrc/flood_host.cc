@@ -915,7 +915,12 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                 if (!walked) {
                     // --- pass 1 of landmass k
                     me.contests.clear();
+                    const auto tw0 = std::chrono::steady_clock::now();
                     walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
+                    // (measured and dropped in round 3: a bucket queue — 2^16 buckets of width 2^-14 behind a two-level bitmap — instead of the
+                    // binary heap for the walks, which do not depend on the order of equal keys: 83-130 ms against 45-60 ms for this landmass in
+                    // the build container; the heap of one landmass stays in cache, the buckets' vectors do not)
+                    if (T.on && q == 0) std::fprintf(stderr, "[flood] walk of the largest landmass (%d cells): %.1f ms\n", S.compSize[k], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
                     const size_t alt0 = me.alt.size();
                     for (const Contest& ct : me.contests) {
                         ++me.contested;
