@@ -10,12 +10,15 @@ priority-flood calls per step run on the host by design and are insi
 
   value = numRegions * 200 iterations * steps * n_gpus / wall / 1e6          [Mcells·iter/s, whole job]
 
-N > 1, default (--mode decomposed): one process per GPU, ONE planet (seed 1) eroded by all of them — landmass
-decomposition (planet_heightmap_generation_amd/decomposed.py: every rank erodes the full mesh with the other ranks'
-landmasses masked as ocean; one all-gather of the land elevations per step over RCCL; bit-identical to the
-unpartitioned run) -> value = cells x 200 x steps / wall of that one planet, "scaling": "strong".
---mode ensemble: one independent planet per rank with seed = 1 + rank (BASELINE config 5; no data-path collective)
--> "scaling": "weak".
+N > 1, default (--mode ensemble = BASELINE config 5): one process per GPU, one independent planet per rank with seed = 1 + rank,
+no collective on the data path (only the barriers and the MAX of the wall time) -> value = cells x 200 x steps x N / wall,
+"scaling": "weak".  The erosion stack's units of work are whole planets; a production job (64 seeds) shards them like this.
+--mode decomposed: ONE planet (seed 1) eroded by all ranks — landmass decomposition (planet_heightmap_generation_amd/
+decomposed.py: every rank erodes the full mesh with the other ranks' landmasses masked as ocean; one all-gather of the land
+elevations per step over RCCL, behind the C ABI: wo_planet_exchange_allgather; bit-identical to the unpartitioned run at
+10 M cells) -> value = cells x 200 x steps / wall of that one planet, "scaling": "strong".  Exact mode does not scale well
+this way (the largest landmass and the fixed per-iteration costs bound a share; projected 1.6x at 8 GPUs),
+which is why it is not the default.
 N = 1 with --mode decomposed [--shares S]: the partitioned code path on ONE GPU — the planet is split into S landmass shares
 (the plan an S-GPU run would use), the shares are eroded one after the other with the same masks, merged, and checked against
 the oracle's CRC; the line reports the time of every share (what each of S GPUs would spend) next to the sequential total.
@@ -51,9 +54,8 @@ PASSES = {
     "thermal":   {"budget": (106.0, 4.0), "kernels": {"thermal_excess": (45.0, 0.0), "thermal_apply": (61.0, 4.0)}},
 }
 assert sum(v["budget"][0] for v in PASSES.values()) == 243.0 and sum(v["budget"][1] for v in PASSES.values()) == 12.0
-for _p in PASSES.values():
-    assert (sum(k[0] for k in _p["kernels"].values() if k) - sum(_p["kernels"][k][0] for k in ("solve_patch", "solve_round") if k in _p["kernels"]),
-            max(k[1] for k in _p["kernels"].values())) == _p["budget"], _p      # (solve_basin / solve_patch / solve_round are alternatives: one of them runs)
+for _p in PASSES.values():      # (solve_basin / solve_patch / solve_round are alternatives: one of them runs in a pass)
+    assert (sum(v[0] for k, v in _p["kernels"].items() if k not in ("solve_patch", "solve_round")), max(v[1] for v in _p["kernels"].values())) == _p["budget"], _p
 # one-off stages and the glacial iterations: bytes per launch of the whole stage
 ONE_OFF = {"soil_creep": (82.0 * 0.8, 4.0), "warp_terrain": (0.0, 20.0 + 100.0 * 24)}      # creep: 82 B per interior-land cell; warp: ~20 + 100 x hops B/cell, ~24 hops at 10M
 GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend")
@@ -443,7 +445,7 @@ def main():
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo + --share-gpu: rehearse the multi-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0")
     ap.add_argument("--mode", choices=("auto", "decomposed", "ensemble"), default="auto",
-                    help="N > 1: 'decomposed' = one planet over all GPUs by landmass (strong scaling, default), 'ensemble' = one planet per GPU (weak); "
+                    help="N > 1: 'ensemble' = one planet per GPU (weak scaling, BASELINE config 5, default), 'decomposed' = one planet over all GPUs by landmass (strong); "
                          "N = 1 with 'decomposed': the partitioned code path, --shares landmass shares one after the other")
     ap.add_argument("--shares", type=int, default=8, help="N = 1, --mode decomposed: number of landmass shares")
     args = ap.parse_args()
@@ -458,11 +460,22 @@ def main():
     torch.cuda.set_device(local_rank)
     numa_node = bind_to_gpu_numa_node(local_rank)
 
+    if world > 1:
+        # several ranks share the host: the flood's workers (24 by default) and the mesh builder's threads (64) are scaled to this
+        # rank's share of the cores it is pinned to (8 ranks x 24 flood workers + 8 x 64 builder threads would oversubscribe a node)
+        try:
+            mine = len(os.sched_getaffinity(0))
+            nodes = max(1, len(list(Path("/sys/devices/system/node").glob("node[0-9]*")))) if numa_node is not None else 1
+            per_rank = max(4, mine * nodes // world)
+            os.environ.setdefault("WO_FLOOD_THREADS", str(min(24, per_rank)))
+            os.environ.setdefault("WO_HOST_THREADS", str(min(64, per_rank)))
+        except Exception:
+            pass
     from planet_heightmap_generation_amd import terrain_post as TP
     params = dict(PARAMS)
     if args.iters != 200:
         params.update(hIters=args.iters, tIters=args.iters, gIters=min(10, max(1, args.iters // 20)))
-    decomposed_mode = world > 1 and args.mode in ("auto", "decomposed")
+    decomposed_mode = world > 1 and args.mode == "decomposed"
     seed = 1 if decomposed_mode else seed_for_rank(rank)
     mesh, xyz, nd, t_mesh = build_inputs(args.cells, seed)
     pl = TP.Planet(mesh, xyz, nd, device=local_rank)
