@@ -78,6 +78,7 @@ constexpr int WO_CARVE_DEPS = 24;       // dependency slots per active carve tas
 struct Fields {
     int32_t N;                 // numRegions
     int32_t xcdTile;           // blocks per XCD tile for index-order kernels (device.h: xcd_tile)
+    int32_t tileLds;           // 1: the index-order passes over land stage their tile's neighbour window in LDS (kernels_impl.h: stage_tile; WO_TILE_LDS=1)
     const int32_t* off;        // adjOffset [N+1]
     const int32_t* adj;        // adjList   [E]
     const float* dist;         // neighborDist [E]
@@ -298,9 +299,11 @@ WO_HD inline float warp_blend(float origF, float warpedF, double warpBias, bool 
 // ------------------------------------------------------------------------------------------------
 // Hydraulic: receivers (js/terrain-post.js:566-601)
 // ------------------------------------------------------------------------------------------------
-WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) {
+// elev(c): the elevation of cell c — F.e[c], or the workgroup's LDS copy of its tile's neighbourhood (kernels_impl.h: TileWindow)
+template <class Elev>
+WO_HD inline int32_t receiver_cell_t(const Fields& F, int32_t r, Elev elev) {
     if (F.ocean[r]) { F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z; return -1; }
-    const double h = F.e[r];
+    const double h = elev(r);
     int32_t bestNb = -1, bestJ = -1;
     double bestDrop = -INFINITY;
     int32_t b, nbs[WO_ROW];
@@ -309,7 +312,7 @@ WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) {
     if (deg <= WO_ROW) {
         float eh[WO_ROW];
 #pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) eh[k] = F.e[nbs[k]];
+        for (int k = 0; k < WO_ROW; ++k) eh[k] = elev(nbs[k]);
 #pragma unroll
         for (int k = 0; k < WO_ROW; ++k) {
             const double drop = h - (double)eh[k];
@@ -326,14 +329,14 @@ WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) {
     } else {
         for (int32_t j = b; j < en; ++j) {
             const int32_t nb = F.adj[j];
-            const double drop = h - (double)F.e[nb];
+            const double drop = h - (double)elev(nb);
             if (drop > bestDrop) { bestDrop = drop; bestNb = nb; bestJ = j; }
         }
         if (bestDrop <= 0) {
             double minAscent = INFINITY;
             for (int32_t j = b; j < en; ++j) {
                 const int32_t nb = F.adj[j];
-                const double ascent = (double)F.e[nb] - h;
+                const double ascent = (double)elev(nb) - h;
                 if (ascent < minAscent) { minAscent = ascent; bestNb = nb; bestJ = j; }
             }
         }
@@ -343,6 +346,8 @@ WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) {
     if (bestNb >= 0) { const float d = F.dist[bestJ]; F.cellDist[r] = (d == 0.0f || d != d) ? (float)1e-6 : d; }
     return bestNb;
 }
+
+WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) { return receiver_cell_t(F, r, [&](int32_t c) { return F.e[c]; }); }
 
 // Flow (js/terrain-post.js:604-611).  fwd edge: receiver is land and ranked after the donor.
 WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
@@ -726,16 +731,18 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
 // nothing because its totalExcess is 0 — exactly the effect of the reference's `if (r_isOcean[nb]) continue`.
 WO_HD inline float masked_elev_cell(const Fields& F, int32_t r) { return F.ocean[r] ? INFINITY : F.e[r]; }
 
-WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) {
+// masked(c): F.me[c], or the workgroup's LDS copy of it (kernels_impl.h: TileWindow)
+template <class Masked>
+WO_HD inline void thermal_excess_cell_t(const Fields& F, int32_t r, double talus, Masked masked) {
     double total = 0;
     if (!F.ocean[r]) {
-        const double h = F.e[r];
+        const double h = masked(r);                            // a land cell's masked height is its height
         int32_t b, nbs[WO_ROW];
         const int deg = load_row(F, r, b, nbs);
         if (deg <= WO_ROW) {
             float mh[WO_ROW], dd[WO_ROW];
 #pragma unroll
-            for (int k = 0; k < WO_ROW; ++k) mh[k] = F.me[nbs[k]];
+            for (int k = 0; k < WO_ROW; ++k) mh[k] = masked(nbs[k]);
             load_row_dist(F, b, deg, dd);
 #pragma unroll
             for (int k = 0; k < WO_ROW; ++k) {
@@ -747,7 +754,7 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
             }
         } else {
             for (int32_t j = b; j < b + deg; ++j) {
-                const double nh = F.me[F.adj[j]];
+                const double nh = masked(F.adj[j]);
                 if (nh >= h) continue;
                 const double d = nd_or_eps(F.dist[j]);
                 const double slope = (h - nh) / d;
@@ -758,19 +765,22 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
     F.totalExcess[r] = total;
 }
 
+WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) { thermal_excess_cell_t(F, r, talus, [&](int32_t c) { return F.me[c]; }); }
+
 // New height of cell c (reads F.e, the pre-thermal field).  inShare / inRank are caller-provided scratch for the
 // <= degree incoming events, element k at [k * stride] (LDS columns on the device: a per-thread array indexed at
 // run time would live in scratch memory and tripled this kernel's HBM traffic).
 // thermal_apply_cell for rows of at most WO_ROW neighbours (99.9 % of the cells), with every per-neighbour quantity in a
 // statically indexed slot: the replay of the serial loop's additions (senders in ascending rank, c's own sends at c's turn
 // in adjacency order) selects by scanning the 8 slots instead of indexing a list, so nothing lives in scratch memory.
+template <class Masked>
 WO_HD inline float thermal_apply_row(const Fields& F, double h, int32_t myRank, double myTotal, int32_t b, const int32_t (&nbs)[WO_ROW], int deg,
-                                     double talus, double kThermal) {
+                                     double talus, double kThermal, Masked masked) {
     const double myTransfer = kThermal * myTotal * 0.5;
     float mh[WO_ROW], dd[WO_ROW];
     double tx[WO_ROW]; int32_t rk[WO_ROW]; bool snd[WO_ROW];
 #pragma unroll
-    for (int k = 0; k < WO_ROW; ++k) mh[k] = F.me[nbs[k]];
+    for (int k = 0; k < WO_ROW; ++k) mh[k] = masked(nbs[k]);
     load_row_dist(F, b, deg, dd);
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) {
@@ -826,8 +836,9 @@ WO_HD inline float thermal_apply_row(const Fields& F, double h, int32_t myRank, 
     return (float)(h + (double)delta);
 }
 
-WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, double kThermal, double* inShare, int32_t* inRank, int stride,
-                                      double* outShare = nullptr) {
+template <class Masked>
+WO_HD inline float thermal_apply_cell_t(const Fields& F, int32_t c, double talus, double kThermal, double* inShare, int32_t* inRank, int stride,
+                                        double* outShare, Masked masked) {
     if (F.ocean[c]) return F.e[c];
     const double h = F.e[c];
     const int32_t myRank = F.rank[c];
@@ -836,7 +847,7 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
     int nIn = 0, nOut = 0; bool hasOut = false;
     int32_t b, nbs[WO_ROW];
     const int deg = load_row(F, c, b, nbs);
-    if (deg <= WO_ROW) return thermal_apply_row(F, h, myRank, myTotal, b, nbs, deg, talus, kThermal);
+    if (deg <= WO_ROW) return thermal_apply_row(F, h, myRank, myTotal, b, nbs, deg, talus, kThermal, masked);
     {
         for (int32_t j = b; j < b + deg; ++j) {
             const int32_t nb = F.adj[j];
@@ -890,6 +901,11 @@ WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, 
         }
     }
     return (float)(h + (double)delta);
+}
+
+WO_HD inline float thermal_apply_cell(const Fields& F, int32_t c, double talus, double kThermal, double* inShare, int32_t* inRank, int stride,
+                                      double* outShare = nullptr) {
+    return thermal_apply_cell_t(F, c, talus, kThermal, inShare, inRank, stride, outShare, [&](int32_t x) { return F.me[x]; });
 }
 
 // ------------------------------------------------------------------------------------------------

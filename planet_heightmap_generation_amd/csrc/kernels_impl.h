@@ -184,9 +184,45 @@ __global__ __launch_bounds__(WO_BLOCK) void k_erode_ocean_init(Fields F) {
         F.accA[r] = 0; F.jumpA[r] = -1; F.flow[r] = 0.0f; F.totalExcess[r] = 0.0; F.me[r] = INFINITY;
     }
 }
+// ---- neighbour cells staged into LDS ----
+// Under the patch-major mirror the land list is in Morton order of all cells: the 256 land cells of a workgroup span ~1 500
+// consecutive cell ids, and 94 % of their neighbours lie inside that span widened by 256 ids on either side (measured on the
+// 10 M-cell bench planet: 87 % with no margin, 97 % with 1 024).  So the workgroup copies that stretch of the field into LDS with
+// coalesced loads (~8 KB) and the ~1 800 neighbour gathers of the tile become LDS reads; the few neighbours outside take the
+// global load.  A tile whose span does not fit (index layout, WO_LAYOUT=index: neighbours are +-15 000 ids away) is not staged.
+// MEASURED (10 M cells, profiles/r03q_*): no gain — receivers 98 -> 100 us per launch, thermal_excess 82 -> 86, thermal_apply 160 -> 181:
+// under the mirror those gathers already hit the vector cache, and the passes wait on their chain of dependent loads (offsets ->
+// row -> values) and, for thermal_apply, on f64 arithmetic, not on the gathers; the staging adds a barrier and ~8 KB of loads per
+// workgroup.  Off by default (Fields::tileLds, WO_TILE_LDS=1 switches it on; results identical either way).
+constexpr int WO_TILE_WIN = 4096;                // floats of LDS per workgroup
+constexpr int WO_TILE_MARGIN = 256;
+struct TileWindow {
+    const float* g; const float* s; int32_t lo, hi;      // s[k] = g[lo + k] for lo <= lo + k <= hi; empty: hi < lo
+    __device__ inline float operator()(int32_t c) const { return (c >= lo && c <= hi) ? s[c - lo] : g[c]; }
+};
+// all threads of the workgroup call this (barrier inside); i0 = the workgroup's first index into the land list
+__device__ inline TileWindow stage_tile(const Fields& F, const float* field, float* s_buf, int32_t i0) {
+    TileWindow W; W.g = field; W.s = s_buf; W.lo = 1; W.hi = 0;
+    if (!F.tileLds) return W;                                     // block-uniform
+    if (i0 < F.L) {
+        const int32_t i1 = min(i0 + (int32_t)blockDim.x, F.L) - 1;
+        const int32_t lo = max(F.landIdx[i0] - WO_TILE_MARGIN, 0), hi = min(F.landIdx[i1] + WO_TILE_MARGIN, F.N - 1);
+        if (hi - lo + 1 <= WO_TILE_WIN) {
+            for (int32_t k = threadIdx.x; k <= hi - lo; k += blockDim.x) s_buf[k] = field[lo + k];
+            W.lo = lo; W.hi = hi;
+        }
+    }
+    __syncthreads();
+    return W;
+}
+// the workgroup's first index into the land list under WO_XCD_LAND's block-to-tile mapping
+#define WO_XCD_LAND_BASE() ((int32_t)(((((int32_t)(blockIdx.x >> 3) / F.xcdTileL) * 8 + (int32_t)(blockIdx.x & 7u)) * F.xcdTileL + ((int32_t)(blockIdx.x >> 3) % F.xcdTileL)) * (int32_t)blockDim.x))
+
 __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int32_t* donorCnt) {
+    __shared__ float s_tile[WO_TILE_WIN];
+    const TileWindow E = stage_tile(F, F.e, s_tile, WO_XCD_LAND_BASE());
     WO_XCD_LAND(i, r) {
-        const int32_t t = receiver_cell(F, r);
+        const int32_t t = receiver_cell_t(F, r, E);
         int32_t j = -1; const uint32_t a = 1;
         if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
         F.accA[r] = a; F.jumpA[r] = j; F.accCnt[r] = 1ull;
@@ -611,15 +647,21 @@ __global__ __launch_bounds__(WO_BLOCK) void k_fill_i32(int32_t* a, int32_t v, in
 
 // ---------------------------------------------------------------- thermal -----------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_masked_elev(Fields F) { WO_XCD_LAND(i, r) F.me[r] = F.e[r]; }
-__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) { WO_XCD_LAND(i, r) thermal_excess_cell(F, r, talus); }
+__global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double talus) {
+    __shared__ float s_tile[WO_TILE_WIN];
+    const TileWindow M = stage_tile(F, F.me, s_tile, WO_XCD_LAND_BASE());
+    WO_XCD_LAND(i, r) thermal_excess_cell_t(F, r, talus, M);
+}
 // meshes whose largest degree is <= 16 (jittered Fibonacci spheres: 10-11 at 10^4..10^6 cells, 13 at 10^7) keep the event
 // lists in registers (12- or 16-entry private arrays are promoted to VGPRs: 103 / 115 VGPRs, no scratch); larger degrees
 // use the LDS form
 template <int MAXIN>
 __global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply_reg(Fields F, float* out, double talus, double kThermal) {
+    __shared__ float s_tile[WO_TILE_WIN];
+    const TileWindow M = stage_tile(F, F.me, s_tile, WO_XCD_LAND_BASE());
     WO_XCD_LAND(i, r) {
         double inShare[MAXIN], outShare[MAXIN]; int32_t inRank[MAXIN];
-        out[r] = thermal_apply_cell(F, r, talus, kThermal, inShare, inRank, 1, outShare);
+        out[r] = thermal_apply_cell_t(F, r, talus, kThermal, inShare, inRank, 1, outShare, M);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out, double talus, double kThermal, int32_t maxDeg) {

@@ -77,7 +77,8 @@ static void ensure_scratch(wo_planet* p) {
 
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
-    F.N = N; F.xcdTile = wo::xcd_tile(N); F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
+    static const int tileLds = (getenv("WO_TILE_LDS") && atoi(getenv("WO_TILE_LDS")) != 0) ? 1 : 0;
+    F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = tileLds; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = (getenv("WO_NO_EVENT_LISTS") == nullptr) ? d_ev : nullptr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
