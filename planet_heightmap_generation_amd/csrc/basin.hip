@@ -18,10 +18,11 @@
 //   2. a stable radix sort of the land list, taken in PROCESSING order (descending rank), by key: group-major, each
 //      group in processing order — a topological order of the group's dependency DAG.  The position in that list is
 //      the task's store index for this pass (Fields::slotOf).
-//   3. k_solve_setup as before (records at the store index), then ONE launch of k_solve_basin: workgroup k owns the
-//      groups that start in [k*T, (k+1)*T) and walks them in windows of WO_PATCH slots; inside a window the chains run
-//      through LDS granules exactly like a visit of k_solve_patch, across windows through the workgroup's own earlier
-//      writes.  No polling cap, no settle step, no external granules.
+//   3. k_solve_setup as before (records at the store index), then ONE launch: workgroup k owns the groups that start in
+//      [k*T, (k+1)*T) and walks them front to back (k_solve_coop / k_solve_stream below).  No polling cap, no settle step,
+//      no external granules.  (Round 3 also built and measured a windowed form — 1 024-slot windows, tasks counting-sorted by
+//      dependency level in LDS, one barrier per level: 440-515 us per launch against 335 here, the workgroup holds its CU
+//      for ~40 barrier-separated levels doing almost nothing; dropped, DESIGN.md section 5 and profiles/r03c..r03g.)
 // The schedule is only a schedule: tasks are single-assignment, so any dependency-respecting order gives the same bits,
 // and a task whose predecessor is NOT where the layout promised (a cycle longer than two cells that the jumping gave
 // up on) simply stays pending and is finished by k_solve_patch launches over the same store order (planet.hip).
@@ -112,198 +113,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_slots(const int32_t* __restr
     }
 }
 constexpr int32_t WO_RANGE_NONE = 0x7f7f7f7f;
-
-// One window = W consecutive store slots of the workgroup's range, one thread per slot.  Every task of a window is runnable
-// (its predecessors are in the window or in an earlier window of the same workgroup), so the question is only in which
-// order the threads take them.  One task per thread with every thread polling its predecessors (the first form of this
-// kernel, 420 us per launch at 10 M cells) spends its time in divergence: the tasks of a wave sit at ~20 different depths of
-// the window's dependency DAG, so the wave runs the expensive part of a turn (three f64 divisions) ~20 times with a few
-// lanes each, and eight such waves share a SIMD.  So a window is run in two steps:
-//   1. levels.  level(task) = 1 + max level of its in-window predecessors, by polling 4-byte words in LDS (integer work
-//      only); the tasks are counting-sorted by level (one LDS atomic per wave and level) and thread i takes the i-th task
-//      of that order: its record goes through LDS, external predecessor values already filled in.
-//   2. turns, level by level with a workgroup barrier in between.  The tasks of a level are neighbours in the thread
-//      order, so a level costs one execution of the turn on the waves that hold it (the shallow levels hold hundreds of
-//      tasks, the deep ones a handful) and nobody polls.  The results go to global memory after the loop (a store inside
-//      it would make every barrier wait for the write to land).
-constexpr int32_t WO_LEV_BLOCKED = -1;
-struct alignas(8) BasinRec { double factor; float er, et, et2, cellDistT; int16_t w0, w1, w2, t; int16_t lev; uint16_t flags; int32_t pad; };
-static_assert(sizeof(BasinRec) == 40, "40-byte hand-over record");
-
-template <int W>
-__global__ __launch_bounds__(W, 8) void k_solve_basin(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
-                                                                         int32_t* patchPending, int32_t* totalPending, unsigned long long* dbg) {
-    __shared__ unsigned long long s_out[2 * W];
-    __shared__ BasinRec s_rec[W];
-    __shared__ int32_t s_lev[W];
-    __shared__ int32_t s_cnt[W + 2];                   // tasks per level, then first thread of each level
-    __shared__ int32_t s_wsum[W / 64];
-    __shared__ int32_t s_maxLev, s_blocked;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // dbg (diagnostic, may be null): shader clocks of thread 0 per phase, summed over the workgroups: [1] records + levels,
-    // [2] counting sort + hand-over, [4] turns, [5] store; [6] windows, [7] levels summed, [8] runnable tasks
-    long long tc = dbg ? clock64() : 0;
-    auto lap = [&](int k) { if (dbg && tid == 0) { const long long now = clock64(); atomicAdd(&dbg[k], (unsigned long long)(now - tc)); tc = now; } };
-    const int32_t S = rangeStart[blockIdx.x];
-    if (S == WO_RANGE_NONE) return;                                 // no group starts in this stretch
-    const long long tStart = dbg ? clock64() : 0;
-    const unsigned long long wStart = dbg ? wall_clock64() : 0;
-    int32_t nWin = 0;
-    int32_t E = L;
-    for (int32_t j = blockIdx.x + 1; j < nRanges; ++j) { const int32_t v = rangeStart[j]; if (v != WO_RANGE_NONE) { E = v; break; } }
-    const Granule* G = reinterpret_cast<const Granule*>(F.out);
-    volatile unsigned long long* vs = s_out;
-    volatile int32_t* vlev = s_lev;
-    auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
-    for (int32_t base = S; base < E; base += W) {
-        const int32_t wHi = E < base + W ? E : base + W;
-        const bool mine = base + tid < wHi;
-        // granule -> its word in s_out, -1 when the producer is not in this window
-        auto word_of = [&](int32_t g) { const int32_t sq = g >> 1; return (g >= 0 && sq >= base && sq < wHi) ? g - 2 * base : -1; };
-        // ---- 1. record, external predecessors, level
-        SolveTask T;
-        double er = 0, et = 0, et2 = 0;
-        int32_t myLev = 0, w0 = -1, w1 = -1, w2 = -1;
-        if (mine) {
-            T = F.task[base + tid];
-            er = T.e0r; et = T.e0t; et2 = T.e0t2;
-            w0 = word_of(T.predSelf); w1 = word_of(T.predT); w2 = word_of(T.predT2);
-            // a predecessor outside the window: an earlier window of this workgroup (there by now, whatever its tag) or — only
-            // when the layout is off — somebody else's task, which counts when an earlier launch produced it
-            bool blocked = false;
-            auto ext = [&](int32_t g, int32_t w, double& v) {
-                if (g < 0 || w >= 0) return;
-                const Granule gq = G[g];
-                const int32_t sq = g >> 1;
-                const bool own = sq >= S && sq < base;
-                if (gq.tag == 0 || (!own && gq.tag >= launchTag)) { blocked = true; return; }
-                v = gq.v;
-            };
-            ext(T.predSelf, w0, er); ext(T.predT, w1, et); ext(T.predT2, w2, et2);
-            myLev = blocked ? WO_LEV_BLOCKED : ((w0 < 0 && w1 < 0 && w2 < 0) ? 1 : 0);          // 0: not known yet
-        }
-        s_lev[tid] = myLev;
-        s_cnt[tid] = 0;
-        if (tid == 0) { s_cnt[W] = 0; s_cnt[W + 1] = 0; s_maxLev = 0; s_blocked = 0; }
-        __syncthreads();
-        while (__any(mine && myLev == 0)) {
-            if (mine && myLev == 0) {
-                // a level word is 0 until known; an absent predecessor counts as known, level 0
-                const int32_t a = w0 >= 0 ? vlev[w0 >> 1] : 0x40000000, b = w1 >= 0 ? vlev[w1 >> 1] : 0x40000000, c = w2 >= 0 ? vlev[w2 >> 1] : 0x40000000;
-                if (a < 0 || b < 0 || c < 0) myLev = WO_LEV_BLOCKED;
-                else if (a > 0 && b > 0 && c > 0) {
-                    const int32_t x = a & 0x3fffffff, y = b & 0x3fffffff, z = c & 0x3fffffff;
-                    const int32_t m = x > y ? x : y;
-                    myLev = 1 + (m > z ? m : z);
-                }
-                if (myLev != 0) vlev[tid] = myLev;
-            }
-        }
-        lap(1);
-        // ---- counting sort by level: one LDS atomic per wave and level (half of a window sits on level 1: one atomic per task
-        // was 25 k clocks of serialised adds on a few words)
-        const bool runnable = mine && myLev > 0;
-        int32_t inLevel = 0;                                         // my index among the wave's tasks of my level
-        {
-            unsigned long long todo = __ballot(runnable);
-            while (todo) {
-                const int32_t l = __shfl(myLev, (int)__builtin_ctzll(todo));
-                const unsigned long long m = __ballot(runnable && myLev == l);
-                if (runnable && myLev == l) inLevel = __popcll(m & ((1ull << lane) - 1ull));
-                if (lane == (int)__builtin_ctzll(m)) atomicAdd(&s_cnt[l], __popcll(m));
-                todo &= ~m;
-            }
-            const unsigned long long bm = __ballot(mine && myLev < 0);
-            if (bm && lane == 0) atomicAdd(&s_blocked, __popcll(bm));
-            int32_t mx = runnable ? myLev : 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { const int32_t v = __shfl_xor(mx, o); mx = v > mx ? v : mx; }
-            if (lane == 0 && mx) atomicMax(&s_maxLev, mx);
-        }
-        __syncthreads();
-        const int32_t maxLev = s_maxLev;
-        {   // exclusive scan of s_cnt[1 .. W] (thread t owns level t + 1)
-            const int32_t c = s_cnt[tid + 1];
-            int32_t incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            if (tid < W / 64) {
-                const int32_t w = s_wsum[tid];
-                int32_t wi = w;
-#pragma unroll
-                for (int o = 1; o < W / 64; o <<= 1) { const int32_t v = __shfl_up(wi, o); if (tid >= o) wi += v; }
-                s_wsum[tid] = wi - w;
-            }
-            __syncthreads();
-            s_cnt[tid + 1] = s_wsum[wave] + incl - c;               // first thread of level tid + 1
-        }
-        vs[2 * tid] = 0; vs[2 * tid + 1] = 0;
-        __syncthreads();
-        {   // positions: the wave's tasks of a level take consecutive threads; s_cnt[l] ends up as the first thread of level l + 1
-            unsigned long long todo = __ballot(runnable);
-            int32_t pos = -1;
-            while (todo) {
-                const int src = (int)__builtin_ctzll(todo);
-                const int32_t l = __shfl(myLev, src);
-                const unsigned long long m = __ballot(runnable && myLev == l);
-                int32_t b0 = 0;
-                if (lane == src) b0 = atomicAdd(&s_cnt[l], __popcll(m));
-                b0 = __shfl(b0, src);
-                if (runnable && myLev == l) pos = b0 + inLevel;
-                todo &= ~m;
-            }
-            if (runnable) {
-                BasinRec R;
-                R.factor = T.factor; R.er = (float)er; R.et = (float)et; R.et2 = (float)et2; R.cellDistT = T.cellDistT;
-                R.w0 = (int16_t)w0; R.w1 = (int16_t)w1; R.w2 = (int16_t)w2; R.t = (int16_t)tid; R.lev = (int16_t)myLev; R.flags = (uint16_t)T.flags; R.pad = 0;
-                s_rec[pos] = R;
-            }
-        }
-        __syncthreads();
-        const int32_t total = maxLev > 0 ? s_cnt[maxLev] : 0;
-        lap(2);
-        if (dbg && tid == 0) { atomicAdd(&dbg[6], 1ull); atomicAdd(&dbg[7], (unsigned long long)maxLev); atomicAdd(&dbg[8], (unsigned long long)total); }
-        // ---- 2. turns
-        SolvePrepared pre;
-        int32_t t = 0, lev = 0;
-        if (tid < total) {
-            const BasinRec R = s_rec[tid];
-            T.factor = R.factor; T.cellDistT = R.cellDistT; T.flags = R.flags;
-            er = R.er; et = R.et; et2 = R.et2; w0 = R.w0; w1 = R.w1; w2 = R.w2; t = R.t; lev = R.lev;
-            pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
-        }
-        SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
-        for (int32_t k = 1; k <= maxLev; ++k) {
-            if (lev == k) {
-                if (w0 >= 0) er = __uint_as_float((uint32_t)vs[w0]);
-                if (w1 >= 0) et = __uint_as_float((uint32_t)vs[w1]);
-                if (w2 >= 0) et2 = __uint_as_float((uint32_t)vs[w2]);
-                o = solve_apply(T, pre, er, et, et2, launchTag);
-                vs[2 * t] = pack(o.self); vs[2 * t + 1] = pack(o.dep);
-            }
-            __syncthreads();
-        }
-        lap(4);
-        if (tid < total) F.out[base + t] = o;
-        if (mine && myLev < 0) { atomicAdd(&patchPending[(base + tid) / WO_PATCH], 1); }
-        if (tid == 0 && s_blocked) atomicAdd(totalPending, s_blocked);
-        __threadfence_block();
-        __syncthreads();
-        lap(5);
-        ++nWin;
-    }
-    // [9] longest workgroup (clocks), [10] most windows of a workgroup, [11] workgroup clocks summed, [12] workgroups that ran,
-    // [13] / [14] first start / last end on the 100 MHz wall clock, [15] windows of the longest workgroup (approximate: last writer)
-    if (dbg && tid == 0) {
-        const unsigned long long d = (unsigned long long)(clock64() - tStart);
-        const unsigned long long old = atomicMax(&dbg[9], d);
-        if (d > old) dbg[15] = (unsigned long long)nWin;
-        atomicMax(&dbg[10], (unsigned long long)nWin); atomicAdd(&dbg[11], d); atomicAdd(&dbg[12], 1ull);
-        atomicMin(&dbg[13], wStart); atomicMax(&dbg[14], wall_clock64());
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Streaming form: ONE WAVE per range, no barrier and no polling.  The store order of a group is its processing order, a
@@ -545,31 +354,12 @@ void basin_layout(wo_planet* p) {
 void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending) {
     const int rangeT = basin_range();
     const int nRanges = (int)(((int64_t)p->L + rangeT - 1) / rangeT);
-    // WO_BASIN_STATS=<n>: per-phase clocks of the n-th basin launch of the planet -> stderr (diagnostic)
-    static const int statsAt = getenv("WO_BASIN_STATS") ? atoi(getenv("WO_BASIN_STATS")) : -1;
-    static const int window = getenv("WO_BASIN_WINDOW") ? atoi(getenv("WO_BASIN_WINDOW")) : 512;
-    unsigned long long* dbg = nullptr;
-    if (statsAt >= 0 && p->basinLaunches == statsAt) { WO_HIP(hipMalloc((void**)&dbg, 16 * 8)); WO_HIP(hipMemsetAsync(dbg, 0, 16 * 8, p->ctx->stream)); WO_HIP(hipMemsetAsync(dbg + 13, 0xff, 8, p->ctx->stream)); }
-    ++p->basinLaunches;
-    static const bool stream = !(getenv("WO_BASIN_KERNEL") && std::string(getenv("WO_BASIN_KERNEL")) == "window");
+    // WO_BASIN_WAVES: waves per range — 4 (default) / 2: k_solve_coop; 1: k_solve_stream
     static const int coopWaves = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
-    if (stream && coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
-    else if (stream && coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
-    else if (stream) launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
-    else if (window >= 1024) launch(p, FAM_SOLVE_BASIN, k_solve_basin<1024>, nRanges, 1024, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, dbg);
-    else if (window >= 512) launch(p, FAM_SOLVE_BASIN, k_solve_basin<512>, nRanges, 512, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, dbg);
-    else launch(p, FAM_SOLVE_BASIN, k_solve_basin<256>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, dbg);
-    if (dbg) {
-        unsigned long long h[16];
-        WO_HIP(hipStreamSynchronize(p->ctx->stream));
-        WO_HIP(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-        WO_HIP(hipFree(dbg));
-        const double nw = std::max<double>(1, (double)h[6]);
-        fprintf(stderr, "basin stats (launch %d): window %d, workgroups %d, windows %llu, levels per window %.1f, runnable tasks %llu of %d; clocks per window: records+levels %.0f sort+handover %.0f turns %.0f store %.0f (total %.0f)\n",
-                statsAt, window, nRanges, h[6], (double)h[7] / nw, h[8], p->L, h[1] / nw, h[2] / nw, h[4] / nw, h[5] / nw, (double)(h[1] + h[2] + h[4] + h[5]) / nw);
-        fprintf(stderr, "basin stats (launch %d): workgroups that ran %llu, clocks summed %.3g, longest workgroup %llu clocks with %llu windows, most windows %llu, kernel span %.1f us (100 MHz wall clock)\n",
-                statsAt, h[12], (double)h[11], h[9], h[15], h[10], (double)(h[14] - h[13]) / 100.0);
-    }
+    ++p->basinLaunches;
+    if (coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    else if (coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    else launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
 }
 
 void basin_free(wo_planet* p) {

@@ -120,8 +120,6 @@ struct wo_planet {
     int32_t *d_iceTarget = nullptr, *d_arank = nullptr;
     uint8_t* d_iceUp = nullptr;
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
-    uint32_t* d_riverA[2] = {nullptr, nullptr}; int32_t* d_riverJ[2] = {nullptr, nullptr}; int32_t* d_riverIdx = nullptr;   // river.hip
-    uint32_t *d_riverRootSize = nullptr, *d_riverRootBase = nullptr; int32_t* d_riverFlag = nullptr; int64_t riverRefreshes = 0;
     hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; bool onSide = false;   // second stream of the planet: the basin layout runs beside the flow accumulation (planet.hip)
     uint32_t* d_basinKey = nullptr; int32_t* d_basinVals[2] = {nullptr, nullptr}; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; int64_t basinLaunches = 0;   // basin.hip: component roots (Morton slot space), group-major store order of the pass
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
@@ -199,9 +197,6 @@ void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
 void rank_from_land(wo_planet* p);
 void sort_by_level(wo_planet* p);
-// river.hip: patch list of the solve ordered along the drainage forest (d_patchOrder / d_slotOf)
-void river_patch_slots(wo_planet* p);
-void river_free(wo_planet* p);
 // basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it
 void basin_layout(wo_planet* p);
 void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending);

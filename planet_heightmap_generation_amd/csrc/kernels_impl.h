@@ -759,50 +759,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const
     const unsigned long long m = __ballot(ran);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(done, __popcll(m));
 }
-// All carve rounds of a glacial step in ONE cooperative launch: the rounds are ~325 dependent steps of a few thousand
-// tasks each, and as separate launches each cost ~37 us (launch + drain) for ~10 us of dependent loads.  Here a grid that
-// is resident as a whole walks the rounds itself, with a grid barrier where the kernel boundary was: same lists, same
-// counters (c[k%3] in, c[(k+1)%3] out, c[(k+2)%3] cleared), same task bodies, hence the same bits.  The barrier's
-// agent-scope fence makes the previous round's stores (lists, e, doneAt) visible to every CU's vector cache.
-// status[0] = rounds run, status[1] = 1 when maxRounds was hit with work left.
-// Barrier across a grid that is resident as a whole (cooperative launch): one agent-scope counter, `gen` barriers passed so
-// far.  (cooperative_groups' grid.sync() measured ~80 us per round with 1024 workgroups; a round's work is ~10 us.)
-__device__ inline void grid_barrier(int32_t* bar, int32_t& gen) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    ++gen;
-    if (threadIdx.x == 0) {
-        const int32_t target = gen * (int32_t)gridDim.x;
-        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-}
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_rounds_persistent(Fields F, int2* listA, int2* listB, int32_t* c, int32_t maxRounds, double gCarve,
-                                                                       double gConv, double gStrength, int32_t* status, int32_t* bar) {
-    int32_t gen = 0;
-    int2* in = listA; int2* out = listB;
-    int32_t k = 1, n = 0;
-    for (; k <= maxRounds; ++k) {
-        n = __hip_atomic_load(c + (k % 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == 0) break;
-        if (blockIdx.x == 0 && threadIdx.x == 0) c[(k + 2) % 3] = 0;
-        int32_t* outCount = c + ((k + 1) % 3);
-        WO_BLOCK_STRIDE(i, valid, n) {
-            bool pending = false; int2 ent = make_int2(-1, -1);
-            if (valid) {
-                ent = in[i];
-                if (ent.y >= 0 && !(F.doneAt[ent.y] < k)) pending = true;             // still parked on the same blocker
-                else if (!carve_task(F, ent.x, k, gCarve, gConv, gStrength)) { pending = true; ent.y = carve_current_blocker(F, ent.x); }
-            }
-            block_append2(pending, ent, out, outCount);
-        }
-        grid_barrier(bar, gen);
-        int2* t = in; in = out; out = t;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { status[0] = k - 1; status[1] = (n != 0) ? 1 : 0; }
-}
 __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDep, double gFjord) {
     WO_XCD_CELLS(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
 }

@@ -673,19 +673,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const double gCarve = 0.02 * gScale, gConv = 0.01 * gScale, gDep = 0.005 * gScale, gFjord = 0.015 * gScale;
     const int32_t midIter = (int32_t)std::floor(total * 0.75 + 0.5);
     bool midDone = false;
-    // WO_RIVER_PATCHES=<n>: rebuild the patch list along the drainage forest every n-th pass.  Default 0 = spatial (Morton)
-    // patches: measured at 10 M cells the river list needs 17 launches per pass instead of 54 when rebuilt every pass, but
-    // its visits hold one long chain each instead of ~40 short ones (77 us per launch against 32), rebuilding costs 1.3 ms,
-    // and a list that is one pass old already needs 28 launches (profiles/r02c_river_patch_experiment.txt).
-    static const int riverEvery = getenv("WO_RIVER_PATCHES") ? atoi(getenv("WO_RIVER_PATCHES")) : 0;
-    int sinceRiver = -1;
+    // (round 2's river-aligned patch lists, WO_RIVER_PATCHES, were measured and dropped: profiles/r02c_river_patch_experiment.txt)
     // WO_BASIN=0: the Morton patches of round 2 (k_solve_patch from the first launch on) instead of the basin-local solve
     static const bool basinSolve = !(getenv("WO_BASIN") && atoi(getenv("WO_BASIN")) == 0);
     int64_t basinPasses = 0, basinLeftoverPasses = 0, carveActive = 0;
     int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
     for (int32_t iter = 0; iter < total; ++iter) {
-        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); sinceRiver = -1; }
+        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
         if (gNow || hNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
 
@@ -723,34 +718,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 if (count > 0) launch(p, FAM_CARVE_SETUP, k_carve_pairs_init, blocks_for(count), WO_BLOCK, (const int32_t*)p->d_listB, (const int32_t*)(c + 1), p->d_carvePairs[0]);
                 int64_t k = 1;
                 int cur = 0;
-                // WO_PERSISTENT_ROUNDS=1: all rounds in one cooperative launch with a grid barrier (k_carve_rounds_persistent).
-                // Measured slower at 10 M cells and therefore off: 168 ms per step at the best grid (128 workgroups; 258 / 188 /
-                // 190 ms with 32 / 64 / 256) against 122 ms for one launch per round — a round is bound by its chain of dependent
-                // loads, which a wide launch overlaps across more workgroups, not by the launch itself
-                // (profiles/r02f_persistent_rounds_grid.txt).
-                static const bool persistentRounds = getenv("WO_PERSISTENT_ROUNDS") != nullptr;
-                if (count > 0 && persistentRounds) {
-                    // one cooperative launch walks every round (k_carve_rounds_persistent); the grid must be resident as a whole
-                    static int perCu = 0;
-                    if (!perCu) { WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_carve_rounds_persistent, WO_BLOCK, 0)); if (perCu < 1) perCu = 1; }
-                    static const int roundGrid = getenv("WO_ROUND_GRID") ? std::max(1, atoi(getenv("WO_ROUND_GRID"))) : 128;
-                    const int grid = std::max(1, std::min(std::min(perCu * p->ctx->prop.multiProcessorCount, roundGrid), blocks_for(count)));
-                    int2* la = p->d_carvePairs[0]; int2* lb = p->d_carvePairs[1];
-                    int32_t maxRounds = (int32_t)std::min<int64_t>(4 * (int64_t)p->N + 1024, 0x7ffffff0);
-                    int32_t* status = c + 4; int32_t* bar = c + 6;
-                    WO_HIP(hipMemsetAsync(bar, 0, sizeof(int32_t), s));
-                    double gc = gCarve, gv = gConv, gs = gStrength;
-                    void* args[] = {(void*)&F, (void*)&la, (void*)&lb, (void*)&c, (void*)&maxRounds, (void*)&gc, (void*)&gv, (void*)&gs, (void*)&status, (void*)&bar};
-                    hipEvent_t ea = nullptr, eb = nullptr;
-                    if (p->profiling) { ea = profile_event(p); eb = profile_event(p); WO_HIP(hipEventRecord(ea, s)); }
-                    WO_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(k_carve_rounds_persistent), dim3(grid), dim3(WO_BLOCK), args, 0, s));
-                    if (p->profiling) { WO_HIP(hipEventRecord(eb, s)); p->pending.push_back({FAM_CARVE_ROUND, ea, eb}); }
-                    WO_HIP(hipMemcpyAsync(p->h_count, status, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-                    WO_HIP(hipStreamSynchronize(s));
-                    if (p->h_count[1] != 0) throw HipError{"carve rounds do not converge"};
-                    k = (int64_t)p->h_count[0] + 1;
-                    count = 0;
-                }
+                // (round 2 also tried all rounds in ONE cooperative launch with a grid barrier: slower, profiles/r02f_persistent_rounds_grid.txt)
                 // default: rounds over the static activation list (k_carve_round_static): every launch covers all active tasks, a
                 // finished one leaves after one load, an open one issues its loads at once; the number of finished tasks is read
                 // back after a burst (first burst: what the previous glacial iteration needed).  WO_CARVE_ROUNDS=lists: the pending
@@ -799,7 +767,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             // The layout needs the receivers only and touches none of the flow accumulation's arrays, and both are chains of
             // latency-bound launches that leave most of the chip idle: the layout runs on the planet's side stream beside the flow
             // accumulation and the solve's setup waits for both (WO_BASIN_OVERLAP=0: one after the other on the main stream).
-            const bool basin = basinSolve && p->patchVersion >= 0 && riverEvery <= 0;
+            const bool basin = basinSolve && p->patchVersion >= 0;
             static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
             if (basin && basinOverlap) {
                 if (!p->side) {
@@ -858,14 +826,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             }
             clk.end();
             clk.begin("solve");
-            // the solve's patch list follows the drainage forest (river.hip); the forest drifts slowly, so the list is
-            // rebuilt every riverEvery-th pass and right after a flood (which re-routes whole basins)
-            if (riverEvery > 0 && p->patchVersion >= 0 && (sinceRiver >= riverEvery || sinceRiver < 0)) {
-                river_patch_slots(p);
-                p->patchVersion = 0;            // not the Morton list any more: the next erodeComposite starts from it again
-                sinceRiver = 0; ++p->riverRefreshes;
-            }
-            ++sinceRiver;
             if (basin) {
                 if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p);
                 F.slotOf = p->d_basinSlot;
@@ -1108,7 +1068,6 @@ void wo_planet_destroy(wo_planet* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     flood_gpu_free(p->fgpu);
-    river_free(p);
     basin_free(p);
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); p->side = nullptr; }
     if (p->evFork) { (void)hipEventDestroy(p->evFork); p->evFork = nullptr; }
