@@ -1135,6 +1135,53 @@ WO_HD inline bool carve_task_eager(const Fields& F, int32_t r, int32_t slot, int
     return true;
 }
 
+// Everything a carve turn reads that does not change during the glacial step's rounds, in one 224-byte record per active
+// task (built once per step next to the dependency list): a round then is record -> {dependencies' tags, heights} -> stores.
+struct alignas(16) CarveRec { int32_t r, depCnt, deg; float fl; int32_t up, pad_[3]; double deepening, bonus; int32_t nbs[WO_EAGER_ROW]; float dist[WO_EAGER_ROW]; int32_t deps[WO_CARVE_DEPS]; };
+static_assert(sizeof(CarveRec) == 240, "CarveRec layout");
+// deepening / bonus: the two pow() terms of the turn (js/terrain-post.js:510,522) — functions of the task's ice flow alone, so they
+// are worked out here, once, instead of on the critical path of a round (a round lasts as long as its slowest task, and a
+// double-precision pow is a few hundred dependent instructions)
+WO_HD inline void carve_record_cell(const Fields& F, int32_t r, int32_t slot, CarveRec* recs, double gCarveRate, double gConvergenceBonus, double glacialStrength) {
+    CarveRec R;
+    const int32_t jb = F.off[r], deg = F.off[r + 1] - jb;
+    R.r = r; R.depCnt = F.carveDepCnt[slot]; R.deg = deg; R.fl = F.iceFlow[r]; R.up = F.iceUp[r]; R.pad_[0] = R.pad_[1] = R.pad_[2] = 0;
+    { const double fl = R.fl; R.deepening = gCarveRate * pow(fl, 0.6) * glacialStrength; R.bonus = gConvergenceBonus * pow(fl, 0.4); }
+    for (int k = 0; k < WO_EAGER_ROW; ++k) { R.nbs[k] = k < deg ? F.adj[jb + k] : r; R.dist[k] = k < deg ? F.dist[jb + k] : 1.0f; }
+    for (int k = 0; k < WO_CARVE_DEPS; ++k) R.deps[k] = (R.depCnt >= 0 && k < R.depCnt) ? F.carveDeps[(size_t)slot * WO_CARVE_DEPS + k] : r;
+    recs[slot] = R;
+}
+// the turn from its record (same arithmetic as carve_task / carve_task_eager); records with depCnt < 0 or a row longer than
+// WO_EAGER_ROW take carve_task_eager
+WO_HD inline bool carve_task_rec(const Fields& F, const CarveRec& R, int32_t slot, int32_t round, double gCarveRate, double gConvergenceBonus, double glacialStrength) {
+    if (R.depCnt < 0 || R.deg > WO_EAGER_ROW) return carve_task_eager(F, R.r, slot, round, gCarveRate, gConvergenceBonus, glacialStrength);
+    int32_t da[WO_CARVE_DEPS]; float en[WO_EAGER_ROW]; uint8_t on[WO_EAGER_ROW];
+#pragma unroll
+    for (int k = 0; k < WO_CARVE_DEPS; ++k) da[k] = k < R.depCnt ? F.doneAt[R.deps[k]] : -1;
+    const float e0 = F.e[R.r];
+#pragma unroll
+    for (int k = 0; k < WO_EAGER_ROW; ++k) { on[k] = F.ocean[R.nbs[k]]; en[k] = F.e[R.nbs[k]]; }
+    bool ready = true;
+#pragma unroll
+    for (int k = 0; k < WO_CARVE_DEPS; ++k) if (k < R.depCnt && !(da[k] < round)) ready = false;
+    if (!ready) return false;
+    const double deepening = R.deepening;
+    float er = (float)((double)e0 - deepening);
+#pragma unroll
+    for (int k = 0; k < WO_EAGER_ROW; ++k) {
+        if (k >= R.deg || on[k]) continue;
+        const double d = nd_or_eps(R.dist[k]);
+        const double slope = fabs((double)er - (double)en[k]) / d;
+        double f = 1 - slope;
+        if (!(f > 0)) f = (f != f) ? f : 0;
+        F.e[R.nbs[k]] = (float)((double)en[k] - deepening * 0.4 * f);
+    }
+    if (R.up >= 2) er = (float)((double)er - R.bonus);
+    F.e[R.r] = er;
+    F.doneAt[R.r] = round;
+    return true;
+}
+
 // the cell a task that just failed carve_task() is waiting for (device schedule: carried in the pending-list entry)
 WO_HD inline int32_t carve_current_blocker(const Fields& F, int32_t r) {
     if (F.carveDeps) {

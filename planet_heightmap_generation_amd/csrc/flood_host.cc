@@ -97,6 +97,51 @@ struct KeyHeap {
     }
 };
 
+// The landmass walks never rely on how their queue orders EQUAL keys (that is what the tie groups are for), so they need the
+// reference's binary heap only where the single heap itself is replayed.  They use a 4-ary heap: half the levels, the four
+// children of a node are one 32-byte stretch.  Same interface as KeyHeap.
+struct KeyHeap4 {
+    hvec<HeapItem>& d;
+    size_t n = 0;
+    explicit KeyHeap4(hvec<HeapItem>& storage) : d(storage) {}
+    void push(int32_t c, float kc) {
+        size_t i = n++;
+        if (d.size() < n + 8) d.resize(d.size() * 2 + 1024);
+        HeapItem* h = d.data();
+        while (i > 0) {
+            const size_t parent = (i - 1) >> 2;
+            if (kc >= h[parent].key) break;
+            h[i] = h[parent];
+            i = parent;
+        }
+        h[i] = HeapItem{kc, c};
+    }
+    int32_t pop() {      // slots n .. n+3 hold +inf so absent children lose
+        HeapItem* h = d.data();
+        const int32_t top = h[0].cell;
+        const HeapItem last = h[--n];
+        h[n].key = INFINITY; h[n + 1].key = INFINITY; h[n + 2].key = INFINITY; h[n + 3].key = INFINITY;
+        if (n > 0) {
+            size_t i = 0;
+            const float kc = last.key;
+            for (;;) {
+                const size_t c0 = 4 * i + 1;
+                if (c0 >= n) break;
+                { const size_t f = 16 * i + 5; if (f < n) { __builtin_prefetch(&h[f]); __builtin_prefetch(&h[f + 8]); } }     // the 16 grandchildren
+                size_t s = c0; float ks = h[c0].key;
+                if (h[c0 + 1].key < ks) { s = c0 + 1; ks = h[c0 + 1].key; }
+                if (h[c0 + 2].key < ks) { s = c0 + 2; ks = h[c0 + 2].key; }
+                if (h[c0 + 3].key < ks) { s = c0 + 3; ks = h[c0 + 3].key; }
+                if (!(ks < kc)) break;
+                h[i] = h[s];
+                i = s;
+            }
+            h[i] = last;
+        }
+        return top;
+    }
+};
+
 inline uint32_t asc_bits(float f) {
     if (f == 0.0f) f = 0.0f;
     uint32_t u; std::memcpy(&u, &f, 4);
@@ -417,7 +462,8 @@ namespace {
 struct TieGroup { float level; int32_t firstFam, fam; };
 struct Contest { int32_t cell, other; float level; };
 
-void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
+template <class Heap>
+void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
                    std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
     const double EPS = 1e-7;
     const int32_t* landCell = S.landCell.data();
@@ -427,7 +473,7 @@ void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<F
     FloodCell* st = S.state.data();
     int32_t* stamp = S.stamp.data();
     if (store.size() < 1024) store.resize(1024);
-    KeyHeap heap(store);
+    Heap heap(store);             // any exact priority queue will do here (see KeyHeap4)
     for (int32_t q = 0; q < nSeeds; ++q) {                  // :118-128, ascending r
         const int32_t s = seeds[q], i = S.seedCell[s];
         st[i].drain = TO_OCEAN;
@@ -489,6 +535,12 @@ void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<F
             heap.push(nb, k);
         }
     }
+}
+void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
+                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
+    static const bool binary = [] { const char* v = std::getenv("WO_FLOOD_HEAP"); return v && std::atoi(v) == 2; }();      // WO_FLOOD_HEAP=2: the binary heap (A/B)
+    if (binary) walk_landmass_h<KeyHeap>(S, seeds, nSeeds, store, contests, nGroups, nNested);
+    else walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
 }
 int flood_workers(int64_t items) {
     static const int capThreads = [] { const char* e = std::getenv("WO_FLOOD_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 24; }();

@@ -697,6 +697,11 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_deps(Fields F, const int32_t
     const int32_t n = *count;
     WO_GRID_STRIDE(i, n) { const int32_t r = list[i]; carveSlot[r] = i; carve_deps_cell(F, r, i); }
 }
+// per-task records of the static rounds (after k_carve_deps) and their slot-indexed round tags
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_records(Fields F, const int32_t* list, const int32_t* count, CarveRec* recs, int32_t* slotDone, double gCarve, double gConv, double gStrength) {
+    const int32_t n = *count;
+    WO_GRID_STRIDE(i, n) { carve_record_cell(F, list[i], i, recs, gCarve, gConv, gStrength); slotDone[i] = WO_NOT_DONE; }
+}
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
                                                            int32_t* outCount, int32_t* zeroCount, int32_t round, double gCarve,
                                                            double gConv, double gStrength) {
@@ -747,14 +752,15 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_pairs(Fields F, const 
 // chain.  A finished task leaves after one load; an open one issues all its loads at once (carve_task_eager) and runs when its
 // dependencies finished in earlier launches.  done: tasks finished so far (one atomic per wave that finished any), read back
 // by the driver every few rounds.
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const int32_t* __restrict__ list, const int32_t* __restrict__ count, int32_t round,
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const CarveRec* __restrict__ recs, int32_t* slotDone, const int32_t* __restrict__ count, int32_t round,
                                                                   double gCarve, double gConv, double gStrength, int32_t* done) {
     const int32_t n = *count;
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool ran = false;
-    if (i < n) {
-        const int32_t r = list[i];
-        if (F.doneAt[r] == WO_NOT_DONE) ran = carve_task_eager(F, r, i, round, gCarve, gConv, gStrength);
+    if (i < n && slotDone[i] == WO_NOT_DONE) {
+        const CarveRec R = recs[i];
+        ran = carve_task_rec(F, R, i, round, gCarve, gConv, gStrength);
+        if (ran) slotDone[i] = round;
     }
     const unsigned long long m = __ballot(ran);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(done, __popcll(m));

@@ -698,15 +698,18 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int32_t active = read_count(p, p->d_counters + 3);
                 carveActive += active;
                 if ((int64_t)active > p->carveCap) {
-                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]);
+                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone);
                     p->carveCap = (int64_t)active + active / 4 + 1024;
                     p->d_carveDeps = dalloc<int32_t>((size_t)p->carveCap * WO_CARVE_DEPS);
                     p->d_carveDepCnt = dalloc<int32_t>((size_t)p->carveCap); p->d_carveDepPos = dalloc<int32_t>((size_t)p->carveCap);
+                    p->d_carveRecs = dalloc<CarveRec>((size_t)p->carveCap); p->d_carveSlotDone = dalloc<int32_t>((size_t)p->carveCap);
                     p->d_carvePairs[0] = dalloc<int2>((size_t)p->carveCap); p->d_carvePairs[1] = dalloc<int2>((size_t)p->carveCap);
                 }
                 F.carveDeps = p->d_carveDeps; F.carveDepCnt = p->d_carveDepCnt; F.carveDepPos = p->d_carveDepPos;
                 if (active > 0)
                     launch(p, FAM_CARVE_SETUP, k_carve_deps, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveSlot);
+                if (active > 0)
+                    launch(p, FAM_CARVE_SETUP, k_carve_records, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength);
             }
             // rounds over {task, blocker} entries (k_carve_round_pairs); counters as in run_rounds: c[k%3] in, c[(k+1)%3] out
             {
@@ -734,7 +737,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     static const int burst = getenv("WO_CARVE_BURST") ? std::max(1, atoi(getenv("WO_CARVE_BURST"))) : 32;
                     for (;;) {
                         for (int b = 0; b < burst; ++b, ++k)
-                            launch(p, FAM_CARVE_ROUND, k_carve_round_static, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), (int32_t)k, gCarve, gConv, gStrength, done);
+                            launch(p, FAM_CARVE_ROUND, k_carve_round_static, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), (int32_t)k, gCarve, gConv, gStrength, done);
                         if (read_count(p, done) >= active) break;
                         if (k > 4 * (int64_t)p->N + 1024) throw HipError{"carve rounds do not converge"};
                     }
@@ -1075,7 +1078,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);
