@@ -65,7 +65,7 @@ PMC_FILE = REPO / "profiles" / "r03_pmc_fetch_write_per_kernel_10m_200iters.json
 FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": "wo::k_solve_setup",
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
                  "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_snap": "wo::k_flow_climb", "carve_round": "wo::k_carve_round_pairs",
-                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": "wo::k_solve_stream"}
+                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_coop", "wo::k_solve_stream")}
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5)
@@ -605,7 +605,8 @@ def main():
             pmc_all = json.loads(PMC_FILE.read_text())
             src = "committed file profiles/" + PMC_FILE.name + " (rocprofv3 --pmc, separate passes per counter, this workload at the full 200 iterations, one planet), not measured in this run"
         if pmc_all and fam in FAMILY_KERNEL:
-            pmc = next((v for k, v in pmc_all.items() if k.replace("(anonymous namespace)::", "").startswith(FAMILY_KERNEL[fam])), None)
+            names = FAMILY_KERNEL[fam] if isinstance(FAMILY_KERNEL[fam], tuple) else (FAMILY_KERNEL[fam],)
+            pmc = next((v for k, v in pmc_all.items() if isinstance(v, dict) and k.replace("(anonymous namespace)::", "").startswith(names)), None)
             if pmc and "FETCH_SIZE_KB" in pmc and "WRITE_SIZE_KB" in pmc:
                 traffic = (pmc["FETCH_SIZE_KB"]["per_launch"] + pmc["WRITE_SIZE_KB"]["per_launch"]) * 1024.0
                 traffic_note = ("traffic_source: " + src + "; bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB; FETCH_SIZE on gfx950 under-reports wide coalesced "
