@@ -95,11 +95,13 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_jump(const int32_t* __restri
     }
 }
 // thread i: the i-th cell in processing order (largest rank first)
+// scramble (test hook, WO_BASIN_SCRAMBLE=1): every third cell is sent to the neighbouring group, so groups are no longer closed under
+// the dependencies and the launch leaves tasks pending — the k_solve_patch launches that finish them must give the same bits
 __global__ __launch_bounds__(WO_BLOCK) void k_basin_keys(const int32_t* __restrict__ land, const uint32_t* __restrict__ keyOfCell, int32_t L,
-                                                          uint32_t* __restrict__ keys, int32_t* __restrict__ vals) {
+                                                          uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t scramble) {
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
         const int32_t c = land[L - 1 - i];
-        keys[i] = keyOfCell[c];
+        keys[i] = (scramble && c % 3 == 0) ? (keyOfCell[c] ^ 1u) : keyOfCell[c];
         vals[i] = c;
     }
 }
@@ -335,7 +337,8 @@ void basin_layout(wo_planet* p) {
     const int grid = blocks_for(L, 1 << 16);
     launch(p, FAM_BASIN, k_basin_init, grid, WO_BLOCK, F, (const int32_t*)p->d_patchOrder, (const int32_t*)p->d_slotOf, p->d_basinJ, L);
     launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
-    launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0]);
+    launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
+           (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0));
     {
         hipEvent_t a = nullptr, b = nullptr;
         if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }

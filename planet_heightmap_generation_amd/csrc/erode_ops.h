@@ -106,6 +106,8 @@ struct Fields {
     const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean [N]; nullptr: store index = cell
     SolveOut* out;                      // per-task event outputs {own turn, deposit on receiver} [N], at the store index
     double solveK, solveM, solveDt;     // the pass's constants (K, m, dt): solve_setup folds them into SolveTask::factor
+    int32_t solveLean;                  // 1: solve_setup writes the task record only — the outputs were cleared by a memset and the blocker hints are
+                                        //    made from the records if a launch ever leaves tasks pending (basin-local solve: 20 of the 68 scattered bytes per task)
     int32_t* blk;                       // patch solve: granule that was seen unresolved when the task last failed, or -1 [N], at the store index
     EventList* ev;                      // events per location [N] (land entries written by flow_final_cell); nullptr: row scans
     int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]
@@ -502,8 +504,8 @@ WO_HD inline void solve_setup_cell(const Fields& F, int32_t r) {
     const int32_t si = store_index(F, r);
     F.task[si] = T;
     SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
-    F.out[si] = z;
-    if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+    if (!F.solveLean) F.out[si] = z;
+    if (F.blk && !F.solveLean) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
 }
 WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r) {
     if (F.ocean[r]) return;
@@ -556,8 +558,8 @@ WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r) {
     const int32_t si = store_index(F, r);
     F.task[si] = T;
     SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
-    F.out[si] = z;
-    if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+    if (!F.solveLean) F.out[si] = z;
+    if (F.blk && !F.solveLean) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
 }
 WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     if (F.ocean[r]) return;
@@ -586,9 +588,9 @@ WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     const int32_t si = store_index(F, r);
     F.task[si] = T;
     SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
-    F.out[si] = z;
+    if (!F.solveLean) F.out[si] = z;
     // any unresolved predecessor is a valid first blocker; the receiver's event usually resolves last
-    if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+    if (F.blk && !F.solveLean) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
 }
 
 // ---- divisions by per-task constants, taken off the dependency chain ----

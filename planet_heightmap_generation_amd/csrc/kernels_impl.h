@@ -621,6 +621,14 @@ __global__ __launch_bounds__(WO_PATCH_THREADS) void k_solve_patch(Fields F, int3
     }
 }
 
+// blocker hints of the tasks a basin launch left pending (solve_setup's choice: any unresolved predecessor will do)
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_blk_init(Fields F, int32_t L) {
+    WO_GRID_STRIDE(s, L) {
+        if (F.out[s].self.tag != 0) continue;
+        const SolveTask T = F.task[s];
+        F.blk[s] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+    }
+}
 __global__ __launch_bounds__(WO_BLOCK) void k_slot_scatter(const int32_t* patchOrder, int32_t* slotOf, int32_t L) {
     WO_GRID_STRIDE(s, L) slotOf[patchOrder[s]] = s;
 }

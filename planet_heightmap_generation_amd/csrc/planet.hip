@@ -277,9 +277,13 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
                 WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));   // wrapped: every earlier slot has been read back
             }
             if (basin && tag == 1) basin_solve_launch(p, F, tag, tot + 1);
-            else
+            else {
+            // the first k_solve_patch launch after a lean setup: its blocker hints are made from the records now (only tasks the basin
+            // launch left pending get one; normally there is no such launch at all)
+            if (basin && tag == 2 && F.solveLean) launch(p, FAM_MISC, k_solve_blk_init, blocks_for(p->L, 4096), WO_BLOCK, F, p->L);
             launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
                    dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)(tag >= lateFrom ? lateCap : spinCap));
+            }
             ++launches;
         }
         static_assert(WO_PATCH_TOTAL_SLOTS <= WO_MAX_LEVEL + 2, "h_levelStart doubles as the read-back buffer of the pending totals");
@@ -832,6 +836,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (basin) {
                 if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p);
                 F.slotOf = p->d_basinSlot;
+                F.solveLean = 1;
+                WO_HIP(hipMemsetAsync(p->d_out, 0, (size_t)L * sizeof(SolveOut), s));       // the outputs' tags, cleared in one sweep instead of one scattered 16-byte write per task
             }
             launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {

@@ -618,3 +618,31 @@ def test_exchange_behind_the_c_abi_single_rank(TP):
     assert np.array_equal(pl.download(), before)
     comm.close()
     pl.close()
+
+
+def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch):
+    """The basin-local solve never leaves a task pending on real layouts (`solve_basin_passes_with_leftovers` is 0 in every run),
+    so the path that finishes pending tasks — blocker hints made from the records, then k_solve_patch launches over the same
+    store order — is exercised with a layout that is wrong on purpose (WO_BASIN_SCRAMBLE: every third cell in its neighbour's
+    group).  The solve is a single-assignment dataflow: the result must be the oracle's bit for bit all the same."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(200000, 0.75, 4)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(4)
+    e0 = pl.download()
+    oc = (e0 <= 0).astype(np.uint8)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    args = (12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 0, 0.0)
+    ref = oracle.erode_composite(om, e0, xyz, oc, *args, nd)
+    monkeypatch.setenv("WO_BASIN_SCRAMBLE", "1")
+    got = e0.copy()
+    pl.erode_composite(got, oc, *args)
+    st = pl.last_erode_stats()
+    monkeypatch.delenv("WO_BASIN_SCRAMBLE")
+    assert st["solve_basin_passes_with_leftovers"] > 0, st
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    got = e0.copy()
+    pl.erode_composite(got, oc, *args)
+    assert pl.last_erode_stats()["solve_basin_passes_with_leftovers"] == 0
+    assert np.array_equal(got, ref)
+    pl.close()
