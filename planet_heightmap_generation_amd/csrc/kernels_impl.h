@@ -760,6 +760,9 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_pairs(Fields F, const 
 // chain.  A finished task leaves after one load; an open one issues all its loads at once (carve_task_eager) and runs when its
 // dependencies finished in earlier launches.  done: tasks finished so far (one atomic per wave that finished any), read back
 // by the driver every few rounds.
+// (Also measured in round 3 and dropped, profiles/r03x_*: launches of several SUB-ROUNDS — dependencies inside the workgroup's 256
+// tasks satisfied through LDS flags between barriers.  3 248 launches became 1 344 with 8 sub-rounds, but a launch then lasts 35 us:
+// glacial stage 58-81 ms against 60; the chains of the carve DAG leave a workgroup's patch after two or three levels.)
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const CarveRec* __restrict__ recs, int32_t* slotDone, const int32_t* __restrict__ count, int32_t round,
                                                                   double gCarve, double gConv, double gStrength, int32_t* done) {
     const int32_t n = *count;
