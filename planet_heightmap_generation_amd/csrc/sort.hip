@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "device.h"
 
 namespace wo {
@@ -72,6 +75,16 @@ size_t sort_temp_bytes(int32_t n) {
     return bytes > bytes2 ? bytes : bytes2;
 }
 
+// diagnostic (WO_SORT_STATS=1): how far does a cell move in the order from one sort to the next?  rank[] still holds the previous
+// positions when this runs.  hist[b]: cells whose displacement d has floor(log2(d + 1)) == b; hist[32]: the maximum.
+__global__ __launch_bounds__(WO_BLOCK) void k_sort_displacement(const int32_t* __restrict__ land, const int32_t* __restrict__ rankOld, int32_t L, unsigned long long* hist) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
+        const int32_t d = abs(i - rankOld[land[i]]);
+        atomicAdd(&hist[31 - __clz((uint32_t)d + 1u)], 1ull);
+        atomicMax(&hist[32], (unsigned long long)d);
+    }
+}
+
 void sort_land_by_elevation(wo_planet* p) {
     const int32_t L = p->L;
     const int cur = p->landCur;
@@ -86,6 +99,17 @@ void sort_land_by_elevation(wo_planet* p) {
     WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, k, v, L, 0, 32, s));
     if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_SORT_RADIX, a, b}); }
     p->landCur = (v.Current() == p->d_land[cur]) ? cur : (cur ^ 1);
+    static const bool stats = getenv("WO_SORT_STATS") != nullptr;
+    if (stats) {
+        unsigned long long* d_h = nullptr; unsigned long long h[33];
+        WO_HIP(hipMalloc((void**)&d_h, sizeof(h))); WO_HIP(hipMemsetAsync(d_h, 0, sizeof(h), s));
+        hipLaunchKernelGGL(k_sort_displacement, dim3(blocks_for(L, 4096)), dim3(WO_BLOCK), 0, s, (const int32_t*)p->d_land[p->landCur], (const int32_t*)p->d_rank, L, d_h);
+        WO_HIP(hipMemcpyAsync(h, d_h, sizeof(h), hipMemcpyDeviceToHost, s)); WO_HIP(hipStreamSynchronize(s)); WO_HIP(hipFree(d_h));
+        unsigned long long moved = 0; for (int b = 1; b < 32; ++b) moved += h[b];
+        fprintf(stderr, "[sort] displacement vs the previous order: %llu of %d cells moved, max %llu; cells by floor(log2(d+1)):", moved, L, h[32]);
+        for (int b = 0; b < 24; ++b) fprintf(stderr, " %llu", h[b]);
+        fprintf(stderr, "\n");
+    }
     launch(p, FAM_RANK, k_rank_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, L);
 }
 
