@@ -414,8 +414,8 @@ def host_thread_usage():
     serial = os.environ.get("WO_FLOOD_HOST") == "serial"
     return dict(available=n, mesh_builder_and_static_tables=ht, flood_workers=1 if serial else min(ht, fl), flood_pass2_pass3_tree_workers=min(ht, fl),
                 note="inside the timed step the host runs only the priority flood (two calls per step): one heap per landmass, landmasses and their "
-                     "drainage trees dealt to the flood workers (erode_stats.flood_host_serial_pass1 counts the calls that had to fall back to the "
-                     "single serial heap walk)")
+                     "drainage trees dealt to the flood workers; landmasses where equal keys matter are decided by a single-threaded replay of the "
+                     "reference's heap (erode_stats.flood_host_replays: 0 at 10 M cells; flood_host_serial_pass1, round 2's serial walk, stays 0)")
 
 
 def parity_crc(pl, cells: int, iters: int):
