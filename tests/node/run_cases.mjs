@@ -142,6 +142,26 @@ async function main() {
             result.climateErrors = errs;
             break;
         }
+        case 'comm_single_rank': {          // the RCCL communicator and both exchange shapes through the addon (one rank: RCCL refuses two on one GPU)
+            const NT = await imp('native.js');
+            const planet = NT.planetFor(mesh, xyz, nd);
+            const e = readArr(j.elevation, Float32Array);
+            native.planetUpload(planet, e, null);
+            const id = native.commUniqueId();
+            const comm = native.commCreate(NT.defaultContext(), id, 1, 0);
+            const send = new Int32Array(1000).map((_, k) => 3 * k);
+            native.planetSetHalo(planet, send, new Int32Array(0));
+            native.planetExchangeAllgather(planet, comm, new Int32Array([send.length]));
+            const errs = [];
+            try { native.planetExchangeAllgather(planet, comm, new Int32Array([send.length, 1])); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
+            try { native.planetExchangeNeighbors(planet, comm, 0, 0); errs.push(null); } catch (ex) { errs.push(ex.constructor.name); }
+            native.planetSetHalo(planet, new Int32Array(0), new Int32Array(0));
+            native.planetExchangeNeighbors(planet, comm, 0, 0);
+            const back = new Float32Array(e.length);
+            native.planetDownload(planet, back);
+            result.comm = { idBytes: id.length, idNonZero: id.some((b) => b !== 0), errors: errs, unchanged: back.every((v, k) => v === e[k]) };
+            break;
+        }
         case 'error_paths': {
             const errs = [];
             const e = readArr(j.elevation, Float32Array), oc = readArr(j.isOcean, Uint8Array);

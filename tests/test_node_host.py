@@ -206,3 +206,21 @@ def test_worker_threads_counterpart(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "w_elev3.bin", np.float32), e)          # back to the first sliders: same field again
     assert res["disposed"] == {"type": "disposed"} and res["afterDispose"]["message"] == "No retained state for reapply"
     pl.close()
+
+
+@pytest.mark.gpu
+def test_js_comm_bindings_single_rank(tmp_path):
+    """include/worogen.h's wo_comm_* / wo_planet_exchange_* through the addon, the way a multi-GPU JS host would call them
+     — with the one-rank communicator a one-GPU box allows: the id is 128 bytes, the communicator
+    comes up, both exchange shapes run and leave the field alone, wrong counts throw."""
+    g = load_golden("post_N10000_s1")
+    m = load_golden("mesh_N10000_s1")
+    for k, arr in (("tri", m["triangles"]), ("he", m["halfedges"]), ("xyz", g["xyz"]), ("nd", g["neighborDist"]), ("e0", g["elevation0"])):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"{k}.bin")
+    res = run_node(tmp_path, [
+        {"op": "load_mesh", "tri": "tri.bin", "he": "he.bin", "xyz": "xyz.bin", "nd": "nd.bin", "numRegions": int(g["numRegions"])},
+        {"op": "comm_single_rank", "elevation": "e0.bin"},
+    ])
+    c = res["comm"]
+    assert c["idBytes"] == 128 and c["idNonZero"] and c["unchanged"]
+    assert c["errors"] == ["RangeError", "Error"], c
