@@ -136,7 +136,9 @@ struct wo_planet {
         int32_t *perm = nullptr, *inv = nullptr, *off = nullptr, *adj = nullptr;       // perm: mirror id -> cell id
         float *dist = nullptr, *xyz = nullptr, *e = nullptr, *e2 = nullptr, *hot = nullptr;
         uint8_t *ocean = nullptr, *coast = nullptr;
-        wo::hvec<int32_t> h_perm;
+        wo::hvec<int32_t> h_perm, h_morton;           // h_morton: all cells in Morton order (mask-independent)
+        wo::hvec<uint8_t> h_mask;                     // the ocean mask the renaming was built for (land first), empty: plain Morton order
+        int64_t version = 0;
         int32_t *o_off = nullptr, *o_adj = nullptr; float *o_dist = nullptr, *o_xyz = nullptr, *o_e = nullptr, *o_e2 = nullptr;
         uint8_t *o_ocean = nullptr, *o_coast = nullptr;
     } mirror;
@@ -197,6 +199,7 @@ void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
 void rank_from_land(wo_planet* p);
 void sort_by_level(wo_planet* p);
+void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount);   // carve tasks in landCells order
 // basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it
 void basin_layout(wo_planet* p);
 void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending);

@@ -72,7 +72,10 @@ struct alignas(8) TargetRank { int32_t target; int32_t rank; };
 // r, its receiver and the receiver's receiver instead of re-reading three neighbour rows (24 gathers), and solve_final
 // reads the latest event off the end of the list.  Locations with more than WO_EVENTS events (own turn + >3 donors:
 // ~1 % of the cells) carry the overflow mark and take the row scans.
-constexpr int WO_EVENTS = 4;
+#ifndef WO_EVENTS_N
+#define WO_EVENTS_N 6
+#endif
+constexpr int WO_EVENTS = WO_EVENTS_N;
 struct alignas(16) EventList { int32_t cell[WO_EVENTS]; int32_t rank[WO_EVENTS]; };     // unused slots: rank -1; overflow: rank[0] == -2
 constexpr int WO_CARVE_DEPS = 24;       // dependency slots per active carve task (a task with more takes the scanning form, and a round lasts as long as its slowest task)
 struct Fields {
@@ -1151,6 +1154,14 @@ WO_HD inline void carve_record_cell(const Fields& F, int32_t r, int32_t slot, Ca
     { const double fl = R.fl; R.deepening = gCarveRate * pow(fl, 0.6) * glacialStrength; R.bonus = gConvergenceBonus * pow(fl, 0.4); }
     for (int k = 0; k < WO_EAGER_ROW; ++k) { R.nbs[k] = k < deg ? F.adj[jb + k] : r; R.dist[k] = k < deg ? F.dist[jb + k] : 1.0f; }
     for (int k = 0; k < WO_CARVE_DEPS; ++k) R.deps[k] = (R.depCnt >= 0 && k < R.depCnt) ? F.carveDeps[(size_t)slot * WO_CARVE_DEPS + k] : r;
+    // highest rank first: the dependency closest to the task in rank tends to finish last, and the one-launch carve (k_carve_flow)
+    // watches the first open entry instead of polling all of them (the order of the list means nothing to the rounds)
+    for (int a = 1; a < R.depCnt; ++a) {
+        const int32_t c = R.deps[a], rc = F.arank[c];
+        int b = a - 1;
+        while (b >= 0 && F.arank[R.deps[b]] < rc) { R.deps[b + 1] = R.deps[b]; --b; }
+        R.deps[b + 1] = c;
+    }
     recs[slot] = R;
 }
 // the turn from its record (same arithmetic as carve_task / carve_task_eager); records with depCnt < 0 or a row longer than

@@ -370,6 +370,100 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* dono
 
 __global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_XCD_LAND(i, r) solve_setup_cell(F, r); }
 
+// The same setup, written for the memory pipeline.  solve_setup_cell decides what to load next from what it has just loaded (has a
+// receiver? is it land? did a list overflow?), so the compiler must wait for every load before the branch that follows it: the ISA
+// was load, s_waitcnt vmcnt(0), branch, load, ... — ~85 loads per wave one after the other, 56 000 cycles per wave with the
+// vector ALU 4 % busy (profiles/r03af_sq_counters_*.json), and the row-scan path of the ~3 % of tasks with an overflowed event list
+// sat inside 86 % of the waves.  Here every level of the chain r -> receiver -> its receiver -> predecessors' slots is loaded
+// unconditionally from a clamped index (the task's own cell where there is no such cell), so each level's loads are in flight
+// together and nothing is decided before the end; tasks that need the row scans are put on a list and set up by
+// k_solve_setup_deferred, in their own waves.  Same record, field for field, as solve_setup_cell.
+template <bool SLOT>
+__device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
+    // level 1: the task's own cell
+    const TargetRank trr = F.tr[r];
+    const EventList Er = F.ev[r];
+    const float e0r = F.e[r], flow = F.flow[r], cdR = F.cellDist[r];
+    const int32_t si = SLOT ? F.slotOf[r] : r;
+    const int32_t t = trr.target, rr = trr.rank;
+    const int32_t tc = t >= 0 ? t : r;
+    // level 2: the receiver; the slot of the latest earlier event on r
+    const TargetRank trt = F.tr[tc];
+    const EventList EtL = F.ev[tc];
+    const float cdTL = F.cellDist[tc], e0tL = F.e[tc];
+    const int32_t p0 = event_before(Er, r, rr);
+    const int32_t p0c = p0 >= 0 ? p0 : r;
+    const int32_t s0 = SLOT ? F.slotOf[p0c] : p0c;
+    const bool tLand = t >= 0 && trt.rank >= 0;                     // ocean cells carry rank -1
+    const float cdT = tLand ? cdTL : 0.0f;
+    const int32_t t2 = (tLand && trt.target >= 0 && cdT > 0) ? trt.target : -1;
+    const int32_t t2c = t2 >= 0 ? t2 : r;
+    // level 3: the receiver's receiver; the slot of the latest earlier event on t
+    const TargetRank trt2 = F.tr[t2c];
+    const EventList Et2L = F.ev[t2c];
+    const float e0t2L = F.e[t2c];
+    const int32_t p1 = tLand ? event_before(EtL, r, rr) : -1;
+    const int32_t p1c = p1 >= 0 ? p1 : r;
+    const int32_t s1 = SLOT ? F.slotOf[p1c] : p1c;
+    const bool t2Land = t2 >= 0 && trt2.rank >= 0;
+    // level 4: the slot of the latest earlier event on t2
+    const int32_t p2 = t2Land ? event_before(Et2L, r, rr) : -1;
+    const int32_t p2c = p2 >= 0 ? p2 : r;
+    const int32_t s2 = SLOT ? F.slotOf[p2c] : p2c;
+    if (Er.rank[0] == -2 || (tLand && EtL.rank[0] == -2) || (t2Land && Et2L.rank[0] == -2)) return false;     // row scans: deferred
+    SolveTask T;
+    T.predSelf = p0 >= 0 ? 2 * s0 + (p0 == r ? 0 : 1) : -1;
+    T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
+    T.e0r = e0r; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
+    T.factor = solve_factor_of(flow, cdR, F.solveK, F.solveM, F.solveDt);
+    if (t >= 0) {
+        T.flags |= 4u;
+        T.e0t = e0tL;
+        if (!tLand) T.flags |= 1u;
+        else {
+            T.predT = p1 >= 0 ? 2 * s1 + (p1 == t ? 0 : 1) : -1;
+            T.cellDistT = cdT;
+            if (t2 >= 0) {
+                T.flags |= 8u;
+                T.e0t2 = e0t2L;
+                if (!t2Land) T.flags |= 2u;
+                else T.predT2 = p2 >= 0 ? 2 * s2 + (p2 == t2 ? 0 : 1) : -1;
+            }
+        }
+    }
+    F.task[si] = T;
+    if (!F.solveLean) {
+        SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
+        F.out[si] = z;
+        if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
+    }
+    return true;
+}
+// Tasks that need the row scans are collected per workgroup (LDS) and set up by the workgroup's first lanes once its main pass is
+// over: the slow path then runs in one partly filled wave per workgroup instead of inside nearly every wave, and no global
+// counter is involved (one returning atomic per wave on a single word was measured to serialise the whole launch: 374 us).
+template <bool SLOT>
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup_batched(Fields F) {
+    __shared__ int32_t s_deferred[WO_BLOCK];
+    __shared__ int32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int32_t i = WO_XCD_LAND_BASE() + (int32_t)threadIdx.x;
+    int32_t r = -1;
+    bool defer = false;
+    if (i < F.L) { r = F.landIdx[i]; defer = !solve_setup_cell_batched<SLOT>(F, r); }
+    const unsigned long long m = __ballot(defer);
+    if (m) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+        int32_t base = 0;
+        if (lane == leader) base = atomicAdd(&s_n, (int32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (defer) s_deferred[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+    __syncthreads();
+    if ((int32_t)threadIdx.x < s_n) solve_setup_cell_rows(F, s_deferred[threadIdx.x]);
+}
+
 // One synchronous round of the solve dataflow.  Tasks come from two places: the leftovers of earlier rounds
 // and the bucket of tasks whose level in the previous erosion iteration was exactly this round (levels barely
 // move between iterations, so almost every task is examined once, when it is ready).
@@ -682,7 +776,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out
 // ---------------------------------------------------------------- glacial -----------------------
 __global__ __launch_bounds__(WO_BLOCK) void k_glac_index(Fields F, double strength) { WO_XCD_CELLS(r, F.N) F.glac[r] = glac_index_cell(F, r, strength); }
 __global__ __launch_bounds__(WO_BLOCK) void k_ice_receivers(Fields F) {
-    WO_XCD_CELLS(r, F.N) { ice_receiver_cell(F, r); if (F.ocean[r]) { F.iceFlow[r] = 0.0f; F.iceUp[r] = 0; } }
+    WO_XCD_CELLS(r, F.N) { ice_receiver_cell(F, r); F.blocker[r] = 0; if (F.ocean[r]) { F.iceFlow[r] = 0.0f; F.iceUp[r] = 0; } }      // blocker: k_ice_climb's arrival counts (carve_setup_cell resets it)
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_ice_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
                                                          int32_t* outCount, int32_t* zeroCount, int32_t round) {
@@ -694,12 +788,102 @@ __global__ __launch_bounds__(WO_BLOCK) void k_ice_round(Fields F, const int32_t*
         block_append(pending, t, out, outCount);
     }
 }
+// ---- in-launch hand-offs between workgroups (MI355X: a CU's L1 is never refreshed by other CUs' stores and the eight XCD L2s are not
+// coherent with each other): every word that crosses between threads inside one launch is written AND read at agent scope
+// (global_store / global_load ... sc1: write-through, L1 bypassed), and a flag or an arrival count follows its payload only after
+// the payload's stores have been acknowledged (s_waitcnt vmcnt(0), as inline asm so that no pass can drop it). ----
+__device__ inline float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Ice accumulation (js/terrain-post.js:495-503) as ONE launch.  A cell's ice flow is glacIdx plus its donors' flows added in
+// landCells order, each add rounded to f32 — the donors must all be final first, and the forest of ice receivers is ~80 cells
+// deep: as synchronous rounds that was ~80 launches of 16 us per glacial step.  Here every cell without donors runs its task and
+// hands over to its receiver through one returning atomic on the receiver's arrival count; the thread whose arrival completes a
+// receiver (last donor in) runs the receiver's task and carries on upwards — no thread ever waits, so nothing depends on dispatch
+// order or residency.  The sum is still taken over the donors in rank order by the one thread that runs the task: the same
+// operations on the same values as ice_accumulate_task.  The receiver's donor list is static during the launch and is read while
+// the cell's own store drains.
+// rows of up to WO_ROW neighbours stay in registers (no indexed arrays: those would live in scratch memory, on the critical path)
+struct IceRow { int32_t nb[WO_ROW]; int32_t rank[WO_ROW]; uint32_t donors; int nd; int deg; };
+__device__ inline void ice_row_of(const Fields& F, int32_t t, IceRow& D) {
+    int32_t b;
+    D.deg = load_row(F, t, b, D.nb);
+    D.donors = 0; D.nd = 0;
+    if (D.deg > WO_ROW) {                                       // long row: only the count here, the task walks the row itself
+        for (int32_t j = b; j < b + D.deg; ++j) if (F.iceTarget[F.adj[j]] == t) ++D.nd;
+        return;
+    }
+    int32_t tg[WO_ROW];
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) { tg[k] = F.iceTarget[D.nb[k]]; D.rank[k] = F.rank[D.nb[k]]; }
+#pragma unroll
+    for (int k = 0; k < WO_ROW; ++k) if (k < D.deg && tg[k] == t) { D.donors |= 1u << k; ++D.nd; }
+}
+__device__ inline float ice_task_long_row(const Fields& F, int32_t t, int& up) {     // ice_accumulate_task's walk, heights of the donors at agent scope
+    int32_t dn[WO_MAX_DEG]; int nd = 0;
+    for (int32_t j = F.off[t]; j < F.off[t + 1]; ++j) { const int32_t n = F.adj[j]; if (F.iceTarget[n] == t) dn[nd++] = n; }
+    float acc = F.glac[t];
+    int32_t last = -1;
+    up = 0;
+    for (int k = 0; k < nd; ++k) {
+        int pick = -1; int32_t pr = 0x7fffffff;
+        for (int q = 0; q < nd; ++q) { const int32_t rk = F.rank[dn[q]]; if (rk > last && rk < pr) { pr = rk; pick = q; } }
+        const float df = ld_agent(&F.iceFlow[dn[pick]]);
+        if (df > 0) { acc = (float)((double)acc + (double)df); ++up; }
+        last = pr;
+    }
+    return acc;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_ice_climb(Fields F, int32_t* arrived) {
+    WO_XCD_LAND(i, r) {
+        IceRow D;
+        ice_row_of(F, r, D);
+        if (D.nd > 0) continue;                                 // its last donor carries on with it
+        int32_t cur = r;
+        for (;;) {
+            float acc;
+            int up = 0;
+            const int32_t tgt = F.iceTarget[cur];
+            if (D.deg > WO_ROW) acc = ice_task_long_row(F, cur, up);
+            else {
+                float fl[WO_ROW];
+#pragma unroll
+                for (int k = 0; k < WO_ROW; ++k) fl[k] = ((D.donors >> k) & 1u) ? ld_agent(&F.iceFlow[D.nb[k]]) : 0.0f;
+                acc = F.glac[cur];
+                int32_t last = -1;
+#pragma unroll
+                for (int step = 0; step < WO_ROW; ++step) {     // donors in landCells order (ascending rank)
+                    int32_t pr = 0x7fffffff; float df = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < WO_ROW; ++q) if (((D.donors >> q) & 1u) && D.rank[q] > last && D.rank[q] < pr) { pr = D.rank[q]; df = fl[q]; }
+                    if (pr == 0x7fffffff) break;
+                    if (df > 0) { acc = (float)((double)acc + (double)df); ++up; }
+                    last = pr;
+                }
+            }
+            st_agent(&F.iceFlow[cur], acc);
+            F.iceUp[cur] = (uint8_t)up;
+            if (tgt < 0 || F.ocean[tgt]) break;                 // ocean cells can be targets, they are not tasks
+            ice_row_of(F, tgt, D);                              // static during the launch: read while the store drains
+            drain_stores();
+            if (atomicAdd(&arrived[tgt], 1) + 1 != D.nd) break; // other donors of tgt are still out
+            cur = tgt;
+        }
+    }
+}
+
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_setup(Fields F, int32_t* list, int32_t* count) {
     WO_BLOCK_STRIDE(r, valid, F.N) {
         bool act = false;
         if (valid) { carve_setup_cell(F, r); act = F.arank[r] != WO_NOT_DONE; }
         block_append(act, r, list, count);
     }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_setup_cells(Fields F) {          // the list comes from select_active_by_rank
+    WO_XCD_CELLS(r, F.N) carve_setup_cell(F, r);
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_deps(Fields F, const int32_t* list, const int32_t* count, int32_t* carveSlot) {
     const int32_t n = *count;
@@ -775,6 +959,127 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const
     }
     const unsigned long long m = __ballot(ran);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(done, __popcll(m));
+}
+// ---- the carve rounds as ONE launch -----------------------------------------------------------------------------------------------
+// A carve turn (js/terrain-post.js:506-526) may run once every lower-ranked active cell within two hops has had its turn; the DAG of
+// those waits is ~330 turns deep on a 10 M-cell planet, and as synchronous rounds every level cost a launch (11 us each, 3.7 ms
+// per glacial step for ~3 us of actual work per level).  Here every active task has its own thread, polls its dependencies' done
+// words at agent scope and takes its turn as soon as the last one is set: a level costs a flag hand-off between CUs (~2 us).
+//  * The activation list is in RANK order (select_active_by_rank), so a task's dependencies all sit at lower positions; thread g
+//    takes positions g, g + G, g + 2G, ... in turn with G = all the launch's threads.  The lowest unfinished position then always
+//    belongs to a thread that has nothing earlier left, so some task can always run provided the G threads are resident: the grid
+//    is sized by the occupancy query (minus a margin, planet.hip), never by the task count.
+//  * A wave is a set of 64 independent little state machines inside ONE wave-uniform loop: a lane that finds its task ready takes
+//    the turn inside the loop body, so no lane ever sits at a reconvergence point waiting for another lane's poll (whose task may
+//    depend on it).
+//  * Every spin is bounded: a lane that has waited `budget` ticks of the 100 MHz wall clock gives up and leaves its task to the
+//    synchronous rounds, which take over from whatever state the launch left (done words and slot tags are the rounds' own).
+//  * Heights are read and written at agent scope (they cross between CUs inside the launch); everything else a turn reads is
+//    static during the glacial step.  Any two turns that touch a common cell are within two hops of each other, hence ordered by
+//    the waits: reads-after-writes, writes-after-writes and writes-after-reads alike.
+// The arithmetic is carve_task_rec's / carve_task's, statement for statement.
+__device__ inline bool carve_flow_open_scan(const Fields& F, int32_t r) {     // tasks whose dependency list did not fit: the two-hop scan
+    const int32_t myRank = F.arank[r];
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t n = F.adj[j];
+        if (F.arank[n] < myRank && ld_agent(&F.doneAt[n]) == WO_NOT_DONE) return true;
+        for (int32_t q = F.off[n]; q < F.off[n + 1]; ++q) {
+            const int32_t m = F.adj[q];
+            if (m != r && F.arank[m] < myRank && ld_agent(&F.doneAt[m]) == WO_NOT_DONE) return true;
+        }
+    }
+    return false;
+}
+__device__ inline void carve_flow_turn_rows(const Fields& F, int32_t r, double deepening, double bonus, int32_t up) {   // rows longer than WO_EAGER_ROW
+    const float er = (float)((double)ld_agent(&F.e[r]) - deepening);
+    st_agent(&F.e[r], er);
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        if (F.ocean[nb]) continue;
+        const double d = nd_or_eps(F.dist[j]);
+        const float en = ld_agent(&F.e[nb]);
+        const double slope = fabs((double)er - (double)en) / d;
+        double f = 1 - slope;
+        if (!(f > 0)) f = (f != f) ? f : 0;
+        st_agent(&F.e[nb], (float)((double)en - deepening * 0.4 * f));
+    }
+    if (up >= 2) st_agent(&F.e[r], (float)((double)ld_agent(&F.e[r]) - bonus));
+}
+__global__ __launch_bounds__(WO_BLOCK, 4) void k_carve_flow(Fields F, const CarveRec* __restrict__ recs, int32_t* slotDone, const int32_t* __restrict__ count,
+                                                          int32_t* done, long long budget, int32_t watchMode, int32_t longSleep) {
+    const int32_t n = *count;
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+    int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const long long t0 = wall_clock64();
+    int32_t finished = 0;
+    bool active = i < n;
+    CarveRec R;
+    uint32_t open = 0;
+    bool listed = false;
+    // polling: a task first looks at all its dependencies at once (sweep), then WATCHES the first one still open — the lists are
+    // in descending rank, so that is the one likeliest to finish last — with one load per turn of the loop, and sweeps again when
+    // it is set.  (Sweeping every turn kept ~5 loads per waiting task in flight all the time: the hand-offs on the critical chain
+    // then queue behind the polls of 130 000 other tasks in every CU's memory pipeline — 6.2 us per level instead of ~2.)
+    int32_t watch = -1;                                           // cell whose done word is watched, -1: sweep next
+    if (active) { R = recs[i]; listed = R.depCnt >= 0 && R.deg <= WO_EAGER_ROW; open = listed ? ((1u << R.depCnt) - 1u) : 1u; }
+    for (;;) {
+        if (active) {
+            if (listed && watch >= 0 && watchMode) {
+                if (ld_agent(&F.doneAt[watch]) != WO_NOT_DONE) watch = -1;      // sweep in the next turn
+            } else if (listed) {
+                int32_t da[WO_CARVE_DEPS];
+#pragma unroll
+                for (int k = 0; k < WO_CARVE_DEPS; ++k) da[k] = ((open >> k) & 1u) ? ld_agent(&F.doneAt[R.deps[k]]) : 0;
+#pragma unroll
+                for (int k = 0; k < WO_CARVE_DEPS; ++k) if (((open >> k) & 1u) && da[k] != WO_NOT_DONE) open &= ~(1u << k);
+                if (open) {
+                    const int first = __ffs(open) - 1;
+                    watch = R.deps[0];
+#pragma unroll
+                    for (int k = 1; k < WO_CARVE_DEPS; ++k) if (k == first) watch = R.deps[k];
+                }
+            } else {
+                open = carve_flow_open_scan(F, R.r) ? 1u : 0u;
+            }
+            if (open == 0) {
+                watch = -1;
+                if (listed) {
+                    float en[WO_EAGER_ROW]; uint8_t on[WO_EAGER_ROW];
+                    const float e0 = ld_agent(&F.e[R.r]);
+#pragma unroll
+                    for (int k = 0; k < WO_EAGER_ROW; ++k) { on[k] = F.ocean[R.nbs[k]]; en[k] = ld_agent(&F.e[R.nbs[k]]); }
+                    const double deepening = R.deepening;
+                    float er = (float)((double)e0 - deepening);
+#pragma unroll
+                    for (int k = 0; k < WO_EAGER_ROW; ++k) {
+                        if (k >= R.deg || on[k]) continue;
+                        const double d = nd_or_eps(R.dist[k]);
+                        const double slope = fabs((double)er - (double)en[k]) / d;
+                        double f = 1 - slope;
+                        if (!(f > 0)) f = (f != f) ? f : 0;
+                        st_agent(&F.e[R.nbs[k]], (float)((double)en[k] - deepening * 0.4 * f));
+                    }
+                    if (R.up >= 2) er = (float)((double)er - R.bonus);
+                    st_agent(&F.e[R.r], er);
+                } else {
+                    carve_flow_turn_rows(F, R.r, R.deepening, R.bonus, R.up);
+                }
+                drain_stores();                                     // the heights are out before the done word is
+                st_agent(&F.doneAt[R.r], 1);
+                slotDone[i] = 1;
+                ++finished;
+                i += stride;
+                active = i < n;
+                if (active) { R = recs[i]; listed = R.depCnt >= 0 && R.deg <= WO_EAGER_ROW; open = listed ? ((1u << R.depCnt) - 1u) : 1u; }
+            } else if (wall_clock64() - t0 > budget) {
+                active = false;                                     // left to the synchronous rounds
+            }
+        }
+        if (!__any(active)) break;
+        if (longSleep) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(2);
+    }
+    for (int o = 32; o > 0; o >>= 1) finished += __shfl_down(finished, o);
+    if ((threadIdx.x & 63) == 0 && finished) atomicAdd(done, finished);
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDep, double gFjord) {
     WO_XCD_CELLS(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);

@@ -500,26 +500,51 @@ static bool mirror_wanted(const wo_planet* p) {
     const char* e = std::getenv("WO_LAYOUT");
     return !(e && std::string(e) == "index") && !p->h_xyz.empty() && p->N > 1;
 }
-static void mirror_build(wo_planet* p) {
+// mask (may be null): the ocean mask of the call the mirror is entered for.  With a mask the renaming is LAND FIRST: the land
+// cells in Morton order take the ids 0 .. L-1, the ocean cells follow in Morton order.  Every per-cell array of the erosion
+// passes is then dense over the land (the passes touch land cells only: 28 % of a synthetic planet, so in plain Morton order a
+// 64-byte line of per-cell state held ~4.5 useful entries of 16 and every 4-8-byte store of a pass was a partial line), the land
+// list of the index-order passes is the identity, and a land cell's land neighbours sit 3.6x closer in memory.  The renaming is
+// still only a renaming (rows keep their order, the initial land order is mapped through it): bit-identical results.  The mirror
+// is rebuilt when a call arrives with a different mask (~50 ms at 10 M cells; the bench's steps all have the same one).
+static void mirror_build(wo_planet* p, const uint8_t* mask = nullptr) {
     auto& M = p->mirror;
-    if (M.built) return;
     const int32_t N = p->N; const size_t E = (size_t)p->E;
+    static const bool landFirst = !(std::getenv("WO_MIRROR_LAND_FIRST") && std::atoi(std::getenv("WO_MIRROR_LAND_FIRST")) == 0);
+    if (!landFirst) mask = nullptr;
+    if (M.built && (!mask || (M.h_mask.size() == (size_t)N && std::memcmp(M.h_mask.data(), mask, (size_t)N) == 0))) return;
     hipStream_t s = p->ctx->stream;
-    morton_order_cells(N, p->h_xyz.data(), M.h_perm);
+    if (M.h_morton.empty()) morton_order_cells(N, p->h_xyz.data(), M.h_morton);
+    M.h_perm.resize(N);
+    if (mask) {
+        int32_t nl = 0;
+        for (int32_t i = 0; i < N; ++i) nl += mask[M.h_morton[i]] ? 0 : 1;
+        int32_t a = 0, b = nl;
+        for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_morton[i]; if (mask[r]) M.h_perm[b++] = r; else M.h_perm[a++] = r; }
+        M.h_mask.assign(mask, mask + N);
+    } else {
+        std::memcpy(M.h_perm.data(), M.h_morton.data(), (size_t)N * 4);
+        M.h_mask.clear();
+    }
     hvec<int32_t> moff((size_t)N + 1);
     moff[0] = 0;
     for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_perm[i]; moff[i + 1] = moff[i] + (p->h_off[r + 1] - p->h_off[r]); }
-    M.perm = dalloc<int32_t>(N); M.inv = dalloc<int32_t>(N); M.off = dalloc<int32_t>((size_t)N + 1); M.adj = dalloc<int32_t>(E + WO_ROW);
-    M.dist = dalloc<float>(E + WO_ROW);
-    WO_HIP(hipMemsetAsync(M.adj + E, 0, WO_ROW * sizeof(int32_t), s)); WO_HIP(hipMemsetAsync(M.dist + E, 0, WO_ROW * sizeof(float), s)); M.xyz = dalloc<float>(3 * (size_t)N); M.e = dalloc<float>(N); M.e2 = dalloc<float>(N);
-    M.ocean = dalloc<uint8_t>(N); M.coast = dalloc<uint8_t>(N);
+    if (!M.perm) {
+        M.perm = dalloc<int32_t>(N); M.inv = dalloc<int32_t>(N); M.off = dalloc<int32_t>((size_t)N + 1); M.adj = dalloc<int32_t>(E + WO_ROW);
+        M.dist = dalloc<float>(E + WO_ROW);
+        WO_HIP(hipMemsetAsync(M.adj + E, 0, WO_ROW * sizeof(int32_t), s)); WO_HIP(hipMemsetAsync(M.dist + E, 0, WO_ROW * sizeof(float), s)); M.xyz = dalloc<float>(3 * (size_t)N); M.e = dalloc<float>(N); M.e2 = dalloc<float>(N);
+        M.ocean = dalloc<uint8_t>(N); M.coast = dalloc<uint8_t>(N);
+    }
+    // the mirror's rows are rebuilt from the planet's own arrays: a scope must not be active (its pointers would be the mirror's)
+    const int32_t* o_off = M.active ? M.o_off : p->d_off; const int32_t* o_adj = M.active ? M.o_adj : p->d_adj;
+    const float* o_dist = M.active ? M.o_dist : p->d_dist; const float* o_xyz = M.active ? M.o_xyz : p->d_xyz;
     WO_HIP(hipMemcpyAsync(M.perm, M.h_perm.data(), (size_t)N * 4, hipMemcpyHostToDevice, s));
     WO_HIP(hipMemcpyAsync(M.off, moff.data(), ((size_t)N + 1) * 4, hipMemcpyHostToDevice, s));
     launch(p, FAM_MISC, k_mirror_invert, blocks_for(N, 4096), WO_BLOCK, (const int32_t*)M.perm, M.inv, N);
-    launch(p, FAM_MISC, k_mirror_rows, blocks_for(N, 4096), WO_BLOCK, (const int32_t*)p->d_off, (const int32_t*)p->d_adj, (const float*)p->d_dist,
-           (const float*)p->d_xyz, (const int32_t*)M.perm, (const int32_t*)M.inv, (const int32_t*)M.off, M.adj, M.dist, M.xyz, N);
+    launch(p, FAM_MISC, k_mirror_rows, blocks_for(N, 4096), WO_BLOCK, o_off, o_adj, o_dist, o_xyz, (const int32_t*)M.perm, (const int32_t*)M.inv, (const int32_t*)M.off, M.adj, M.dist, M.xyz, N);
     WO_HIP(hipStreamSynchronize(s));                    // moff / h_perm uploads done
     M.built = true;
+    ++M.version;
 }
 static void mirror_free(wo_planet* p) {
     auto& M = p->mirror;
@@ -539,9 +564,9 @@ struct MirrorScope {
         p->d_off = M.o_off; p->d_adj = M.o_adj; p->d_dist = M.o_dist; p->d_xyz = M.o_xyz; p->d_e = M.o_e; p->d_e2 = M.o_e2; p->d_ocean = M.o_ocean; p->d_coast = M.o_coast;
     }
     // field and ocean mask into the mirror, the planet's pointers onto it
-    void enter() {
+    void enter(const uint8_t* mask = nullptr) {
         if (!mirror_wanted(p) || p->mirror.active) return;
-        mirror_build(p);
+        mirror_build(p, mask);
         auto& M = p->mirror;
         const int32_t N = p->N;
         launch(p, FAM_MISC, k_mirror_gather_f32, blocks_for(N, 4096), WO_BLOCK, (const float*)p->d_e, (const int32_t*)M.perm, M.e, N);
@@ -586,13 +611,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t N = p->N;
     const int gridN = xcd_grid(N);
     StageClock clk(p);
-    int64_t solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0, patchLaunches = 0;
+    int64_t carveFlowLeft = 0, solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0, patchLaunches = 0;
     double floodHostMs = 0;
 
     clk.begin("setup");
     refresh_host_ocean(p);          // the planet's own mask, before the pointers move
     MirrorScope mir(p);
-    mir.enter();
+    mir.enter(p->h_ocean.data());          // land first (mirror_build)
     coast_flags(p);
     // landCells in ascending r (js/terrain-post.js:384-390): host-side compaction of the ocean mask
     {
@@ -692,12 +717,23 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.begin("glacial");
             Fields F = p->fields();
             launch(p, FAM_ICE_RECV, k_ice_receivers, gridN, WO_BLOCK, F);
-            iceRounds += run_rounds(p, p->d_landIdx, L, false, 8,
+            // ice accumulation: one launch in which the last donor to arrive runs its receiver's task (k_ice_climb);
+            // WO_ICE_ROUNDS=1: the synchronous rounds of earlier builds (cross-check)
+            static const bool iceRoundsEnv = getenv("WO_ICE_ROUNDS") && atoi(getenv("WO_ICE_ROUNDS")) != 0;
+            if (!iceRoundsEnv) { launch(p, FAM_ICE_ROUND, k_ice_climb, gridL, WO_BLOCK, F, F.blocker); ++iceRounds; }
+            else iceRounds += run_rounds(p, p->d_landIdx, L, false, 8,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
                 });
-            WO_HIP(hipMemsetAsync(p->d_counters + 3, 0, sizeof(int32_t), s));
-            launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
+            // WO_CARVE_FLOW=0: no one-launch carve (k_carve_flow), activation list in arrival order as in earlier builds
+            static const bool carveFlow = !(getenv("WO_CARVE_FLOW") && atoi(getenv("WO_CARVE_FLOW")) == 0);
+            if (carveFlow) {
+                launch(p, FAM_CARVE_SETUP, k_carve_setup_cells, gridN, WO_BLOCK, F);
+                select_active_by_rank(p, F.arank, p->d_listB, p->d_counters + 3);     // the active tasks in landCells order
+            } else {
+                WO_HIP(hipMemsetAsync(p->d_counters + 3, 0, sizeof(int32_t), s));
+                launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
+            }
             {   // dependency lists of the active tasks (once per glacial step)
                 const int32_t active = read_count(p, p->d_counters + 3);
                 carveActive += active;
@@ -739,7 +775,27 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     // the depth of the carve DAG falls from one glacial iteration to the next (the ice smooths its bed), so the count of
                     // finished tasks is read back every 32 rounds (a read-back costs about as much as three empty rounds)
                     static const int burst = getenv("WO_CARVE_BURST") ? std::max(1, atoi(getenv("WO_CARVE_BURST"))) : 32;
-                    for (;;) {
+                    bool allDone = false;
+                    if (carveFlow) {
+                        // every task in one launch (k_carve_flow); the grid is what is certainly resident at once: the occupancy
+                        // query's blocks per CU less one (the query is known to answer one too many near register-file edges)
+                        static int flowBlocks = 0;
+                        if (!flowBlocks) {
+                            int perCu = 0, dev = 0; hipDeviceProp_t prop;
+                            WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_carve_flow, WO_BLOCK, 0));
+                            WO_HIP(hipGetDevice(&dev)); WO_HIP(hipGetDeviceProperties(&prop, dev));
+                            flowBlocks = std::max(1, std::min(perCu, 8) - 1) * prop.multiProcessorCount;
+                        }
+                        static const int32_t flowWatch = getenv("WO_CARVE_FLOW_WATCH") ? atoi(getenv("WO_CARVE_FLOW_WATCH")) : 1;
+                        static const int32_t flowSleep = getenv("WO_CARVE_FLOW_SLEEP") ? atoi(getenv("WO_CARVE_FLOW_SLEEP")) : 0;
+                        static const long long flowBudget = (getenv("WO_CARVE_FLOW_BUDGET_MS") ? atoll(getenv("WO_CARVE_FLOW_BUDGET_MS")) : 200) * 100000ll;   // 100 MHz ticks
+                        launch(p, FAM_CARVE_ROUND, k_carve_flow, std::min(grid, flowBlocks), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget, flowWatch, flowSleep);
+                        ++k;
+                        const int32_t fin = read_count(p, done);
+                        allDone = fin >= active;
+                        if (!allDone) ++carveFlowLeft;
+                    }
+                    for (; !allDone;) {
                         for (int b = 0; b < burst; ++b, ++k)
                             launch(p, FAM_CARVE_ROUND, k_carve_round_static, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), (int32_t)k, gCarve, gConv, gStrength, done);
                         if (read_count(p, done) >= active) break;
@@ -839,7 +895,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 F.solveLean = 1;
                 WO_HIP(hipMemsetAsync(p->d_out, 0, (size_t)L * sizeof(SolveOut), s));       // the outputs' tags, cleared in one sweep instead of one scattered 16-byte write per task
             }
-            launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
+            // WO_SETUP_BATCHED=0: the setup that decides load by load (solve_setup_cell) instead of k_solve_setup_batched
+            static const bool setupBatched = !(getenv("WO_SETUP_BATCHED") && atoi(getenv("WO_SETUP_BATCHED")) == 0);
+            if (setupBatched && F.ev) {
+                if (F.slotOf) launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<true>, gridL, WO_BLOCK, F);
+                else launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<false>, gridL, WO_BLOCK, F);
+            } else
+                launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
                 const int64_t r = run_solve_patches(p, F, K, m, dt, basin);
                 if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
@@ -884,7 +946,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
-                     {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"flood_stage_ms", floodHostMs},
+                     {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"carve_flow_launches_with_leftovers", (double)carveFlowLeft}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
                      {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
                      {"flood_pass1_on_host", (floodRun.usedDevice && !floodRun.fellBack) ? 0.0 : 1.0},

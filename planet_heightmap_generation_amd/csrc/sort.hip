@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -64,6 +65,20 @@ void sort_by_level(wo_planet* p) {
     WO_HIP(hipStreamSynchronize(s));
 }
 
+// the active carve tasks in landCells order: the cells of the current order whose arank is set, order kept (stable selection)
+struct CarveActive {
+    const int32_t* arank;
+    __device__ bool operator()(const int32_t& r) const { return arank[r] != WO_NOT_DONE; }
+};
+void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount) {
+    size_t bytes = p->sortTempBytes;
+    hipStream_t s = p->ctx->stream;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+    WO_HIP(hipcub::DeviceSelect::If(p->d_sortTemp, bytes, (const int32_t*)p->d_land[p->landCur], out, outCount, p->L, CarveActive{arank}, s));
+    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_CARVE_SETUP, a, b}); }
+}
+
 size_t sort_temp_bytes(int32_t n) {
     size_t bytes = 0;
     hipcub::DoubleBuffer<uint32_t> k(nullptr, nullptr);
@@ -72,7 +87,9 @@ size_t sort_temp_bytes(int32_t n) {
     size_t bytes2 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
                                              (int32_t*)nullptr, n, 0, WO_LEVEL_BITS, nullptr);
-    return bytes > bytes2 ? bytes : bytes2;
+    size_t bytes3 = 0;
+    (void)hipcub::DeviceSelect::If(nullptr, bytes3, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, n, CarveActive{nullptr}, nullptr);
+    return std::max(bytes, std::max(bytes2, bytes3));
 }
 
 // diagnostic (WO_SORT_STATS=1): how far does a cell move in the order from one sort to the next?  rank[] still holds the previous
