@@ -91,7 +91,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_jump(const int32_t* __restri
     for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < L; s += gridDim.x * blockDim.x) {
         const int32_t j = basin_root(J, s);
         __atomic_store_n(&J[s], j, __ATOMIC_RELAXED);
-        keyOfCell[slotCell[s]] = (uint32_t)j >> shift;
+        keyOfCell[slotCell ? slotCell[s] : s] = (uint32_t)j >> shift;      // slotCell == nullptr: slot == cell id
     }
 }
 // thread i: the i-th cell in processing order (largest rank first)
@@ -318,8 +318,8 @@ static int basin_range() {
 
 // Group-major store order for this pass (d_basinSlot) and the sorted group keys (d_keys[1]).  Call after the receivers
 // pass (F.tr) and before k_solve_setup; everything is enqueued on the planet's stream, no host sync.
-void basin_layout(wo_planet* p) {
-    const int32_t N = p->N, L = p->L;
+void basin_alloc(wo_planet* p) {
+    const int32_t N = p->N;
     hipStream_t s = cur_stream(p);
     if (!p->d_basinJ) {
         WO_HIP(hipMalloc((void**)&p->d_basinJ, (size_t)N * 4));
@@ -329,14 +329,23 @@ void basin_layout(wo_planet* p) {
         WO_HIP(hipMalloc((void**)&p->d_basinRange, ((size_t)N / 64 + 4) * 4));
         WO_HIP(hipMemsetAsync(p->d_basinSlot, 0xff, (size_t)N * 4, s));
     }
+}
+
+// jFromReceivers: J already holds the start state (k_receivers_flow_init, Fields::basinJ; pairs of cells draining into each other
+// are rings of two there, which the search cuts like any ring: at the smaller slot, as k_basin_init does).  slotIdentity: a land
+// cell's Morton slot is its id (land-first mirror).
+void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
+    const int32_t L = p->L;
+    hipStream_t s = cur_stream(p);
+    basin_alloc(p);
     const Fields F = p->fields();
     int bitsL = 1;
     while (((int64_t)1 << bitsL) < (int64_t)L) ++bitsL;
     static const int keyBits = getenv("WO_BASIN_KEY_BITS") ? std::max(8, std::min(30, atoi(getenv("WO_BASIN_KEY_BITS")))) : 16;
     const int shift = bitsL > keyBits ? bitsL - keyBits : 0;
     const int grid = blocks_for(L, 1 << 16);
-    launch(p, FAM_BASIN, k_basin_init, grid, WO_BLOCK, F, (const int32_t*)p->d_patchOrder, (const int32_t*)p->d_slotOf, p->d_basinJ, L);
-    launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
+    if (!jFromReceivers) launch(p, FAM_BASIN, k_basin_init, grid, WO_BLOCK, F, (const int32_t*)p->d_patchOrder, (const int32_t*)p->d_slotOf, p->d_basinJ, L);
+    launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, slotIdentity ? (const int32_t*)nullptr : (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
     launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
            (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0));
     {

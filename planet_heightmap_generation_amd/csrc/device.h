@@ -201,7 +201,8 @@ void rank_from_land(wo_planet* p);
 void sort_by_level(wo_planet* p);
 void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount);   // carve tasks in landCells order
 // basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it
-void basin_layout(wo_planet* p);
+void basin_alloc(wo_planet* p);
+void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity);
 void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending);
 void basin_free(wo_planet* p);
 

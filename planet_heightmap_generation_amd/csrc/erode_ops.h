@@ -111,6 +111,8 @@ struct Fields {
     double solveK, solveM, solveDt;     // the pass's constants (K, m, dt): solve_setup folds them into SolveTask::factor
     int32_t solveLean;                  // 1: solve_setup writes the task record only — the outputs were cleared by a memset and the blocker hints are
                                         //    made from the records if a launch ever leaves tasks pending (basin-local solve: 20 of the 68 scattered bytes per task)
+    int32_t* basinJ;                    // basin layout (basin.hip): the receivers pass leaves the start state of the component search here — J[slot of r] = slot of
+    const int32_t* basinMslot;          //    r's land receiver, or r's own slot; basinMslot: Morton slot of a cell, nullptr: slot == cell id (land-first mirror).  nullptr: off
     int32_t* blk;                       // patch solve: granule that was seen unresolved when the task last failed, or -1 [N], at the store index
     EventList* ev;                      // events per location [N] (land entries written by flow_final_cell); nullptr: row scans
     int32_t* doneAt;                    // glacial rounds: round in which the task finished, WO_NOT_DONE before [N]

@@ -227,6 +227,11 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
         F.accA[r] = a; F.jumpA[r] = j; F.accCnt[r] = 1ull;
         if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
+        if (F.basinJ) {                                      // start state of the drainage-component search (basin.hip: k_basin_init's job, one launch less on the layout's chain)
+            const bool landT = t >= 0 && !F.ocean[t];
+            const int32_t sr = F.basinMslot ? F.basinMslot[r] : r;
+            F.basinJ[sr] = landT ? (F.basinMslot ? F.basinMslot[t] : t) : sr;
+        }
     }
 }
 // Flow accumulation, part 1: rake.  Subtree sizes are integers, so any order of the additions is exact.  Most land

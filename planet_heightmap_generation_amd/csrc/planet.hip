@@ -823,14 +823,20 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (gNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             F.solveK = K; F.solveM = m; F.solveDt = dt;
+            const bool basin = basinSolve && p->patchVersion >= 0;
+            // the receivers pass also leaves the start state of the layout's component search (WO_BASIN_INIT=kernel: k_basin_init does)
+            static const bool basinInitKernel = getenv("WO_BASIN_INIT") && std::string(getenv("WO_BASIN_INIT")) == "kernel";
+            const bool basinJFromReceivers = basin && !basinInitKernel;
+            const bool slotIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;          // land-first mirror: a land cell's Morton slot is its id
+            if (basinJFromReceivers) { basin_alloc(p); F.basinJ = p->d_basinJ; F.basinMslot = slotIdentity ? nullptr : p->d_slotOf; }
             clk.begin("receivers");
             launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();
+            F.basinJ = nullptr;
             // basin-local solve (basin.hip): this pass's store order groups every drainage component with everything it depends on.
             // The layout needs the receivers only and touches none of the flow accumulation's arrays, and both are chains of
             // latency-bound launches that leave most of the chip idle: the layout runs on the planet's side stream beside the flow
             // accumulation and the solve's setup waits for both (WO_BASIN_OVERLAP=0: one after the other on the main stream).
-            const bool basin = basinSolve && p->patchVersion >= 0;
             static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
             if (basin && basinOverlap) {
                 if (!p->side) {
@@ -840,7 +846,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 WO_HIP(hipEventRecord(p->evFork, s));
                 WO_HIP(hipStreamWaitEvent(p->side, p->evFork, 0));
                 p->onSide = true;
-                try { basin_layout(p); } catch (...) { p->onSide = false; throw; }
+                try { basin_layout(p, basinJFromReceivers, slotIdentity); } catch (...) { p->onSide = false; throw; }
                 p->onSide = false;
                 WO_HIP(hipEventRecord(p->evJoin, p->side));
             }
@@ -890,7 +896,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.end();
             clk.begin("solve");
             if (basin) {
-                if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p);
+                if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p, basinJFromReceivers, slotIdentity);
                 F.slotOf = p->d_basinSlot;
                 F.solveLean = 1;
                 WO_HIP(hipMemsetAsync(p->d_out, 0, (size_t)L * sizeof(SolveOut), s));       // the outputs' tags, cleared in one sweep instead of one scattered 16-byte write per task
