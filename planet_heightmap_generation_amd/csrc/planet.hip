@@ -719,14 +719,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             launch(p, FAM_ICE_RECV, k_ice_receivers, gridN, WO_BLOCK, F);
             // ice accumulation: one launch in which the last donor to arrive runs its receiver's task (k_ice_climb);
             // WO_ICE_ROUNDS=1: the synchronous rounds of earlier builds (cross-check)
-            static const bool iceRoundsEnv = getenv("WO_ICE_ROUNDS") && atoi(getenv("WO_ICE_ROUNDS")) != 0;
+            const bool iceRoundsEnv = getenv("WO_ICE_ROUNDS") && atoi(getenv("WO_ICE_ROUNDS")) != 0;     // read per glacial step (tests switch it)
             if (!iceRoundsEnv) { launch(p, FAM_ICE_ROUND, k_ice_climb, gridL, WO_BLOCK, F, F.blocker); ++iceRounds; }
             else iceRounds += run_rounds(p, p->d_landIdx, L, false, 8,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
                 });
             // WO_CARVE_FLOW=0: no one-launch carve (k_carve_flow), activation list in arrival order as in earlier builds
-            static const bool carveFlow = !(getenv("WO_CARVE_FLOW") && atoi(getenv("WO_CARVE_FLOW")) == 0);
+            const bool carveFlow = !(getenv("WO_CARVE_FLOW") && atoi(getenv("WO_CARVE_FLOW")) == 0);
             if (carveFlow) {
                 launch(p, FAM_CARVE_SETUP, k_carve_setup_cells, gridN, WO_BLOCK, F);
                 select_active_by_rank(p, F.arank, p->d_listB, p->d_counters + 3);     // the active tasks in landCells order
@@ -788,7 +788,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                         }
                         static const int32_t flowWatch = getenv("WO_CARVE_FLOW_WATCH") ? atoi(getenv("WO_CARVE_FLOW_WATCH")) : 1;
                         static const int32_t flowSleep = getenv("WO_CARVE_FLOW_SLEEP") ? atoi(getenv("WO_CARVE_FLOW_SLEEP")) : 0;
-                        static const long long flowBudget = (getenv("WO_CARVE_FLOW_BUDGET_MS") ? atoll(getenv("WO_CARVE_FLOW_BUDGET_MS")) : 200) * 100000ll;   // 100 MHz ticks
+                        const long long flowBudget = (getenv("WO_CARVE_FLOW_BUDGET_MS") ? atoll(getenv("WO_CARVE_FLOW_BUDGET_MS")) : 200) * 100000ll;   // 100 MHz ticks
                         launch(p, FAM_CARVE_ROUND, k_carve_flow, std::min(grid, flowBlocks), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget, flowWatch, flowSleep);
                         ++k;
                         const int32_t fin = read_count(p, done);

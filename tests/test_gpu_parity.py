@@ -646,3 +646,38 @@ def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch)
     assert pl.last_erode_stats()["solve_basin_passes_with_leftovers"] == 0
     assert np.array_equal(got, ref)
     pl.close()
+
+
+def test_glacial_step_routes_agree(TP, oracle, monkeypatch):
+    """The glacial step's two dependency walks run as ONE launch each: the ice accumulation by last-arriver climb (k_ice_climb),
+    the carve turns by agent-scope flag hand-offs between the tasks' own threads (k_carve_flow).  Both must give the oracle's
+    field bit for bit, and so must (i) the synchronous rounds they replace (WO_ICE_ROUNDS=1 WO_CARVE_FLOW=0) and (ii) the mixed
+    case in which the one-launch carve gives up at once (budget 0 ms: every lane that finds a dependency open leaves its task)
+    and the rounds finish from whatever state it left."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(300000, 0.75, 6)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(6)
+    e0 = pl.download()
+    oc = (e0 <= 0).astype(np.uint8)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    args = (6, 3e-4, 0.5, 1.0, 6, 1.16, 0.015, 4, 0.8)
+    ref = oracle.erode_composite(om, e0, xyz, oc, *args, nd)
+    got = e0.copy(); pl.erode_composite(got, oc, *args)
+    st = pl.last_erode_stats()
+    assert st["carve_active_total"] > 1000, st                 # the case does carve
+    assert st["carve_flow_launches_with_leftovers"] == 0, st
+    assert st["carve_rounds_total"] == 4 and st["ice_rounds_total"] == 4, st      # one launch per glacial step
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    monkeypatch.setenv("WO_ICE_ROUNDS", "1"); monkeypatch.setenv("WO_CARVE_FLOW", "0")
+    got = e0.copy(); pl.erode_composite(got, oc, *args)
+    st = pl.last_erode_stats()
+    assert st["carve_rounds_total"] > 4 and st["ice_rounds_total"] > 4, st
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    monkeypatch.delenv("WO_ICE_ROUNDS"); monkeypatch.delenv("WO_CARVE_FLOW")
+    monkeypatch.setenv("WO_CARVE_FLOW_BUDGET_MS", "0")
+    got = e0.copy(); pl.erode_composite(got, oc, *args)
+    st = pl.last_erode_stats()
+    assert st["carve_flow_launches_with_leftovers"] > 0, st
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    pl.close()
