@@ -111,7 +111,7 @@ struct wo_planet {
     float *d_cellDist = nullptr, *d_flow = nullptr;
     wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; int32_t *d_haloSend = nullptr, *d_haloRecv = nullptr; float *d_haloBuf = nullptr, *h_haloBuf = nullptr; int32_t nHaloSend = 0, nHaloRecv = 0;   // banded Jacobi passes
     int32_t* d_flowCnt = nullptr; wo::TargetRank* d_tr = nullptr; wo::EventList* d_ev = nullptr; float* d_me = nullptr;
-    int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; int2* d_carvePairs[2] = {nullptr, nullptr}; wo::CarveRec* d_carveRecs = nullptr; int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
+    int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; int2* d_carvePairs[2] = {nullptr, nullptr}; wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
     uint32_t *d_acc = nullptr, *d_snap = nullptr; unsigned long long* d_accCnt = nullptr;
     int32_t *d_jump = nullptr, *d_nj = nullptr;
     int32_t* d_doneAt = nullptr;

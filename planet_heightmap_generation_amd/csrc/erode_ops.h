@@ -1146,19 +1146,25 @@ WO_HD inline bool carve_task_eager(const Fields& F, int32_t r, int32_t slot, int
 // task (built once per step next to the dependency list): a round then is record -> {dependencies' tags, heights} -> stores.
 struct alignas(16) CarveRec { int32_t r, depCnt, deg; float fl; int32_t up, pad_[3]; double deepening, bonus; int32_t nbs[WO_EAGER_ROW]; float dist[WO_EAGER_ROW]; int32_t deps[WO_CARVE_DEPS]; };
 static_assert(sizeof(CarveRec) == 240, "CarveRec layout");
+// k_carve_granules (kernels_impl.h): the tag each granule a task reads must carry before its turn — tag[k]: neighbour k (-1: past the
+// row's end or ocean, not read), tag[WO_EAGER_ROW]: the cell itself; myTag: what the task's own stores carry
+struct alignas(16) CarveExpect { int32_t tag[WO_EAGER_ROW + 1]; int32_t myTag; int32_t pad_[2]; };
+static_assert(sizeof(CarveExpect) == 64, "CarveExpect layout");
 // deepening / bonus: the two pow() terms of the turn (js/terrain-post.js:510,522) — functions of the task's ice flow alone, so they
 // are worked out here, once, instead of on the critical path of a round (a round lasts as long as its slowest task, and a
 // double-precision pow is a few hundred dependent instructions)
-WO_HD inline void carve_record_cell(const Fields& F, int32_t r, int32_t slot, CarveRec* recs, double gCarveRate, double gConvergenceBonus, double glacialStrength) {
+// withDeps: 2 = dependency list in descending rank (k_carve_flow), 1 = as listed (the rounds), 0 = none (k_carve_granules does not read it; should
+// that launch leave tasks to the rounds, the records are made again with their lists)
+WO_HD inline void carve_record_cell(const Fields& F, int32_t r, int32_t slot, CarveRec* recs, double gCarveRate, double gConvergenceBonus, double glacialStrength, int withDeps = 2) {
     CarveRec R;
     const int32_t jb = F.off[r], deg = F.off[r + 1] - jb;
-    R.r = r; R.depCnt = F.carveDepCnt[slot]; R.deg = deg; R.fl = F.iceFlow[r]; R.up = F.iceUp[r]; R.pad_[0] = R.pad_[1] = R.pad_[2] = 0;
+    R.r = r; R.depCnt = withDeps ? F.carveDepCnt[slot] : 0; R.deg = deg; R.fl = F.iceFlow[r]; R.up = F.iceUp[r]; R.pad_[0] = R.pad_[1] = R.pad_[2] = 0;
     { const double fl = R.fl; R.deepening = gCarveRate * pow(fl, 0.6) * glacialStrength; R.bonus = gConvergenceBonus * pow(fl, 0.4); }
     for (int k = 0; k < WO_EAGER_ROW; ++k) { R.nbs[k] = k < deg ? F.adj[jb + k] : r; R.dist[k] = k < deg ? F.dist[jb + k] : 1.0f; }
     for (int k = 0; k < WO_CARVE_DEPS; ++k) R.deps[k] = (R.depCnt >= 0 && k < R.depCnt) ? F.carveDeps[(size_t)slot * WO_CARVE_DEPS + k] : r;
     // highest rank first: the dependency closest to the task in rank tends to finish last, and the one-launch carve (k_carve_flow)
     // watches the first open entry instead of polling all of them (the order of the list means nothing to the rounds)
-    for (int a = 1; a < R.depCnt; ++a) {
+    for (int a = 1; withDeps == 2 && a < R.depCnt; ++a) {
         const int32_t c = R.deps[a], rc = F.arank[c];
         int b = a - 1;
         while (b >= 0 && F.arank[R.deps[b]] < rc) { R.deps[b + 1] = R.deps[b]; --b; }

@@ -895,9 +895,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_deps(Fields F, const int32_t
     WO_GRID_STRIDE(i, n) { const int32_t r = list[i]; carveSlot[r] = i; carve_deps_cell(F, r, i); }
 }
 // per-task records of the static rounds (after k_carve_deps) and their slot-indexed round tags
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_records(Fields F, const int32_t* list, const int32_t* count, CarveRec* recs, int32_t* slotDone, double gCarve, double gConv, double gStrength) {
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_records(Fields F, const int32_t* list, const int32_t* count, CarveRec* recs, int32_t* slotDone, double gCarve, double gConv, double gStrength,
+                                                             int32_t withDeps, int32_t resetDone) {
     const int32_t n = *count;
-    WO_GRID_STRIDE(i, n) { carve_record_cell(F, list[i], i, recs, gCarve, gConv, gStrength); slotDone[i] = WO_NOT_DONE; }
+    WO_GRID_STRIDE(i, n) { carve_record_cell(F, list[i], i, recs, gCarve, gConv, gStrength, withDeps); if (resetDone) slotDone[i] = WO_NOT_DONE; }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
                                                            int32_t* outCount, int32_t* zeroCount, int32_t round, double gCarve,
@@ -1082,6 +1083,140 @@ __global__ __launch_bounds__(WO_BLOCK, 4) void k_carve_flow(Fields F, const Carv
         }
         if (!__any(active)) break;
         if (longSleep) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(2);
+    }
+    for (int o = 32; o > 0; o >>= 1) finished += __shfl_down(finished, o);
+    if ((threadIdx.x & 63) == 0 && finished) atomicAdd(done, finished);
+}
+// ---- the same launch with the heights as self-validating granules ------------------------------------------------------------------
+// k_carve_flow pays four memory round trips per level of the DAG: the finished task's stores must be acknowledged before its done
+// word goes out, the waiting task's poll must see the word, then it loads the heights, then it stores.  Here a height travels
+// WITH its validity: during the carve every cell's height lives in an 8-byte granule {height, tag}, written by one store, where
+// tag = 1 + rank of the task that wrote it (0: not written yet in this glacial step).  Which task writes a cell x last before task
+// T's turn is static — the highest-ranked active cell below T among x and x's neighbours (the turns that touch x are the active
+// cells of that set, and they touch x in rank order) — so T knows, for each of the <=13 cells it reads, the tag it must see
+// (k_carve_expect).  T polls those granules; when all carry their expected tags it already HAS the values, takes its turn and
+// stores the new granules: no done word, no drain, no second load — a level is one store seen by one poll.
+//  * nothing can overwrite a granule before T has read it: a task U that writes x after T is an active cell of the same set with
+//    a higher rank, so U itself waits for x to carry T's tag (or a later one) — and T writes x only after reading it.
+//  * an 8-byte naturally aligned store is seen whole (MI355X_MICROARCH.md: hand-off granules), so no ordering is needed at all.
+//  * progress, residency, the wave-uniform loop and the bounded spin are k_carve_flow's; a task that gives up leaves its done word
+//    unset, the heights go back into the field (k_carve_unpack) and the synchronous rounds finish the step.
+__device__ inline unsigned long long granule_pack(float v, int32_t tag) { return ((unsigned long long)(uint32_t)tag << 32) | (unsigned long long)__float_as_uint(v); }
+__device__ inline float granule_value(unsigned long long g) { return __uint_as_float((uint32_t)g); }
+__device__ inline int32_t granule_tag(unsigned long long g) { return (int32_t)(g >> 32); }
+__device__ inline unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// tag of the last turn that writes x before the turn of the task with rank myRank (0: none)
+__device__ inline int32_t carve_expected_tag(const Fields& F, int32_t x, int32_t myRank) {
+    int32_t m = -1;
+    { const int32_t a = F.arank[x]; if (a < myRank) m = a; }
+    for (int32_t j = F.off[x]; j < F.off[x + 1]; ++j) { const int32_t a = F.arank[F.adj[j]]; if (a < myRank && a > m) m = a; }
+    return m + 1;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_expect(Fields F, const CarveRec* __restrict__ recs, const int32_t* __restrict__ count, CarveExpect* ex) {
+    const int32_t n = *count;
+    WO_GRID_STRIDE(i, n) {
+        const int32_t r = recs[i].r, deg = recs[i].deg, myRank = F.arank[r];
+        CarveExpect X;
+        X.myTag = myRank + 1; X.pad_[0] = X.pad_[1] = 0;
+        for (int k = 0; k <= WO_EAGER_ROW; ++k) X.tag[k] = -1;
+        if (deg <= WO_EAGER_ROW) {
+            const int32_t b = F.off[r];
+            for (int k = 0; k < deg; ++k) { const int32_t x = F.adj[b + k]; if (!F.ocean[x]) X.tag[k] = carve_expected_tag(F, x, myRank); }
+            X.tag[WO_EAGER_ROW] = carve_expected_tag(F, r, myRank);
+        }
+        ex[i] = X;
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_pack(const float* __restrict__ e, unsigned long long* __restrict__ G, int32_t n) { WO_GRID_STRIDE(i, n) G[i] = granule_pack(e[i], 0); }
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_unpack(const unsigned long long* __restrict__ G, float* __restrict__ e, int32_t n) { WO_GRID_STRIDE(i, n) e[i] = granule_value(G[i]); }
+// rows longer than WO_EAGER_ROW: one non-blocking sweep (expected tags worked out on the spot); true: the turn was taken
+__device__ inline bool carve_granule_turn_long_row(const Fields& F, unsigned long long* G, int32_t r, double deepening, double bonus, int32_t up) {
+    const int32_t myRank = F.arank[r], myTag = myRank + 1;
+    if (granule_tag(ld_agent(&G[r])) != carve_expected_tag(F, r, myRank)) return false;
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        if (!F.ocean[nb] && granule_tag(ld_agent(&G[nb])) != carve_expected_tag(F, nb, myRank)) return false;
+    }
+    float er = (float)((double)granule_value(ld_agent(&G[r])) - deepening);
+    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
+        const int32_t nb = F.adj[j];
+        if (F.ocean[nb]) continue;
+        const double d = nd_or_eps(F.dist[j]);
+        const float en = granule_value(ld_agent(&G[nb]));
+        const double slope = fabs((double)er - (double)en) / d;
+        double f = 1 - slope;
+        if (!(f > 0)) f = (f != f) ? f : 0;
+        st_agent(&G[nb], granule_pack((float)((double)en - deepening * 0.4 * f), myTag));
+    }
+    if (up >= 2) er = (float)((double)er - bonus);
+    st_agent(&G[r], granule_pack(er, myTag));
+    return true;
+}
+__global__ __launch_bounds__(WO_BLOCK, 4) void k_carve_granules(Fields F, const CarveRec* __restrict__ recs, const CarveExpect* __restrict__ expect, unsigned long long* G,
+                                                              int32_t* slotDone, const int32_t* __restrict__ count, int32_t* done, long long budget) {
+    const int32_t n = *count;
+    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
+    int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    const long long t0 = wall_clock64();
+    int32_t finished = 0;
+    bool active = i < n;
+    // the task's record, the part a turn needs (the dependency list is the rounds')
+    int32_t r = 0, deg = 0, up = 0, nbs[WO_EAGER_ROW]; float dist[WO_EAGER_ROW]; double deepening = 0, bonus = 0;
+    CarveExpect X;
+    float vals[WO_EAGER_ROW + 1];
+    uint32_t pend = 0;
+    auto fetch = [&]() {
+        const CarveRec& R = recs[i];
+        r = R.r; deg = R.deg; up = R.up; deepening = R.deepening; bonus = R.bonus;
+#pragma unroll
+        for (int k = 0; k < WO_EAGER_ROW; ++k) { nbs[k] = R.nbs[k]; dist[k] = R.dist[k]; }
+        X = expect[i];
+        pend = 0;
+#pragma unroll
+        for (int k = 0; k <= WO_EAGER_ROW; ++k) if (X.tag[k] >= 0) pend |= 1u << k;
+    };
+    if (active) fetch();
+    for (;;) {
+        if (active) {
+            bool ran = false;
+            if (deg > WO_EAGER_ROW) ran = carve_granule_turn_long_row(F, G, r, deepening, bonus, up);
+            else {
+                unsigned long long g[WO_EAGER_ROW + 1];
+#pragma unroll
+                for (int k = 0; k <= WO_EAGER_ROW; ++k) g[k] = ((pend >> k) & 1u) ? ld_agent(&G[k < WO_EAGER_ROW ? nbs[k] : r]) : 0ull;
+#pragma unroll
+                for (int k = 0; k <= WO_EAGER_ROW; ++k)
+                    if (((pend >> k) & 1u) && granule_tag(g[k]) == X.tag[k]) { vals[k] = granule_value(g[k]); pend &= ~(1u << k); }
+                if (pend == 0) {
+                    float er = (float)((double)vals[WO_EAGER_ROW] - deepening);
+#pragma unroll
+                    for (int k = 0; k < WO_EAGER_ROW; ++k) {
+                        if (X.tag[k] < 0) continue;                 // past the row's end, or an ocean neighbour
+                        const double d = nd_or_eps(dist[k]);
+                        const double slope = fabs((double)er - (double)vals[k]) / d;
+                        double f = 1 - slope;
+                        if (!(f > 0)) f = (f != f) ? f : 0;
+                        st_agent(&G[nbs[k]], granule_pack((float)((double)vals[k] - deepening * 0.4 * f), X.myTag));
+                    }
+                    if (up >= 2) er = (float)((double)er - bonus);
+                    st_agent(&G[r], granule_pack(er, X.myTag));
+                    ran = true;
+                }
+            }
+            if (ran) {
+                F.doneAt[r] = 1;                                    // for the rounds, should they have to finish the step (read after the launch)
+                slotDone[i] = 1;
+                ++finished;
+                i += stride;
+                active = i < n;
+                if (active) fetch();
+            } else if (wall_clock64() - t0 > budget) {
+                active = false;                                     // left to the synchronous rounds
+            }
+        }
+        if (!__any(active)) break;
+        __builtin_amdgcn_s_sleep(2);
     }
     for (int o = 32; o > 0; o >>= 1) finished += __shfl_down(finished, o);
     if ((threadIdx.x & 63) == 0 && finished) atomicAdd(done, finished);

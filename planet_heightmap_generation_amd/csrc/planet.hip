@@ -726,7 +726,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
                 });
             // WO_CARVE_FLOW=0: no one-launch carve (k_carve_flow), activation list in arrival order as in earlier builds
-            const bool carveFlow = !(getenv("WO_CARVE_FLOW") && atoi(getenv("WO_CARVE_FLOW")) == 0);
+            const int carveFlowMode = getenv("WO_CARVE_FLOW") ? atoi(getenv("WO_CARVE_FLOW")) : 2;      // 2: heights as granules (k_carve_granules), 1: done words (k_carve_flow), 0: rounds
+            const bool carveFlow = carveFlowMode != 0;
             if (carveFlow) {
                 launch(p, FAM_CARVE_SETUP, k_carve_setup_cells, gridN, WO_BLOCK, F);
                 select_active_by_rank(p, F.arank, p->d_listB, p->d_counters + 3);     // the active tasks in landCells order
@@ -738,18 +739,21 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int32_t active = read_count(p, p->d_counters + 3);
                 carveActive += active;
                 if ((int64_t)active > p->carveCap) {
-                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone);
+                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveExpect);
                     p->carveCap = (int64_t)active + active / 4 + 1024;
                     p->d_carveDeps = dalloc<int32_t>((size_t)p->carveCap * WO_CARVE_DEPS);
                     p->d_carveDepCnt = dalloc<int32_t>((size_t)p->carveCap); p->d_carveDepPos = dalloc<int32_t>((size_t)p->carveCap);
-                    p->d_carveRecs = dalloc<CarveRec>((size_t)p->carveCap); p->d_carveSlotDone = dalloc<int32_t>((size_t)p->carveCap);
+                    p->d_carveRecs = dalloc<CarveRec>((size_t)p->carveCap); p->d_carveSlotDone = dalloc<int32_t>((size_t)p->carveCap); p->d_carveExpect = dalloc<CarveExpect>((size_t)p->carveCap);
                     p->d_carvePairs[0] = dalloc<int2>((size_t)p->carveCap); p->d_carvePairs[1] = dalloc<int2>((size_t)p->carveCap);
                 }
                 F.carveDeps = p->d_carveDeps; F.carveDepCnt = p->d_carveDepCnt; F.carveDepPos = p->d_carveDepPos;
-                if (active > 0)
+                // the dependency lists (a two-hop walk per task) are for the done-word launch and the rounds; the granule launch waits on the
+                // heights themselves and makes the lists only if it leaves tasks to the rounds
+                if (active > 0 && carveFlowMode != 2)
                     launch(p, FAM_CARVE_SETUP, k_carve_deps, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveSlot);
                 if (active > 0)
-                    launch(p, FAM_CARVE_SETUP, k_carve_records, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength);
+                    launch(p, FAM_CARVE_SETUP, k_carve_records, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength,
+                           (int32_t)(carveFlowMode == 2 ? 0 : carveFlowMode == 1 ? 2 : 1), (int32_t)1);
             }
             // rounds over {task, blocker} entries (k_carve_round_pairs); counters as in run_rounds: c[k%3] in, c[(k+1)%3] out
             {
@@ -782,18 +786,35 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                         static int flowBlocks = 0;
                         if (!flowBlocks) {
                             int perCu = 0, dev = 0; hipDeviceProp_t prop;
+                            int perCuG = 0;
                             WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_carve_flow, WO_BLOCK, 0));
+                            WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuG, k_carve_granules, WO_BLOCK, 0));
+                            perCu = std::min(perCu, perCuG);
                             WO_HIP(hipGetDevice(&dev)); WO_HIP(hipGetDeviceProperties(&prop, dev));
                             flowBlocks = std::max(1, std::min(perCu, 8) - 1) * prop.multiProcessorCount;
                         }
                         static const int32_t flowWatch = getenv("WO_CARVE_FLOW_WATCH") ? atoi(getenv("WO_CARVE_FLOW_WATCH")) : 1;
                         static const int32_t flowSleep = getenv("WO_CARVE_FLOW_SLEEP") ? atoi(getenv("WO_CARVE_FLOW_SLEEP")) : 0;
                         const long long flowBudget = (getenv("WO_CARVE_FLOW_BUDGET_MS") ? atoll(getenv("WO_CARVE_FLOW_BUDGET_MS")) : 200) * 100000ll;   // 100 MHz ticks
+                        if (carveFlowMode == 2) {
+                            if (!p->d_carveG) p->d_carveG = dalloc<unsigned long long>((size_t)N);
+                            launch(p, FAM_CARVE_SETUP, k_carve_expect, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const int32_t*)(c + 3), p->d_carveExpect);
+                            launch(p, FAM_CARVE_SETUP, k_carve_pack, blocks_for(N, 4096), WO_BLOCK, (const float*)F.e, p->d_carveG, N);
+                            launch(p, FAM_CARVE_ROUND, k_carve_granules, std::min(grid, flowBlocks), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const CarveExpect*)p->d_carveExpect, p->d_carveG,
+                                   p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget);
+                            launch(p, FAM_CARVE_SETUP, k_carve_unpack, blocks_for(N, 4096), WO_BLOCK, (const unsigned long long*)p->d_carveG, F.e, N);
+                        } else
                         launch(p, FAM_CARVE_ROUND, k_carve_flow, std::min(grid, flowBlocks), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget, flowWatch, flowSleep);
                         ++k;
                         const int32_t fin = read_count(p, done);
                         allDone = fin >= active;
-                        if (!allDone) ++carveFlowLeft;
+                        if (!allDone) {
+                            ++carveFlowLeft;
+                            if (carveFlowMode == 2) {          // the rounds want the dependency lists after all
+                                launch(p, FAM_CARVE_SETUP, k_carve_deps, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), p->d_carveSlot);
+                                launch(p, FAM_CARVE_SETUP, k_carve_records, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength, (int32_t)1, (int32_t)0);
+                            }
+                        }
                     }
                     for (; !allDone;) {
                         for (int b = 0; b < burst; ++b, ++k)
@@ -1152,7 +1173,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

@@ -650,7 +650,8 @@ def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch)
 
 def test_glacial_step_routes_agree(TP, oracle, monkeypatch):
     """The glacial step's two dependency walks run as ONE launch each: the ice accumulation by last-arriver climb (k_ice_climb),
-    the carve turns by agent-scope flag hand-offs between the tasks' own threads (k_carve_flow).  Both must give the oracle's
+    the carve turns by agent-scope hand-offs between the tasks' own threads (k_carve_granules: heights as
+    self-validating granules; k_carve_flow: done words).  Both must give the oracle's
     field bit for bit, and so must (i) the synchronous rounds they replace (WO_ICE_ROUNDS=1 WO_CARVE_FLOW=0) and (ii) the mixed
     case in which the one-launch carve gives up at once (budget 0 ms: every lane that finds a dependency open leaves its task)
     and the rounds finish from whatever state it left."""
@@ -674,10 +675,17 @@ def test_glacial_step_routes_agree(TP, oracle, monkeypatch):
     st = pl.last_erode_stats()
     assert st["carve_rounds_total"] > 4 and st["ice_rounds_total"] > 4, st
     assert np.array_equal(got, ref), int((got != ref).sum())
-    monkeypatch.delenv("WO_ICE_ROUNDS"); monkeypatch.delenv("WO_CARVE_FLOW")
-    monkeypatch.setenv("WO_CARVE_FLOW_BUDGET_MS", "0")
-    got = e0.copy(); pl.erode_composite(got, oc, *args)
-    st = pl.last_erode_stats()
-    assert st["carve_flow_launches_with_leftovers"] > 0, st
-    assert np.array_equal(got, ref), int((got != ref).sum())
+    monkeypatch.delenv("WO_ICE_ROUNDS")
+    for mode in ("1", "2"):                # 1: done words (k_carve_flow), 2 (default): heights as self-validating granules (k_carve_granules)
+        monkeypatch.setenv("WO_CARVE_FLOW", mode)
+        monkeypatch.delenv("WO_CARVE_FLOW_BUDGET_MS", raising=False)
+        got = e0.copy(); pl.erode_composite(got, oc, *args)
+        st = pl.last_erode_stats()
+        assert st["carve_flow_launches_with_leftovers"] == 0 and st["carve_rounds_total"] == 4, (mode, st)
+        assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
+        monkeypatch.setenv("WO_CARVE_FLOW_BUDGET_MS", "0")
+        got = e0.copy(); pl.erode_composite(got, oc, *args)
+        st = pl.last_erode_stats()
+        assert st["carve_flow_launches_with_leftovers"] > 0, (mode, st)
+        assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
     pl.close()
