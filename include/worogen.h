@@ -256,7 +256,9 @@ int wo_profile_reset(wo_planet* p);
 int wo_profile_report(wo_planet* p, int32_t cap, const char** names, double* total_ms, int64_t* launches,
                       int32_t* count);
 /* Stage timings of the last erodeComposite call, same {stage, ms} shape the reference ships in
- * _postTiming (js/planet-worker.js:42-93). */
+ * _postTiming (js/planet-worker.js:42-93).  Stages inside the iteration loop are bracketed by events on every
+ * 8th iteration only and scaled to all of them (the brackets themselves cost stream time); setup and the
+ * floods are timed exactly.  WO_STAGE_TIMING=all brackets every iteration. */
 int wo_last_stage_timing(wo_planet* p, int32_t cap, const char** stages, double* ms, int32_t* count);
 /* Counters of the last erodeComposite call (land cells, dependency rounds, ...), for DESIGN/bench. */
 int wo_last_erode_stats(wo_planet* p, int32_t cap, const char** names, double* values, int32_t* count);

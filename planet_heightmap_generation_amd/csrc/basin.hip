@@ -110,7 +110,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_keys(const int32_t* __restri
 __global__ __launch_bounds__(WO_BLOCK) void k_basin_slots(const int32_t* __restrict__ order, const uint32_t* __restrict__ keys, int32_t* __restrict__ slotOf, int32_t L,
                                                            int32_t* rangeStart, int32_t rangeT) {
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < L; q += gridDim.x * blockDim.x) {
-        slotOf[order[q]] = q;
+        if (slotOf) slotOf[order[q]] = q;           // (the in-tree sort's last pass has written it)
         if (q == 0 || keys[q] != keys[q - 1]) atomicMin(&rangeStart[q / rangeT], q);
     }
 }
@@ -348,7 +348,14 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
     launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, slotIdentity ? (const int32_t*)nullptr : (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
     launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
            (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0));
-    {
+    // the in-tree sort (radix.hip; its last pass also writes slotOf[cell] = position); WO_SORT=hipcub: the library sort
+    static const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";
+    int sorted = 1;                                  // which of d_keys / d_basinVals holds the result
+    if (!library) {
+        uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
+        int32_t* const vb[2] = {p->d_basinVals[0], p->d_basinVals[1]};
+        sorted = radix_sort_pairs(p, FAM_BASIN_SORT, kb, vb, L, 0, ((bitsL - shift) + 7) / 8 * 8, p->d_basinSlot, radix_scratch(p, 1), p->N, p->rsFlip[1]);
+    } else {
         hipEvent_t a = nullptr, b = nullptr;
         if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
         size_t bytes = p->sortTempBytes;
@@ -359,7 +366,7 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
     const int rangeT = basin_range();
     const int nRanges = (int)(((int64_t)L + rangeT - 1) / rangeT);
     WO_HIP(hipMemsetAsync(p->d_basinRange, 0x7f, (size_t)(nRanges + 1) * 4, s));
-    launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[1], (const uint32_t*)p->d_keys[1], p->d_basinSlot, L, p->d_basinRange, (int32_t)rangeT);
+    launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[sorted], (const uint32_t*)p->d_keys[sorted], library ? p->d_basinSlot : (int32_t*)nullptr, L, p->d_basinRange, (int32_t)rangeT);
 }
 
 // the one launch of the pass; F.slotOf must be d_basinSlot, patchPending zeroed

@@ -111,7 +111,7 @@ struct wo_planet {
     float *d_cellDist = nullptr, *d_flow = nullptr;
     wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; int32_t *d_haloSend = nullptr, *d_haloRecv = nullptr; float *d_haloBuf = nullptr, *h_haloBuf = nullptr; int32_t nHaloSend = 0, nHaloRecv = 0;   // banded Jacobi passes
     int32_t* d_flowCnt = nullptr; wo::TargetRank* d_tr = nullptr; wo::EventList* d_ev = nullptr; float* d_me = nullptr;
-    int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; int2* d_carvePairs[2] = {nullptr, nullptr}; wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
+    int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; int2* d_carvePairs[2] = {nullptr, nullptr}; uint32_t* d_rs[2] = {nullptr, nullptr}; int rsFlip[2] = {0, 0};   /* radix.hip scratch: elevation sort, basin sort */ wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
     uint32_t *d_acc = nullptr, *d_snap = nullptr; unsigned long long* d_accCnt = nullptr;
     int32_t *d_jump = nullptr, *d_nj = nullptr;
     int32_t* d_doneAt = nullptr;
@@ -199,6 +199,11 @@ void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
 void rank_from_land(wo_planet* p);
 void sort_by_level(wo_planet* p);
+// radix.hip: the in-tree stable radix sort (scratch: radix_scratch_words(nMax) u32, zero before the first use; flip: call parity kept by the caller)
+size_t radix_scratch_words(int32_t nMax);
+int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t* const vals[2], int32_t n, int beginBit, int endBit, int32_t* posOut,
+                     uint32_t* scratch, int32_t nMax, int& flip);
+uint32_t* radix_scratch(wo_planet* p, int which);      // 0: elevation sort, 1: basin sort (allocated and cleared on first use)
 void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount);   // carve tasks in landCells order
 // basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it
 void basin_alloc(wo_planet* p);

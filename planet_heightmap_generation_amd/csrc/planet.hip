@@ -304,11 +304,23 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
     return need;
 }
 
+// Stage timings (wo_last_stage_timing, the reference's _postTiming).  A pair of event records costs ~10 us of stream time, and the
+// composite loop has five stages per iteration (a 1.6 ms iteration: 8 ms of a 460 ms step went into timing it), so inside the loop
+// only every 8th iteration is bracketed (`on`) and a stage's sum is scaled by occurrences / bracketed occurrences; stages outside
+// the loop (setup, floods) are always bracketed.  WO_STAGE_TIMING=all, or per-launch profiling, brackets every iteration.
 struct StageClock {
     wo_planet* p; std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
+    std::map<std::string, std::pair<int64_t, int64_t>> seen;      // stage -> {occurrences, bracketed}
+    bool on = true, open = false;
     explicit StageClock(wo_planet* pl) : p(pl) {}
-    void begin(const char* name) { hipEvent_t a = profile_event(p), b = profile_event(p); WO_HIP(hipEventRecord(a, p->ctx->stream)); ev.push_back({name, {a, b}}); }
-    void end() { WO_HIP(hipEventRecord(ev.back().second.second, p->ctx->stream)); }
+    void begin(const char* name) {
+        auto& c = seen[name]; ++c.first;
+        open = on;
+        if (!on) return;
+        ++c.second;
+        hipEvent_t a = profile_event(p), b = profile_event(p); WO_HIP(hipEventRecord(a, p->ctx->stream)); ev.push_back({name, {a, b}});
+    }
+    void end() { if (open) WO_HIP(hipEventRecord(ev.back().second.second, p->ctx->stream)); open = false; }
     void finish() {
         WO_HIP(hipStreamSynchronize(p->ctx->stream));
         std::map<std::string, double> acc; std::vector<std::string> order;
@@ -319,7 +331,7 @@ struct StageClock {
             p->eventPool.push_back(e.second.first); p->eventPool.push_back(e.second.second);
         }
         p->stageTiming.clear();
-        for (auto& n : order) p->stageTiming.push_back({n, acc[n]});
+        for (auto& n : order) { const auto& c = seen[n]; p->stageTiming.push_back({n, acc[n] * (c.second > 0 ? (double)c.first / (double)c.second : 1.0)}); }
     }
 };
 
@@ -708,8 +720,11 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     int64_t basinPasses = 0, basinLeftoverPasses = 0, carveActive = 0;
     int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
+    static const bool stageAll = getenv("WO_STAGE_TIMING") && std::string(getenv("WO_STAGE_TIMING")) == "all";
     for (int32_t iter = 0; iter < total; ++iter) {
+        clk.on = true;
         if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
+        clk.on = stageAll || p->profiling || total <= 16 || iter % 8 == 0;
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
         if (gNow || hNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
 
@@ -959,6 +974,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.end();
         }
     }
+    clk.on = true;
     if (glacial) {
         clk.begin("glacial_blend");
         launch(p, FAM_GLAC_BLEND, k_glacial_blend, gridN, WO_BLOCK, p->fields(), (const float*)p->d_e, p->d_e2);
@@ -1173,7 +1189,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <string>
 #include <cstdlib>
 
 #include "device.h"
@@ -107,17 +108,30 @@ void sort_land_by_elevation(wo_planet* p) {
     const int cur = p->landCur;
     launch(p, FAM_SORT_KEYS, k_sort_keys, blocks_for(L, 4096), WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_land[cur],
            p->d_keys[0], L);
-    hipcub::DoubleBuffer<uint32_t> k(p->d_keys[0], p->d_keys[1]);
-    hipcub::DoubleBuffer<int32_t> v(p->d_land[cur], p->d_land[cur ^ 1]);
     hipStream_t s = p->ctx->stream;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
-    size_t bytes = p->sortTempBytes;
-    // (11-bit digits — three passes instead of four, rocPRIM's onesweep with the `match` ranking — were measured: 180 us per pass
-    // against 32 us, profiles/r03aj_*; the library default stays)
-    WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, k, v, L, 0, 32, s));
-    p->landCur = (v.Current() == p->d_land[cur]) ? cur : (cur ^ 1);
-    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_SORT_RADIX, a, b}); }
+    // WO_SORT=hipcub: the library sort + the rank scatter of earlier builds; default: the in-tree sort (radix.hip), whose last pass
+    // also writes rank[cell] = position
+    static const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";
+    static const bool stats0 = getenv("WO_SORT_STATS") != nullptr;
+    bool rankWritten = false;
+    if (!library) {
+        uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
+        int32_t* const vb[2] = {p->d_land[cur], p->d_land[cur ^ 1]};
+        const int r = radix_sort_pairs(p, FAM_SORT_RADIX, kb, vb, L, 0, 32, stats0 ? (int32_t*)nullptr : p->d_rank, radix_scratch(p, 0), p->N, p->rsFlip[0]);
+        p->landCur = r == 0 ? cur : (cur ^ 1);
+        rankWritten = !stats0;
+    } else {
+        hipcub::DoubleBuffer<uint32_t> k(p->d_keys[0], p->d_keys[1]);
+        hipcub::DoubleBuffer<int32_t> v(p->d_land[cur], p->d_land[cur ^ 1]);
+        hipEvent_t a = nullptr, b = nullptr;
+        if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+        size_t bytes = p->sortTempBytes;
+        // (11-bit digits — three passes instead of four, rocPRIM's onesweep with the `match` ranking — were measured: 180 us per pass
+        // against 32 us, profiles/r03aj_*)
+        WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, k, v, L, 0, 32, s));
+        if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_SORT_RADIX, a, b}); }
+        p->landCur = (v.Current() == p->d_land[cur]) ? cur : (cur ^ 1);
+    }
     static const bool stats = getenv("WO_SORT_STATS") != nullptr;
     if (stats) {
         unsigned long long* d_h = nullptr; unsigned long long h[33];
@@ -129,7 +143,7 @@ void sort_land_by_elevation(wo_planet* p) {
         for (int b = 0; b < 24; ++b) fprintf(stderr, " %llu", h[b]);
         fprintf(stderr, "\n");
     }
-    launch(p, FAM_RANK, k_rank_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, L);
+    if (!rankWritten) launch(p, FAM_RANK, k_rank_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, L);
 }
 
 }  // namespace wo
