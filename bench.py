@@ -45,11 +45,11 @@ sys.path.insert(0, str(REPO))
 # that only exists because of how the pass is implemented here — the basin layout, its sort — gets 0 bytes: its time still
 # counts in the pass).  (per land cell, per cell) per launch of the pass.
 PASSES = {
-    "sort":      {"budget": (8.0, 0.0),   "kernels": {"sort_keys": (2.0, 0.0), "sort_radix(hipcub)": (4.0, 0.0), "rank_scatter": (2.0, 0.0)}},
+    "sort":      {"budget": (8.0, 0.0),   "kernels": {"sort_keys": (2.0, 0.0), "sort_radix": (6.0, 0.0), "rank_scatter": (0.0, 0.0)}},
     "receivers": {"budget": (68.0, 4.0),  "kernels": {"receivers": (68.0, 4.0)}},
     "flow":      {"budget": (16.0, 4.0),  "kernels": {"flow_snap": (8.0, 0.0), "flow_final": (8.0, 4.0), "flow_init": (0.0, 0.0), "flow_apply": (0.0, 0.0)}},
     "solve":     {"budget": (45.0, 0.0),  "kernels": {"solve_setup": (33.0, 0.0), "solve_basin": (8.0, 0.0), "solve_patch": (8.0, 0.0), "solve_round": (8.0, 0.0),
-                                                       "solve_tail": (0.0, 0.0), "solve_final": (4.0, 0.0), "basin_layout": (0.0, 0.0), "basin_sort(hipcub)": (0.0, 0.0),
+                                                       "solve_tail": (0.0, 0.0), "solve_final": (4.0, 0.0), "basin_layout": (0.0, 0.0), "basin_sort": (0.0, 0.0),
                                                        "level_sort": (0.0, 0.0), "river_order": (0.0, 0.0)}},
     "thermal":   {"budget": (106.0, 4.0), "kernels": {"thermal_excess": (45.0, 0.0), "thermal_apply": (61.0, 4.0)}},
 }
@@ -58,11 +58,11 @@ for _p in PASSES.values():      # (solve_basin / solve_patch / solve_round are a
     assert (sum(v[0] for k, v in _p["kernels"].items() if k not in ("solve_patch", "solve_round")), max(v[1] for v in _p["kernels"].values())) == _p["budget"], _p
 # one-off stages and the glacial iterations: bytes per launch of the whole stage
 ONE_OFF = {"soil_creep": (82.0 * 0.8, 4.0), "warp_terrain": (0.0, 20.0 + 100.0 * 24)}      # creep: 82 B per interior-land cell; warp: ~20 + 100 x hops B/cell, ~24 hops at 10M
-GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend")
+GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend")      # ice_round: k_ice_climb, carve_round: k_carve_granules (one launch each per glacial step)
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload at the full iteration count (separate passes;
 # profiles/collect_pmc.sh); used for roofline.traffic of the dominant kernel unless WO_BENCH_PMC=1 asks for a live collection.
 PMC_FILE = REPO / "profiles" / "r03_pmc_fetch_write_per_kernel_10m_200iters.json"
-FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": "wo::k_solve_setup",
+FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": ("void wo::k_solve_setup_batched<true>", "wo::k_solve_setup"), "sort_radix": "wo::k_rs_scatter",
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
                  "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_snap": "wo::k_flow_climb", "carve_round": "wo::k_carve_round_pairs",
                  "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_coop", "wo::k_solve_stream")}

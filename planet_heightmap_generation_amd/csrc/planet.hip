@@ -24,9 +24,9 @@ namespace wo {
 
 const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
-    "ocean_from_elevation", "sort_keys", "sort_radix(hipcub)", "rank_scatter", "receivers", "flow_init", "flow_snap",
+    "ocean_from_elevation", "sort_keys", "sort_radix", "rank_scatter", "receivers", "flow_init", "flow_snap",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort(hipcub)", "solve_basin", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort", "solve_basin", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -876,7 +876,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
             if (basin && basinOverlap) {
                 if (!p->side) {
-                    WO_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+                    // the layout's chain of short launches is the longer of the two: at equal priority its workgroups queue behind the thousands of
+                    // the flow kernels' (a 22 us scatter pass took 108 us beside k_flow_final), so the side stream gets the highest priority
+                    int prLeast = 0, prGreatest = 0;
+                    WO_HIP(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+                    static const bool sidePriority = !(getenv("WO_SIDE_PRIORITY") && atoi(getenv("WO_SIDE_PRIORITY")) == 0);
+                    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, sidePriority ? prGreatest : prLeast));
                     WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
                 }
                 WO_HIP(hipEventRecord(p->evFork, s));
