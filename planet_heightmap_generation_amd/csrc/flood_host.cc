@@ -495,7 +495,8 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
                 else { if (nOpen) ++nNested; ++nGroups; ++famCounter; groups[nOpen++] = TieGroup{kc, famCounter, famCounter}; }
             }
         }
-        {
+        static const bool noPrefetch = std::getenv("WO_FLOOD_NOPREFETCH") != nullptr;
+        if (!noPrefetch) {
             const size_t lim2 = heap.n < 7 ? heap.n : 7;
             for (size_t q = 0; q < lim2; ++q) {
                 const int32_t cc = hp[q].cell;

@@ -298,14 +298,18 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_climb(Fields F, const int32_t
         int32_t d = r;
         if (!(donorCnt[d] == 0 && F.jumpA[d] >= 0)) continue;
         unsigned long long v = 1;                                 // a leaf's total
+        int32_t j = F.jumpA[d];
         for (int32_t step = 0; step < cap; ++step) {
-            const int32_t j = F.jumpA[d];
-            const int32_t donors = donorCnt[j];                   // fixed since the receivers pass
+            // a hop is two round trips: {the receiver's donor count, ITS receiver, the hand-over atomic} go out together (the first two
+            // are fixed since the receivers pass: reading them before the hand-over is decided costs nothing), then the next hop's
+            const int32_t donors = donorCnt[j];
+            const int32_t jj = F.jumpA[j];                        // only -2 ("retired") is ever written here, by the thread that retires j: not before this hop's atomic
             const unsigned long long old = atomicAdd(&F.accCnt[j], (1ull << 32) | v);
             F.jumpA[d] = -2;                                      // retired
             if ((int32_t)(old >> 32) + 1 != donors) break;        // other donors of j are still out
-            if (F.jumpA[j] < 0) break;                            // a root keeps the sum
+            if (jj < 0) break;                                    // a root keeps the sum
             d = j;
+            j = jj;
             v = (old & 0xffffffffull) + v;
         }
     }
@@ -448,9 +452,11 @@ __device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
 // over: the slow path then runs in one partly filled wave per workgroup instead of inside nearly every wave, and no global
 // counter is involved (one returning atomic per wave on a single word was measured to serialise the whole launch: 374 us).
 template <bool SLOT>
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup_batched(Fields F) {
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup_batched(Fields F, int32_t* zeroA, int32_t nA, int32_t* zeroB, int32_t nB) {
     __shared__ int32_t s_deferred[WO_BLOCK];
     __shared__ int32_t s_n;
+    // the solve launch's counters (tasks left pending per patch, per launch) start at zero: cleared here instead of by two launches of their own
+    for (int32_t z = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x); z < nA + nB; z += (int32_t)(gridDim.x * blockDim.x)) { if (z < nA) zeroA[z] = 0; else zeroB[z - nA] = 0; }
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int32_t i = WO_XCD_LAND_BASE() + (int32_t)threadIdx.x;

@@ -244,13 +244,13 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
 // Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
 // basin: the store order is the group-major one of basin_layout() and the first launch of the pass is k_solve_basin, which
 // normally leaves nothing pending; whatever it does leave (layout off: see basin.hip) is finished by k_solve_patch launches.
-static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin) {
+static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin, bool countersCleared = false) {
     hipStream_t s = p->ctx->stream;
     const int np = p->numPatches;
-    launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, basin ? 0 : 1, (int32_t)np);
+    if (!countersCleared) launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, basin ? 0 : 1, (int32_t)np);
     // one pending-total slot per launch, cleared once per pass (a memset per launch was 13.6 k fill kernels per step)
     int32_t* tot = p->d_patchTotals;
-    WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
+    if (!countersCleared) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
     int64_t launches = 0;
     // WO_SOLVE_SPINS: polling passes per visit (kernels_impl.h).  WO_SOLVE_STATS=<n>: per-launch counters of the n-th solve
     // pass of the planet -> stderr (diagnostic).
@@ -944,13 +944,18 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             }
             // WO_SETUP_BATCHED=0: the setup that decides load by load (solve_setup_cell) instead of k_solve_setup_batched
             static const bool setupBatched = !(getenv("WO_SETUP_BATCHED") && atoi(getenv("WO_SETUP_BATCHED")) == 0);
+            bool countersCleared = false;
             if (setupBatched && F.ev) {
-                if (F.slotOf) launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<true>, gridL, WO_BLOCK, F);
-                else launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<false>, gridL, WO_BLOCK, F);
+                // (with the basin solve the setup launch also clears the counters of the solve launch: run_solve_patches' countersCleared)
+                int32_t* zA = basin ? p->d_patchPending : nullptr; const int32_t nA = basin ? p->numPatches : 0;
+                int32_t* zB = basin ? p->d_patchTotals : nullptr; const int32_t nB = basin ? (int32_t)WO_PATCH_TOTAL_SLOTS : 0;
+                if (F.slotOf) launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<true>, gridL, WO_BLOCK, F, zA, nA, zB, nB);
+                else launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<false>, gridL, WO_BLOCK, F, zA, nA, zB, nB);
+                countersCleared = basin;
             } else
                 launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
-                const int64_t r = run_solve_patches(p, F, K, m, dt, basin);
+                const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared);
                 if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
                 if (getenv("WO_SOLVE_TRACE")) fprintf(stderr, "iter %d: %lld patch launches\n", iter, (long long)r);
