@@ -25,11 +25,15 @@ let W = null;          // retained state (js/planet-worker.js:22)
 
 function progress(pct, label) { parentPort.postMessage({ type: 'progress', pct, label }); }
 
+// the retained planet holds several GB of device memory at 40 M cells and its JS handle is a few bytes: free it explicitly
+function releaseRetained() { if (W && W.planet) addon.planetDestroy(W.planet); W = null; }
+
 function handleRetain(data) {
     try {
         const { mesh, r_xyz, neighborDist, prePostElev, seed, r_hotspot } = data;
         if (!mesh || !(mesh.adjOffset instanceof Int32Array) || !(mesh.adjList instanceof Int32Array)) throw new TypeError('retain: mesh.adjOffset / mesh.adjList must be Int32Arrays');
         if (!(r_xyz instanceof Float32Array) || !(prePostElev instanceof Float32Array)) throw new TypeError('retain: r_xyz and prePostElev must be Float32Arrays');
+        releaseRetained();                               // a second retain replaces the first: its device memory goes now, not at the next GC
         const planet = addon.planetCreate(defaultContext(), mesh.numRegions, mesh.adjOffset, mesh.adjList, r_xyz, neighborDist || null);
         addon.planetUpload(planet, prePostElev, null);
         if (r_hotspot) addon.planetUploadHotspot(planet, r_hotspot);
@@ -82,7 +86,7 @@ parentPort.on('message', (data) => {
     switch (cmd) {
         case 'retain': handleRetain(data); break;
         case 'reapply': handleReapply(data); break;
-        case 'dispose': W = null; parentPort.postMessage({ type: 'disposed' }); break;
+        case 'dispose': releaseRetained(); parentPort.postMessage({ type: 'disposed' }); break;
         case 'generate': case 'editRecompute': case 'computeClimate': case 'importHeightmap':
             parentPort.postMessage({ type: 'error', message: `Command not served by the device worker (host stages of the reference): ${cmd}` });
             break;

@@ -126,10 +126,16 @@ void FinalizeCtx(napi_env, void* data, void*) { wo_ctx_destroy((wo_ctx*)data); }
 // wo_planet_destroy uses the planet's context (device, stream), and the order in which the garbage collector finalizes
 // two externals is unspecified: the planet holds a strong reference to its context value and drops it only after the
 // planet itself is gone.
+// The external's data is a box, so that planetDestroy() can free the device memory NOW (a planet at 40 M cells holds several GB,
+// and the external's tiny JS footprint gives the collector no reason to run) and leave a dead handle behind: the finalizer then
+// only frees the box, and every entry point sees a null planet ("expected a live planet handle").
+struct PlanetBox { wo_planet* p; };
 void FinalizePlanet(napi_env env, void* data, void* hint) {
-    wo_planet_destroy((wo_planet*)data);
+    PlanetBox* b = (PlanetBox*)data;
+    if (b) { if (b->p) wo_planet_destroy(b->p); delete b; }
     if (hint) napi_delete_reference(env, (napi_ref)hint);
 }
+static wo_planet* planet_at(Args& a, size_t i) { PlanetBox* b = (PlanetBox*)a.ext(i); return b ? b->p : nullptr; }
 
 napi_value DeviceCount(napi_env env, napi_callback_info) { napi_value v; napi_create_int32(env, wo_device_count(), &v); return v; }
 
@@ -156,8 +162,15 @@ napi_value PlanetCreate(napi_env env, napi_callback_info info) {               /
     napi_ref ctxRef = nullptr;
     if (napi_create_reference(env, a.argv[0], 1, &ctxRef) != napi_ok) { wo_planet_destroy(p); napi_throw_error(env, nullptr, "planetCreate: cannot reference the context"); return nullptr; }
     napi_value v;
-    if (napi_create_external(env, p, FinalizePlanet, ctxRef, &v) != napi_ok) { wo_planet_destroy(p); napi_delete_reference(env, ctxRef); napi_throw_error(env, nullptr, "planetCreate: cannot wrap the planet"); return nullptr; }
+    PlanetBox* box = new PlanetBox{p};
+    if (napi_create_external(env, box, FinalizePlanet, ctxRef, &v) != napi_ok) { wo_planet_destroy(p); delete box; napi_delete_reference(env, ctxRef); napi_throw_error(env, nullptr, "planetCreate: cannot wrap the planet"); return nullptr; }
     return v;
+}
+napi_value PlanetDestroy(napi_env env, napi_callback_info info) {               // (planet): frees the device memory now; the handle stays, dead
+    Args a(env, info);
+    PlanetBox* b = (PlanetBox*)a.ext(0);
+    if (b && b->p) { wo_planet_destroy(b->p); b->p = nullptr; }
+    napi_value u; napi_get_undefined(env, &u); return u;
 }
 
 // A planet argument must be a live handle, and every per-region array handed over with it must have exactly
@@ -177,7 +190,7 @@ bool regions_ok(napi_env env, wo_planet* p, size_t len, const char* what) {
 
 // ---- terrain-post, JS call surface (arrays mutated in place, return undefined) --------------------------
 #define PLANET_AND_ELEV()                                                                        \
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);                                      \
+    Args a(env, info); wo_planet* p = planet_at(a, 0);                                      \
     if (!planet_ok(env, p)) return nullptr;                                                      \
     size_t ne; float* e = (float*)a.ta(1, napi_float32_array, &ne); if (!a.ok) return nullptr;   \
     if (!regions_ok(env, p, ne, "r_elevation")) return nullptr;
@@ -221,7 +234,7 @@ napi_value ErodeComposite(napi_env env, napi_callback_info info) {             /
 
 // ---- resident variants ("reapply": the field stays in HBM) ---------------------------------------------
 napi_value PlanetUpload(napi_env env, napi_callback_info info) {               // (planet, elev|null, isOcean|null)
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     size_t n1 = 0, n2 = 0;
     float* e = a.has(1) ? (float*)a.ta(1, napi_float32_array, &n1) : nullptr; if (!a.ok) return nullptr;
@@ -236,7 +249,7 @@ napi_value PlanetDownload(napi_env env, napi_callback_info info) {             /
     return nullptr;
 }
 napi_value PlanetDownloadOcean(napi_env env, napi_callback_info info) {        // (planet, isOceanOut)
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     size_t n; uint8_t* oc = (uint8_t*)a.ta(1, napi_uint8_array, &n); if (!a.ok) return nullptr;
     if (!regions_ok(env, p, n, "r_isOcean")) return nullptr;
@@ -250,7 +263,7 @@ napi_value PlanetUploadHotspot(napi_env env, napi_callback_info info) {
 }
 #define SIMPLE_PLANET_CALL(NAME, EXPR)                                                     \
     napi_value NAME(napi_env env, napi_callback_info info) {                               \
-        Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);                            \
+        Args a(env, info); wo_planet* p = planet_at(a, 0);                            \
         if (!planet_ok(env, p)) return nullptr;                                            \
         if (EXPR) return throw_wo(env, #NAME);                                             \
         return nullptr;                                                                    \
@@ -268,7 +281,7 @@ SIMPLE_PLANET_CALL(ErodeCompositeResident, wo_erode_composite_resident(p, a.i32(
 SIMPLE_PLANET_CALL(TimerStart, wo_timer_start(p))
 
 napi_value TimerStopMs(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     double ms = 0;
     if (wo_timer_stop_ms(p, &ms)) return throw_wo(env, "timerStopMs");
@@ -277,7 +290,7 @@ napi_value TimerStopMs(napi_env env, napi_callback_info info) {
 
 // [{stage, ms}] of the last erodeComposite — same shape as the reference's _postTiming entries
 napi_value LastStageTiming(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     const char* names[64]; double ms[64]; int32_t n = 0;
     if (wo_last_stage_timing(p, 64, names, ms, &n)) return throw_wo(env, "lastStageTiming");
@@ -293,7 +306,7 @@ napi_value LastStageTiming(napi_env env, napi_callback_info info) {
 
 // lastErodeStats(planet) -> {name: number}: counters of the last erodeComposite (rounds, launches, the host flood's route)
 napi_value LastErodeStats(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     const char* names[64]; double vals[64]; int32_t n = 0;
     if (wo_last_erode_stats(p, 64, names, vals, &n)) return throw_wo(env, "lastErodeStats");
@@ -346,7 +359,7 @@ bool read_table(Args& a, napi_value obj, wo_plate_table* t) {
 }
 
 napi_value AssignElevation(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     size_t n, ns, nsup = 0, np_, nm;
     int32_t* r_plate = (int32_t*)a.ta(1, napi_int32_array, &n); if (!a.ok) return nullptr;
@@ -391,7 +404,7 @@ static void* opt_regions(Args& a, size_t i, napi_typedarray_type t, wo_planet* p
 }
 // diffuseOceanWarmth(planet, r_oceanWarmth|null, r_isLand, r_plateContinentality|null, passes) -> Float32Array
 napi_value DiffuseOceanWarmth(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     float* w = (float*)opt_regions(a, 1, napi_float32_array, p, "r_oceanWarmth", false); if (!a.ok) return nullptr;
     uint8_t* land = (uint8_t*)opt_regions(a, 2, napi_uint8_array, p, "r_isLand", true); if (!a.ok) return nullptr;
@@ -402,7 +415,7 @@ napi_value DiffuseOceanWarmth(napi_env env, napi_callback_info info) {
 }
 // computeWindConvergence(planet, r_wind3dX, r_wind3dY, r_wind3dZ) -> Float32Array
 napi_value WindConvergence(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     float* x = (float*)opt_regions(a, 1, napi_float32_array, p, "r_wind3dX", true); if (!a.ok) return nullptr;
     float* y = (float*)opt_regions(a, 2, napi_float32_array, p, "r_wind3dY", true); if (!a.ok) return nullptr;
@@ -413,7 +426,7 @@ napi_value WindConvergence(napi_env env, napi_callback_info info) {
 }
 // advectMoisture(planet, r_heightKm, r_isLand, r_windE, r_windN, r_wind3dX, r_wind3dY, r_wind3dZ, r_oceanWarmth|null, r_coastDistLand, maxHops) -> Float32Array
 napi_value AdvectMoisture(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     float* hk = (float*)opt_regions(a, 1, napi_float32_array, p, "r_heightKm", true); if (!a.ok) return nullptr;
     uint8_t* land = (uint8_t*)opt_regions(a, 2, napi_uint8_array, p, "r_isLand", true); if (!a.ok) return nullptr;
@@ -443,7 +456,7 @@ napi_value LandComponents(napi_env env, napi_callback_info info) {
 }
 // projectCoarsePlates(planet, coarseAdjOffset, coarseAdjList, coarse_xyz, coarse_r_plate, seed, numPlates|null) -> Int32Array
 napi_value ProjectCoarsePlates(napi_env env, napi_callback_info info) {
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     size_t no, na, nx, np_;
     int32_t* off = (int32_t*)a.ta(1, napi_int32_array, &no); if (!a.ok) return nullptr;
@@ -489,7 +502,7 @@ napi_value CommCreate(napi_env env, napi_callback_info info) {                 /
     return v;
 }
 napi_value PlanetSetHalo(napi_env env, napi_callback_info info) {              // (planet, sendIdx Int32Array, recvIdx Int32Array)
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0);
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
     if (!planet_ok(env, p)) return nullptr;
     size_t ns, nr; int32_t* s = (int32_t*)a.ta(1, napi_int32_array, &ns); if (!a.ok) return nullptr;
     int32_t* r = (int32_t*)a.ta(2, napi_int32_array, &nr); if (!a.ok) return nullptr;
@@ -497,7 +510,7 @@ napi_value PlanetSetHalo(napi_env env, napi_callback_info info) {              /
     return nullptr;
 }
 napi_value PlanetExchangeAllgather(napi_env env, napi_callback_info info) {    // (planet, comm, counts Int32Array(nranks))
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0); wo_comm* cm = (wo_comm*)a.ext(1);
+    Args a(env, info); wo_planet* p = planet_at(a, 0); wo_comm* cm = (wo_comm*)a.ext(1);
     if (!planet_ok(env, p)) return nullptr;
     size_t n; int32_t* counts = (int32_t*)a.ta(2, napi_int32_array, &n); if (!a.ok) return nullptr;
     if (!cm || (int)n != wo_comm_size(cm)) { napi_throw_range_error(env, nullptr, "planetExchangeAllgather: one count per rank"); return nullptr; }
@@ -505,7 +518,7 @@ napi_value PlanetExchangeAllgather(napi_env env, napi_callback_info info) {    /
     return nullptr;
 }
 napi_value PlanetExchangeNeighbors(napi_env env, napi_callback_info info) {    // (planet, comm, nToPrev, nFromPrev)
-    Args a(env, info); wo_planet* p = (wo_planet*)a.ext(0); wo_comm* cm = (wo_comm*)a.ext(1);
+    Args a(env, info); wo_planet* p = planet_at(a, 0); wo_comm* cm = (wo_comm*)a.ext(1);
     if (!planet_ok(env, p)) return nullptr;
     if (!cm) { napi_throw_type_error(env, nullptr, "planetExchangeNeighbors: expected a communicator handle"); return nullptr; }
     if (wo_planet_exchange_neighbors(p, cm, a.i32(2), a.i32(3))) return throw_wo(env, "planetExchangeNeighbors");
@@ -516,7 +529,7 @@ napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"fibSpherePoints", FibSpherePoints}, {"sphereDelaunay", SphereDelaunay}, {"meshCsr", MeshCsr}, {"neighborDist", NeighborDist},
         {"triangleElevations", TriangleElevations}, {"noiseTables", NoiseTables}, {"noiseEval", NoiseEval}, {"noisePoint", NoisePoint},
-        {"deviceCount", DeviceCount}, {"ctxCreate", CtxCreate}, {"planetCreate", PlanetCreate},
+        {"deviceCount", DeviceCount}, {"ctxCreate", CtxCreate}, {"planetCreate", PlanetCreate}, {"planetDestroy", PlanetDestroy},
         {"warpTerrain", WarpTerrain}, {"smoothElevation", SmoothElevation}, {"erodeComposite", ErodeComposite},
         {"sharpenRidges", SharpenRidges}, {"applySoilCreep", ApplySoilCreep},
         {"planetUpload", PlanetUpload}, {"planetDownload", PlanetDownload}, {"planetDownloadOcean", PlanetDownloadOcean},
