@@ -938,6 +938,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     std::vector<uint8_t> dirty(std::max(nComp, 1), 0);
     const int forceDirty = [] { const char* v = std::getenv("WO_FLOOD_FORCE_DIRTY"); return v ? std::atoi(v) : -1; }();     // test hook (read per call): treat this landmass (by rank in size) as undecided
     // One round over a list of landmasses.  walked: pass 1 of these landmasses is already there (the replay's).
+    const auto tRound0 = std::chrono::steady_clock::now();
     auto run_round = [&](const std::vector<int32_t>& list, bool walked) {
         const int32_t nList = (int32_t)list.size();
         int32_t nBig = 0;
@@ -1013,6 +1014,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     pos.assign(c.begin(), c.end() - 1);
                     for (int32_t qq = 0; qq < n; ++qq) { const int32_t i = cells[qq]; list2[base + pos[S.seedLocal[st[i].root]]++] = i; }
                 }
+                if (T.on && q == 0) std::fprintf(stderr, "[flood] largest landmass: walk + contests + tree lists done at %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tRound0).count());
                 if (isBig) {                                  // hand the trees out in chunks
                     BigJob& J = big[q];
                     J.k = k; J.track = track;
@@ -1038,13 +1040,14 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
             }
         };
         const int use = std::min(nt, std::max(1, nList));
+        if (T.on) std::fprintf(stderr, "[flood] round setup done at %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tRound0).count());
         if (use == 1 && nBig == 0) worker(0);
         else {
             const int th_n = nBig > 0 ? nt : use;                  // chunks of a big landmass are worth every worker
-            std::vector<std::thread> th;
-            for (int w = 0; w < th_n; ++w) th.emplace_back(worker, w);
-            for (auto& t : th) t.join();
+            // on the persistent host workers (host_util.h: HostPool; threads of its own when the pool is busy with another planet)
+            parallel_ranges((int64_t)th_n, [&](int64_t b, int64_t en, int) { for (int64_t w = b; w < en; ++w) worker((int)w); }, 1);
         }
+        if (T.on) std::fprintf(stderr, "[flood] round joined at %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tRound0).count());
     };
     std::vector<int32_t> all(nComp);
     for (int32_t k = 0; k < nComp; ++k) all[k] = k;

@@ -2,6 +2,11 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <new>
+#include <pthread.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -45,12 +50,87 @@ struct HugeAlloc {
 };
 template <class T> using hvec = std::vector<T, HugeAlloc<T>>;
 
+// Persistent host workers for parallel_ranges().  A flood call makes half a dozen parallel sweeps (clears, gather, write-back) and the
+// composite's setup a few more; creating up to 64 threads for each cost 1-2 ms per sweep on the 256-thread host of the GPU box.
+// One job at a time: a caller that finds the pool busy (several planets in flight, each driven by its own host thread), or is itself
+// a pool worker, falls back to the plain form (threads of its own / inline).  The pool is never destroyed (its threads sleep on a
+// condition variable between jobs) and is rebuilt in a forked child.
+class HostPool {
+public:
+    static HostPool& get() { static HostPool* p = new HostPool(); return *p; }
+    // runs job(c) for c in [0, chunks); false: pool not available, nothing was run
+    bool run(int64_t chunks, const std::function<void(int64_t)>& job) {
+        if (tl_in_worker()) return false;
+        std::unique_lock<std::mutex> own(jobLock_, std::try_to_lock);
+        if (!own.owns_lock()) return false;
+        ensure_threads();
+        if (workers_ == 0) return false;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &job; chunks_ = chunks; next_.store(0); remaining_.store(chunks); error_ = nullptr; ++gen_;
+        }
+        cv_.notify_all();
+        work(job, chunks);                                   // the caller takes chunks too
+        std::unique_lock<std::mutex> g(m_);
+        cvDone_.wait(g, [&] { return remaining_.load() == 0 && active_ == 0; });
+        job_ = nullptr;
+        if (error_) std::rethrow_exception(error_);
+        return true;
+    }
+private:
+    HostPool() { pthread_atfork(nullptr, nullptr, [] { HostPool::get().after_fork(); }); }
+    static bool& tl_in_worker() { static thread_local bool v = false; return v; }
+    void after_fork() { workers_ = 0; new (&m_) std::mutex(); new (&jobLock_) std::mutex(); new (&cv_) std::condition_variable(); new (&cvDone_) std::condition_variable(); active_ = 0; job_ = nullptr; }
+    void ensure_threads() {
+        if (workers_ > 0) return;
+        const int n = std::max(0, host_threads() - 1);
+        for (int i = 0; i < n; ++i) std::thread([this] { tl_in_worker() = true; loop(); }).detach();
+        workers_ = n;
+    }
+    void work(const std::function<void(int64_t)>& job, int64_t chunks) {
+        for (;;) {
+            const int64_t c = next_.fetch_add(1);
+            if (c >= chunks) break;
+            try { job(c); } catch (...) { std::lock_guard<std::mutex> g(m_); if (!error_) error_ = std::current_exception(); }
+            if (remaining_.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); cvDone_.notify_all(); }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int64_t)>* job; int64_t chunks;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (!job_ || next_.load() >= chunks_) continue;            // woke late: the job is already handed out
+                job = job_; chunks = chunks_; ++active_;
+            }
+            work(*job, chunks);
+            { std::lock_guard<std::mutex> g(m_); --active_; if (active_ == 0) cvDone_.notify_all(); }
+        }
+    }
+    std::mutex m_, jobLock_;
+    std::condition_variable cv_, cvDone_;
+    const std::function<void(int64_t)>* job_ = nullptr;
+    int64_t chunks_ = 0;
+    std::atomic<int64_t> next_{0}, remaining_{0};
+    int active_ = 0, workers_ = 0;
+    uint64_t gen_ = 0;
+    std::exception_ptr error_;
+};
+
 // Static-chunked parallel loop over [0, n). fn(begin, end, tid).
 template <class F>
 inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
     int nt = host_threads();
     if (n < min_chunk * 2 || nt == 1) { fn((int64_t)0, n, 0); return; }
     int64_t chunks = std::min<int64_t>(nt, (n + min_chunk - 1) / min_chunk);
+    static const bool pooled = !(std::getenv("WO_HOST_POOL") && std::atoi(std::getenv("WO_HOST_POOL")) == 0);
+    if (pooled) {
+        const std::function<void(int64_t)> job = [&](int64_t c) { fn(n * c / chunks, n * (c + 1) / chunks, (int)c); };
+        if (HostPool::get().run(chunks, job)) return;
+    }
     std::vector<std::thread> th;
     th.reserve(chunks);
     for (int64_t c = 0; c < chunks; ++c) {
