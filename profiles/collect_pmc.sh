@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
 for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o pmc -- \
+    timeout 240 rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o pmc -- \
         python bench.py --no-cpu --no-profile --in-flight 0 --steps 1 --warmup 0 --iters "$ITERS" > "$OUT/$C.log" 2>&1
     echo "$C rc=$?"
 done
