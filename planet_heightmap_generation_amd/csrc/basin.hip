@@ -229,10 +229,10 @@ __global__ __launch_bounds__(64, 4) void k_solve_stream(Fields F, int32_t L, con
 // keeps the waves together (ring entries are reused RING slots later).  Loads are pipelined as in k_solve_stream.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 6) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
+__global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
                                                             int32_t* patchPending, int32_t* totalPending) {
     constexpr int SC = 64 * NW;                        // tasks per super-chunk
-    constexpr int RING = 1024;                         // tasks whose granules the workgroup keeps in LDS
+    constexpr int RING = (2 * SC > 1024) ? 2 * SC : 1024;    // tasks whose granules the workgroup keeps in LDS (power of two, >= 2 super-chunks)
     __shared__ unsigned long long s_ring[2 * RING];
     const int tid = threadIdx.x;
     const int32_t S = rangeStart[blockIdx.x];
@@ -349,7 +349,7 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
     launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
            (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0));
     // the in-tree sort (radix.hip; its last pass also writes slotOf[cell] = position); WO_SORT=hipcub: the library sort
-    static const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";
+    const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";     // read per sort (tests switch it)
     int sorted = 1;                                  // which of d_keys / d_basinVals holds the result
     if (!library) {
         uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
@@ -376,7 +376,9 @@ void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_
     // WO_BASIN_WAVES: waves per range — 4 (default) / 2: k_solve_coop; 1: k_solve_stream
     static const int coopWaves = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
     ++p->basinLaunches;
-    if (coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    if (coopWaves >= 16) launch(p, FAM_SOLVE_BASIN, k_solve_coop<16>, nRanges, 1024, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    else if (coopWaves >= 8) launch(p, FAM_SOLVE_BASIN, k_solve_coop<8>, nRanges, 512, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    else if (coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
     else if (coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
     else launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
 }

@@ -111,7 +111,7 @@ void sort_land_by_elevation(wo_planet* p) {
     hipStream_t s = p->ctx->stream;
     // WO_SORT=hipcub: the library sort + the rank scatter of earlier builds; default: the in-tree sort (radix.hip), whose last pass
     // also writes rank[cell] = position
-    static const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";
+    const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";     // read per sort (tests switch it)
     static const bool stats0 = getenv("WO_SORT_STATS") != nullptr;
     bool rankWritten = false;
     if (!library) {
