@@ -37,6 +37,7 @@ namespace wo {
 
 namespace {
 
+constexpr int32_t WO_RANGE_NONE = 0x7f7f7f7f;
 constexpr int WO_BASIN_CHASE_CAP = 1 << 16;         // pointer-jumping steps of one thread before it gives up (never reached: chains and rings are shorter)
 
 // J[s] = Morton slot of the receiver of the cell at Morton slot s, or s itself for a root: no land receiver, or the
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_jump(const int32_t* __restri
 // scramble (test hook, WO_BASIN_SCRAMBLE=1): every third cell is sent to the neighbouring group, so groups are no longer closed under
 // the dependencies and the launch leaves tasks pending — the k_solve_patch launches that finish them must give the same bits
 __global__ __launch_bounds__(WO_BLOCK) void k_basin_keys(const int32_t* __restrict__ land, const uint32_t* __restrict__ keyOfCell, int32_t L,
-                                                          uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t scramble) {
+                                                          uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t scramble, int32_t* rangeStart, int32_t nRangeWords) {
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nRangeWords; i += gridDim.x * blockDim.x) rangeStart[i] = WO_RANGE_NONE;     // k_basin_slots takes minima into it (was a memset launch)
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
         const int32_t c = land[L - 1 - i];
         keys[i] = (scramble && c % 3 == 0) ? (keyOfCell[c] ^ 1u) : keyOfCell[c];
@@ -114,7 +116,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_slots(const int32_t* __restr
         if (q == 0 || keys[q] != keys[q - 1]) atomicMin(&rangeStart[q / rangeT], q);
     }
 }
-constexpr int32_t WO_RANGE_NONE = 0x7f7f7f7f;
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Streaming form: ONE WAVE per range, no barrier and no polling.  The store order of a group is its processing order, a
@@ -346,8 +347,10 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
     const int grid = blocks_for(L, 1 << 16);
     if (!jFromReceivers) launch(p, FAM_BASIN, k_basin_init, grid, WO_BLOCK, F, (const int32_t*)p->d_patchOrder, (const int32_t*)p->d_slotOf, p->d_basinJ, L);
     launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, slotIdentity ? (const int32_t*)nullptr : (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
+    const int rangeT = basin_range();
+    const int nRanges = (int)(((int64_t)L + rangeT - 1) / rangeT);
     launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
-           (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0));
+           (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0), p->d_basinRange, (int32_t)(nRanges + 1));
     // the in-tree sort (radix.hip; its last pass also writes slotOf[cell] = position); WO_SORT=hipcub: the library sort
     const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";     // read per sort (tests switch it)
     int sorted = 1;                                  // which of d_keys / d_basinVals holds the result
@@ -363,9 +366,6 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
                                                  (const int32_t*)p->d_basinVals[0], p->d_basinVals[1], L, 0, bitsL - shift, s));
         if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_BASIN_SORT, a, b}); }
     }
-    const int rangeT = basin_range();
-    const int nRanges = (int)(((int64_t)L + rangeT - 1) / rangeT);
-    WO_HIP(hipMemsetAsync(p->d_basinRange, 0x7f, (size_t)(nRanges + 1) * 4, s));
     launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[sorted], (const uint32_t*)p->d_keys[sorted], library ? p->d_basinSlot : (int32_t*)nullptr, L, p->d_basinRange, (int32_t)rangeT);
 }
 

@@ -92,6 +92,7 @@ struct wo_planet {
     bool h_ocean_valid = false;
     float* h_pinned = nullptr;          // N floats, pinned
     int32_t* h_count = nullptr;         // pinned scalar(s) for round-count read-back
+    unsigned long long *h_word = nullptr, *d_word = nullptr; uint32_t wordSerial = 0;   // host-mapped {serial, value} word the host polls (planet.hip: publish_and_wait)
     wo::FloodScratch flood;
     wo_flood_gpu fgpu;
 

@@ -1248,6 +1248,12 @@ __global__ __launch_bounds__(WO_BLOCK) void k_mirror_rows(const int32_t* off, co
     }
 }
 
+// {serial, value} of a device counter into a host-mapped word: the host polls the word instead of paying a copy, a stream
+// synchronisation and its wake-up for one integer (planet.hip: publish_and_wait)
+__global__ void k_publish_count(const int32_t* __restrict__ src, unsigned long long* hostWord, uint32_t serial) {
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        __hip_atomic_store(hostWord, ((unsigned long long)serial << 32) | (unsigned long long)(uint32_t)*src, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_set_counters(int32_t* c, int32_t v0, int32_t v1, int32_t v2, int32_t v3) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = v0; c[1] = v1; c[2] = v2; c[3] = v3; }
 }
