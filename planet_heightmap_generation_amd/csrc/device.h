@@ -92,6 +92,7 @@ struct wo_planet {
     bool h_ocean_valid = false;
     float* h_pinned = nullptr;          // N floats, pinned
     int32_t* h_count = nullptr;         // pinned scalar(s) for round-count read-back
+    float* d_redoE = nullptr; int32_t* d_pendingEver = nullptr; int64_t redoCalls = 0;   // erode_composite_checked: the field at entry, tasks any basin launch of the call left pending, calls that had to run again
     unsigned long long *h_word = nullptr, *d_word = nullptr; uint32_t wordSerial = 0;   // host-mapped {serial, value} word the host polls (planet.hip: publish_and_wait)
     wo::FloodScratch flood;
     wo_flood_gpu fgpu;

@@ -370,9 +370,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t
         block_append(again, d, out, outCount);
     }
 }
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt) {
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt, SolveOut* clearOut) {
     WO_XCD_LAND(i, c) {
         donorCnt[c] = 0;                                    // for the next iteration's receivers pass (only land cells are counted into)
+        if (clearOut) { SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0; clearOut[i] = z; }      // the solve's output tags of this pass (store index i: one coalesced sweep, was a memset launch)
         flow_final_cell(F, c);                              // + the event list of c for the solve
     }
 }

@@ -269,9 +269,16 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
 // Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
 // basin: the store order is the group-major one of basin_layout() and the first launch of the pass is k_solve_basin, which
 // normally leaves nothing pending; whatever it does leave (layout off: see basin.hip) is finished by k_solve_patch launches.
-static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin, bool countersCleared = false) {
+static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin, bool countersCleared = false, bool deferCheck = false) {
     hipStream_t s = p->ctx->stream;
     const int np = p->numPatches;
+    if (basin && deferCheck && countersCleared) {
+        // the one launch of the basin solve, and no look at what it left: tasks left pending are counted into a word that is not
+        // cleared during the call and looked at where the host synchronises anyway (erode_composite: RedoWithChecks)
+        basin_solve_launch(p, F, 1, p->d_pendingEver);
+        p->lastPatchLaunches = 1;
+        return 1;
+    }
     if (!countersCleared) launch(p, FAM_MISC, k_fill_i32, blocks_for(np, 64), WO_BLOCK, p->d_patchPending, basin ? 0 : 1, (int32_t)np);
     // one pending-total slot per launch, cleared once per pass (a memset per launch was 13.6 k fill kernels per step)
     int32_t* tot = p->d_patchTotals;
@@ -639,8 +646,12 @@ struct MirrorScope {
 };
 
 // erodeComposite on the resident field (js/terrain-post.js:369-707)
+// Thrown by erode_composite when a basin-solve launch whose result was not checked on the spot turns out to have left tasks pending:
+// the caller restores the field and runs the call again with the check after every pass (erode_composite_checked).
+struct RedoWithChecks {};
+
 static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talus,
-                            double kThermal, int32_t gIters, double gStrength) {
+                            double kThermal, int32_t gIters, double gStrength, bool checkEveryPass = true) {
     if (gIters < 0) gIters = 0;
     if (gStrength != gStrength) gStrength = 0;
     const int32_t total = std::max(hIters, std::max(tIters, gIters));
@@ -726,7 +737,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     clk.end();
 
     FloodRun floodRun;
+    auto leftovers_so_far = [&]() {
+        if (checkEveryPass || !p->d_pendingEver) return;
+        if (read_count(p, p->d_pendingEver) != 0) throw RedoWithChecks{};
+    };
     auto flood = [&](double cs) {
+        leftovers_so_far();                    // the host is about to read the field
         clk.begin("priority_flood");
         auto t0 = std::chrono::steady_clock::now();
         mir.suspend();
@@ -961,7 +977,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             {
                 Fields Ff = F;
                 if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
-                launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt);
+                launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt, basin ? p->d_out : (SolveOut*)nullptr);
             }
             clk.end();
             clk.begin("solve");
@@ -969,7 +985,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p, basinJFromReceivers, slotIdentity);
                 F.slotOf = p->d_basinSlot;
                 F.solveLean = 1;
-                WO_HIP(hipMemsetAsync(p->d_out, 0, (size_t)L * sizeof(SolveOut), s));       // the outputs' tags, cleared in one sweep instead of one scattered 16-byte write per task
+                // (the outputs' tags were cleared by k_flow_final: one coalesced sweep instead of one scattered 16-byte write per task)
             }
             // WO_SETUP_BATCHED=0: the setup that decides load by load (solve_setup_cell) instead of k_solve_setup_batched
             static const bool setupBatched = !(getenv("WO_SETUP_BATCHED") && atoi(getenv("WO_SETUP_BATCHED")) == 0);
@@ -984,7 +1000,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             } else
                 launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
-                const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared);
+                const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared, !checkEveryPass);
                 if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
                 if (getenv("WO_SOLVE_TRACE")) fprintf(stderr, "iter %d: %lld patch launches\n", iter, (long long)r);
@@ -1014,6 +1030,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         }
     }
     clk.on = true;
+    leftovers_so_far();
     if (glacial) {
         clk.begin("glacial_blend");
         launch(p, FAM_GLAC_BLEND, k_glacial_blend, gridN, WO_BLOCK, p->fields(), (const float*)p->d_e, p->d_e2);
@@ -1028,7 +1045,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
                      {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
-                     {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"carve_flow_launches_with_leftovers", (double)carveFlowLeft}, {"flood_stage_ms", floodHostMs},
+                     {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"carve_flow_launches_with_leftovers", (double)carveFlowLeft}, {"solve_check_every_pass", checkEveryPass ? 1.0 : 0.0}, {"calls_run_again_with_checks", (double)p->redoCalls}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
                      {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
                      {"flood_pass1_on_host", (floodRun.usedDevice && !floodRun.fellBack) ? 0.0 : 1.0},
@@ -1119,6 +1136,31 @@ static bool check_planet(wo_planet* p, const char* fn) {
     hipError_t e = hipSetDevice(p->ctx->device);
     if (e != hipSuccess) { set_error(std::string(fn) + ": hipSetDevice failed: " + hipGetErrorString(e)); return false; }
     return true;
+}
+
+// The host used to look at the basin solve's pending count after every pass (a read-back and ~30 us of idle GPU per iteration, and
+// the host never got ahead of the device).  No real layout has ever left a task pending, so the look is deferred: the launches add
+// into one word per call, the word is read where the host synchronises anyway (before the second flood, at the end), and if it is
+// not zero the field is restored from a copy taken at entry and the call runs again with the check after every pass — the form
+// that finishes pending tasks with k_solve_patch launches.  WO_SOLVE_CHECK=pass: always that form.
+static void erode_composite_checked(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talus,
+                                    double kThermal, int32_t gIters, double gStrength) {
+    static const bool everyPass = getenv("WO_SOLVE_CHECK") && std::string(getenv("WO_SOLVE_CHECK")) == "pass";
+    if (everyPass || hIters <= 0) { erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true); return; }
+    hipStream_t s = p->ctx->stream;
+    if (!p->d_redoE) p->d_redoE = dalloc<float>((size_t)p->N);
+    if (!p->d_pendingEver) p->d_pendingEver = dalloc<int32_t>(16);
+    WO_HIP(hipMemcpyAsync(p->d_redoE, p->d_e, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    WO_HIP(hipMemsetAsync(p->d_pendingEver, 0, 16 * sizeof(int32_t), s));
+    try {
+        erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, false);
+    } catch (const RedoWithChecks&) {
+        WO_HIP(hipStreamSynchronize(s));
+        if (p->side) WO_HIP(hipStreamSynchronize(p->side));
+        WO_HIP(hipMemcpyAsync(p->d_e, p->d_redoE, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        ++p->redoCalls;
+        erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true);
+    }
 }
 
 extern "C" {
@@ -1228,7 +1270,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);
@@ -1416,7 +1458,7 @@ int wo_erode_composite_resident(wo_planet* p, int32_t hIters, double K, double m
                                 double kThermal, int32_t gIters, double glacialStrength) {
     if (!check_planet(p, "wo_erode_composite_resident")) return 1;
     WO_TRY
-    erode_composite(p, hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength);
+    erode_composite_checked(p, hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength);
     return 0;
     WO_CATCH("wo_erode_composite_resident")
 }
@@ -1470,7 +1512,7 @@ int wo_erode_composite(wo_planet* p, float* e, const uint8_t* oc, int32_t hIters
                        double talusSlope, double kThermal, int32_t gIters, double glacialStrength) {
     ErodeArgs a{hIters, K, m, dt, tIters, talusSlope, kThermal, gIters, glacialStrength};
     return with_host_field(p, "wo_erode_composite", e, oc, true,
-                           [](wo_planet* q, void* v) { auto* x = (ErodeArgs*)v; erode_composite(q, x->h, x->K, x->m, x->dt, x->t, x->talus, x->kT, x->g, x->gs); }, &a);
+                           [](wo_planet* q, void* v) { auto* x = (ErodeArgs*)v; erode_composite_checked(q, x->h, x->K, x->m, x->dt, x->t, x->talus, x->kT, x->g, x->gs); }, &a);
 }
 
 // smoothField (js/climate-util.js:5-25) on a caller-owned field; the planet's resident elevation is not touched

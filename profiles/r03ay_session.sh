@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/r03ay
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden or against_oracle_large or ties or edge_cases or sort_routes or basin_leftovers" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden or against_oracle_large or ties or edge_cases or sort_routes or basin_leftovers or glacial_step or flow_accumulation or mirror_layout" 2>&1 | tail -2
 timeout 300 python bench.py --no-cpu --in-flight 0 --steps 2 --warmup 1 > gpurun_out/r03ay/b.json 2> gpurun_out/r03ay/b.err
 python - <<'PY'
 import json

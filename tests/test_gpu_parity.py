@@ -640,10 +640,14 @@ def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch)
     st = pl.last_erode_stats()
     monkeypatch.delenv("WO_BASIN_SCRAMBLE")
     assert st["solve_basin_passes_with_leftovers"] > 0, st
+    # the pending count is not looked at after every pass any more: the call notices at its next host synchronisation that a launch
+    # left tasks behind, restores the field and runs again with the check (and the k_solve_patch finisher) after every pass
+    assert st["solve_check_every_pass"] == 1 and st["calls_run_again_with_checks"] >= 1, st
     assert np.array_equal(got, ref), int((got != ref).sum())
     got = e0.copy()
     pl.erode_composite(got, oc, *args)
     assert pl.last_erode_stats()["solve_basin_passes_with_leftovers"] == 0
+    assert pl.last_erode_stats()["solve_check_every_pass"] == 0
     assert np.array_equal(got, ref)
     pl.close()
 
