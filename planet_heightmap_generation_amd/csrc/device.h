@@ -108,6 +108,7 @@ struct wo_planet {
     uint8_t* d_tables = nullptr;        // perm[512] + pm12[512]
     // erode scratch (allocated on first erodeComposite)
     bool scratch = false;
+    bool landIdentity = false;          // erode_composite under the land-first mirror: landIdx[i] == i
     int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
     uint32_t* d_keys[2] = {nullptr, nullptr};
     float *d_cellDist = nullptr, *d_flow = nullptr;

@@ -36,7 +36,7 @@ namespace wo {
                  i = (int32_t)((((xi_ / xt_) * 8 + (int32_t)(blockIdx.x & 7u)) * xt_ + (xi_ % xt_)) * (int32_t)blockDim.x + (int32_t)threadIdx.x), \
                  once_ = 1;                                                                                          \
          once_ && i < F.L; once_ = 0)                                                                                \
-        for (int32_t r = F.landIdx[i], once2_ = 1; once2_; once2_ = 0)
+        for (int32_t r = F.landIdx ? F.landIdx[i] : i, once2_ = 1; once2_; once2_ = 0)          /* landIdx == nullptr: the land cells ARE the ids 0 .. L-1 (land-first mirror): one dependent load less per thread */
 
 // Block-uniform strided loop: every thread of the workgroup runs the same number of trips (needed around
 // block_append's barriers); `valid` tells whether index i is in range.
@@ -206,7 +206,7 @@ __device__ inline TileWindow stage_tile(const Fields& F, const float* field, flo
     if (!F.tileLds) return W;                                     // block-uniform
     if (i0 < F.L) {
         const int32_t i1 = min(i0 + (int32_t)blockDim.x, F.L) - 1;
-        const int32_t lo = max(F.landIdx[i0] - WO_TILE_MARGIN, 0), hi = min(F.landIdx[i1] + WO_TILE_MARGIN, F.N - 1);
+        const int32_t lo = max((F.landIdx ? F.landIdx[i0] : i0) - WO_TILE_MARGIN, 0), hi = min((F.landIdx ? F.landIdx[i1] : i1) + WO_TILE_MARGIN, F.N - 1);
         if (hi - lo + 1 <= WO_TILE_WIN) {
             for (int32_t k = threadIdx.x; k <= hi - lo; k += blockDim.x) s_buf[k] = field[lo + k];
             W.lo = lo; W.hi = hi;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_solve_setup_batched(Fields F, int3
     const int32_t i = WO_XCD_LAND_BASE() + (int32_t)threadIdx.x;
     int32_t r = -1;
     bool defer = false;
-    if (i < F.L) { r = F.landIdx[i]; defer = !solve_setup_cell_batched<SLOT>(F, r); }
+    if (i < F.L) { r = F.landIdx ? F.landIdx[i] : i; defer = !solve_setup_cell_batched<SLOT>(F, r); }
     const unsigned long long m = __ballot(defer);
     if (m) {
         const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;

@@ -79,7 +79,7 @@ wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     static const int tileLds = (getenv("WO_TILE_LDS") && atoi(getenv("WO_TILE_LDS")) != 0) ? 1 : 0;
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = tileLds; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = (getenv("WO_NO_EVENT_LISTS") == nullptr) ? d_ev : nullptr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = (getenv("WO_NO_EVENT_LISTS") == nullptr) ? d_ev : nullptr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -670,6 +670,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     refresh_host_ocean(p);          // the planet's own mask, before the pointers move
     MirrorScope mir(p);
     mir.enter(p->h_ocean.data());          // land first (mirror_build)
+    static const bool identityOk = !(getenv("WO_LAND_IDENTITY") && atoi(getenv("WO_LAND_IDENTITY")) == 0);
+    p->landIdentity = identityOk && mir.on && p->mirror.h_mask.size() == (size_t)N;      // land cells are the ids 0 .. L-1: the index-order passes skip the land list
     coast_flags(p);
     // landCells in ascending r (js/terrain-post.js:384-390): host-side compaction of the ocean mask
     {

@@ -1,12 +1,12 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/r03ba
 export TMPDIR=/tmp
-for V in deferred pass deferred2 pass2; do
-  unset WO_SOLVE_CHECK; case $V in pass*) export WO_SOLVE_CHECK=pass;; esac
+for V in ident noident ident2 noident2; do
+  unset WO_LAND_IDENTITY; case $V in noident*) export WO_LAND_IDENTITY=0;; esac
   timeout 300 python bench.py --no-cpu --no-profile --in-flight 0 --steps 3 --warmup 1 > gpurun_out/r03ba/$V.json 2> gpurun_out/r03ba/$V.err
   python - $V <<'PY'
 import json,sys
 d=json.loads(open(f"gpurun_out/r03ba/{sys.argv[1]}.json").read().strip().splitlines()[-1])
-st=d["stage_ms_last_step"]; print(sys.argv[1], round(d["ms_per_step"],1), d["parity"]["parity_crc_ok"], "flood", round(st["priority_flood"],1), "rest", round(d["ms_per_step"]-st["priority_flood"],1), {k:round(v,1) for k,v in st.items() if k in ("solve","thermal","sort","flow")})
+st=d["stage_ms_last_step"]; print(sys.argv[1], round(d["ms_per_step"],1), d["parity"]["parity_crc_ok"], "flood", round(st["priority_flood"],1), "rest", round(d["ms_per_step"]-st["priority_flood"],1), {k:round(v,1) for k,v in st.items() if k in ("solve","thermal","sort","flow","receivers")})
 PY
 done
