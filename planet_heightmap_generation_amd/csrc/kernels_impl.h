@@ -227,6 +227,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
         F.accA[r] = a; F.jumpA[r] = j; F.accCnt[r] = 1ull;
         if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
+        if (F.lateDonor && t >= 0 && !F.ocean[t] && !(F.rank[r] < F.rank[t])) F.lateDonor[t] = 1;      // r's total is added to t's flow by the totals pass, not forwarded
         if (F.basinJ) {                                      // start state of the drainage-component search (basin.hip: k_basin_init's job, one launch less on the layout's chain)
             const bool landT = t >= 0 && !F.ocean[t];
             const int32_t sr = F.basinMslot ? F.basinMslot[r] : r;
@@ -368,6 +369,19 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t
             }
         }
         block_append(again, d, out, outCount);
+    }
+}
+// three-stream form (planet.hip): event lists beside the flow accumulation; totals after it
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_events(Fields F, SolveOut* clearOut) {
+    WO_XCD_LAND(i, c) {
+        if (clearOut) { SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0; clearOut[i] = z; }
+        flow_events_cell(F, c);
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_totals(Fields F, int32_t* donorCnt) {
+    WO_XCD_LAND(i, c) {
+        donorCnt[c] = 0;                                    // for the next iteration's receivers pass
+        flow_totals_cell(F, c);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt, SolveOut* clearOut) {

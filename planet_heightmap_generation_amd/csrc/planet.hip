@@ -36,6 +36,7 @@ void profile_resolve(wo_planet* p) {
     if (p->pending.empty()) return;
     WO_HIP(hipStreamSynchronize(p->ctx->stream));
     if (p->side) WO_HIP(hipStreamSynchronize(p->side));
+    if (p->side2) WO_HIP(hipStreamSynchronize(p->side2));
     for (auto& pe : p->pending) {
         float ms = 0; WO_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
         p->famMs[pe.fam] += ms; p->famLaunches[pe.fam] += 1;
@@ -912,6 +913,22 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             const bool basinJFromReceivers = basin && !basinInitKernel;
             const bool slotIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;          // land-first mirror: a land cell's Morton slot is its id
             if (basinJFromReceivers) { basin_alloc(p); F.basinJ = p->d_basinJ; F.basinMslot = slotIdentity ? nullptr : p->d_slotOf; }
+            static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
+            const char* climbEnv = getenv("WO_FLOW_CLIMB");
+            const int climbCap = climbEnv ? std::max(0, atoi(climbEnv)) : 0x7fffffff;
+            const bool climbAll = climbCap == 0x7fffffff;
+            // three streams: the event lists of the solve (they need the receivers only) are built on a stream of their own beside the flow
+            // accumulation (main) and the basin layout (side); the totals pass after the accumulation is a coalesced sweep, because the
+            // receivers pass flags the few cells that have a late donor.  MEASURED, NOT FASTER, off by default (WO_FLOW_EVENTS_STREAM=1): with
+            // three kernels at once the climb takes 274 us instead of 200, the events 261 instead of ~90, the layout's scatter 75 instead of
+            // 27, and the setup starts at the same moment (profiles/r03bc_*): these "latency-bound" launches do fill the memory pipelines
+            // when two of them already run side by side.  Default: k_flow_final after the accumulation.
+            const bool eventsStreamEnv = getenv("WO_FLOW_EVENTS_STREAM") && atoi(getenv("WO_FLOW_EVENTS_STREAM")) != 0;      // read per pass (tests switch it)
+            const bool eventsStream = eventsStreamEnv && basin && basinOverlap && climbAll && F.ev;
+            if (eventsStream) {
+                if (!p->d_lateDonor) { p->d_lateDonor = dalloc<uint8_t>((size_t)N); WO_HIP(hipMemsetAsync(p->d_lateDonor, 0, (size_t)N, s)); }
+                F.lateDonor = p->d_lateDonor;
+            }
             clk.begin("receivers");
             launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
             clk.end();
@@ -920,7 +937,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             // The layout needs the receivers only and touches none of the flow accumulation's arrays, and both are chains of
             // latency-bound launches that leave most of the chip idle: the layout runs on the planet's side stream beside the flow
             // accumulation and the solve's setup waits for both (WO_BASIN_OVERLAP=0: one after the other on the main stream).
-            static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
             if (basin && basinOverlap) {
                 if (!p->side) {
                     // the layout's chain of short launches is the longer of the two: at equal priority its workgroups queue behind the thousands of
@@ -937,6 +953,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 try { basin_layout(p, basinJFromReceivers, slotIdentity); } catch (...) { p->onSide = false; throw; }
                 p->onSide = false;
                 WO_HIP(hipEventRecord(p->evJoin, p->side));
+                if (eventsStream) {
+                    if (!p->side2) { WO_HIP(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking)); WO_HIP(hipEventCreateWithFlags(&p->evJoin2, hipEventDisableTiming)); }
+                    WO_HIP(hipStreamWaitEvent(p->side2, p->evFork, 0));
+                    hipStream_t keep = p->side; p->side = p->side2; p->onSide = true;          // launch() follows cur_stream(): the planet's side stream slot
+                    try { launch(p, FAM_FLOW_FINAL, k_flow_events, gridL, WO_BLOCK, F, p->d_out); } catch (...) { p->side = keep; p->onSide = false; throw; }
+                    p->side = keep; p->onSide = false;
+                    WO_HIP(hipEventRecord(p->evJoin2, p->side2));
+                }
             }
             clk.begin("flow");
             // Flow accumulation = subtree sizes of the forward forest (integers: any order of the additions is exact).
@@ -947,9 +971,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             //                    very long unbranched chains, where one thread's walk would bound the launch)
             //  WO_FLOW_CLIMB=0   the synchronous rake rounds + pointer doubling of earlier builds
             // 10 M cells, flow stage per step: rake rounds 108 ms, cap 12: 69, cap 128: 60, cap 256: 59, no cap: 45 (profiles/r02r_*).
-            const char* climbEnv = getenv("WO_FLOW_CLIMB");
-            const int climbCap = climbEnv ? std::max(0, atoi(climbEnv)) : 0x7fffffff;
-            const bool climbAll = climbCap == 0x7fffffff;
             if (climbCap > 0) launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, (const int32_t*)p->d_flowCnt, (int32_t)climbCap);
             if (!climbAll) {
                 {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
@@ -979,11 +1000,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             {
                 Fields Ff = F;
                 if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
-                launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt, basin ? p->d_out : (SolveOut*)nullptr);
+                if (eventsStream) launch(p, FAM_FLOW_FINAL, k_flow_totals, gridL, WO_BLOCK, Ff, p->d_flowCnt);
+                else launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt, basin ? p->d_out : (SolveOut*)nullptr);
             }
             clk.end();
             clk.begin("solve");
             if (basin) {
+                if (basinOverlap && eventsStream) WO_HIP(hipStreamWaitEvent(s, p->evJoin2, 0));
                 if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p, basinJFromReceivers, slotIdentity);
                 F.slotOf = p->d_basinSlot;
                 F.solveLean = 1;
@@ -1159,6 +1182,7 @@ static void erode_composite_checked(wo_planet* p, int32_t hIters, double K, doub
     } catch (const RedoWithChecks&) {
         WO_HIP(hipStreamSynchronize(s));
         if (p->side) WO_HIP(hipStreamSynchronize(p->side));
+        if (p->side2) WO_HIP(hipStreamSynchronize(p->side2));
         WO_HIP(hipMemcpyAsync(p->d_e, p->d_redoE, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
         ++p->redoCalls;
         erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true);
@@ -1269,6 +1293,9 @@ void wo_planet_destroy(wo_planet* p) {
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); p->side = nullptr; }
     if (p->evFork) { (void)hipEventDestroy(p->evFork); p->evFork = nullptr; }
     if (p->evJoin) { (void)hipEventDestroy(p->evJoin); p->evJoin = nullptr; }
+    if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); p->side2 = nullptr; }
+    if (p->evJoin2) { (void)hipEventDestroy(p->evJoin2); p->evJoin2 = nullptr; }
+    dfree(p->d_lateDonor);
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);

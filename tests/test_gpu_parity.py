@@ -381,20 +381,25 @@ def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
     for field in (e0, eq):
         oc = (field <= 0).astype(np.uint8)
         ref = oracle.erode_composite(om, field, xyz, oc, *args, nd)
-        for route in (None, "3", "40", "0"):
+        for route in (None, "3", "40", "0", "events"):
+            monkeypatch.delenv("WO_FLOW_EVENTS_STREAM", raising=False)
             if route is None:
                 monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+            elif route == "events":                     # the solve's event lists on a third stream beside the accumulation, totals pass with late-donor flags
+                monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+                monkeypatch.setenv("WO_FLOW_EVENTS_STREAM", "1")
             else:
                 monkeypatch.setenv("WO_FLOW_CLIMB", route)
             got = field.copy()
             pl.erode_composite(got, oc, *args)
             st = pl.last_erode_stats()
             assert np.array_equal(got, ref), (route, int((got != ref).sum()))
-            if route is None:
+            if route in (None, "events"):
                 assert st["flow_rounds_total"] == 0, st["flow_rounds_total"]          # nothing left for the pointer doubling
             elif route in ("3", "0"):
                 assert st["flow_rounds_total"] > 0, (route, st["flow_rounds_total"])  # the doubling really ran
     monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+    monkeypatch.delenv("WO_FLOW_EVENTS_STREAM", raising=False)
     pl.close()
 
 
