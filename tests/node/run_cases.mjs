@@ -162,6 +162,20 @@ async function main() {
             result.comm = { idBytes: id.length, idNonZero: id.some((b) => b !== 0), errors: errs, unchanged: back.every((v, k) => v === e[k]) };
             break;
         }
+        case 'planet_destroy': {            // explicit release of a planet's device memory: the handle stays, dead
+            const NT = await imp('native.js');
+            const planet = native.planetCreate(NT.defaultContext(), mesh.numRegions, mesh.adjOffset, mesh.adjList, xyz, nd);
+            const e = readArr(j.elevation, Float32Array);
+            native.planetUpload(planet, e, null);
+            const back = new Float32Array(e.length);
+            native.planetDownload(planet, back);
+            native.planetDestroy(planet);
+            let after = null;
+            try { native.planetDownload(planet, back); } catch (ex) { after = ex.constructor.name; }
+            native.planetDestroy(planet);                                   // twice is harmless
+            result.destroy = { roundTrip: back.every((v, k) => v === e[k]), afterDestroy: after };
+            break;
+        }
         case 'error_paths': {
             const errs = [];
             const e = readArr(j.elevation, Float32Array), oc = readArr(j.isOcean, Uint8Array);

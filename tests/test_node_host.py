@@ -224,3 +224,19 @@ def test_js_comm_bindings_single_rank(tmp_path):
     c = res["comm"]
     assert c["idBytes"] == 128 and c["idNonZero"] and c["unchanged"]
     assert c["errors"] == ["RangeError", "Error"], c
+
+
+@pytest.mark.gpu
+def test_js_planet_destroy(tmp_path):
+    """planetDestroy frees a planet's device memory at once (the worker's dispose / re-retain use it): the handle stays behind
+    dead — every entry point then throws instead of touching freed memory — and destroying twice is harmless."""
+    g = load_golden("post_N10000_s1")
+    m = load_golden("mesh_N10000_s1")
+    for k, arr in (("tri", m["triangles"]), ("he", m["halfedges"]), ("xyz", g["xyz"]), ("nd", g["neighborDist"]), ("e0", g["elevation0"])):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"{k}.bin")
+    res = run_node(tmp_path, [
+        {"op": "load_mesh", "tri": "tri.bin", "he": "he.bin", "xyz": "xyz.bin", "nd": "nd.bin", "numRegions": int(g["numRegions"])},
+        {"op": "planet_destroy", "elevation": "e0.bin"},
+    ])
+    d = res["destroy"]
+    assert d["roundTrip"] and d["afterDestroy"] in ("TypeError", "Error"), d
