@@ -254,10 +254,20 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
     unsigned long long a0 = G[far_index(T1.predSelf, S)], a1 = G[far_index(T1.predT, S)], a2 = G[far_index(T1.predT2, S)];
     SolveOut oPrev; oPrev.self.v = 0; oPrev.self.tag = 0; oPrev.dep.v = 0; oPrev.dep.tag = 0;
     bool storePrev = false;
+    uint32_t fPrev = 0; int32_t rPrev = 0, tPrev = 0;                  // Fields::solveFinals: the previous task's finality flags and cells
+    // with solveFinals a task that leaves the LAST event of the pass on a cell writes the cell's new height (and masked height) itself:
+    // k_solve_final — a pass over all land cells that looks the last event up again — is not launched (planet.hip)
+    auto store_prev = [&](int32_t slot) {
+        F.out[slot] = oPrev;
+        if (F.solveFinals) {
+            if (fPrev & 16u) { F.e2[rPrev] = oPrev.self.v; F.me[rPrev] = oPrev.self.v; }
+            if (fPrev & 32u) { F.e2[tPrev] = oPrev.dep.v; F.me[tPrev] = oPrev.dep.v; }
+        }
+    };
     for (int32_t base = S; base < E; base += SC) {
         const int32_t q = base + tid;
         const bool mine = q < E;
-        if (storePrev) F.out[q - SC] = oPrev;                          // a super-chunk late (see k_solve_stream)
+        if (storePrev) store_prev(q - SC);                             // a super-chunk late (see k_solve_stream)
         const SolveTask T = T1;
         T1 = T2;
         T2 = record(base + 2 * SC + tid);
@@ -301,12 +311,12 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
                 }
             }
         }
-        oPrev = o; storePrev = mine && !blocked;
+        oPrev = o; storePrev = mine && !blocked; fPrev = T.flags; rPrev = T.pad_[0]; tPrev = T.pad_[1];
         if (mine && blocked) { atomicAdd(&patchPending[q / WO_PATCH], 1); atomicAdd(totalPending, 1); }
         a0 = n0; a1 = n1; a2 = n2;
         __syncthreads();
     }
-    if (storePrev) F.out[S + ((E - S - 1) / SC) * SC + tid] = oPrev;
+    if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
 }
 
 }  // namespace

@@ -53,7 +53,8 @@ struct alignas(WO_TASK_ALIGN) SolveTask {
     float cellDistT;                   // cellDist[target]
     double factor;                     // K * flow[r]^m * dt / cellDist[r] (js/terrain-post.js:621-622): depends on nothing the pass changes, so
                                        // solve_setup works it out once per task instead of every visit of the task's patch before it may poll
-    int32_t pad_[2];
+    int32_t pad_[2];                   // with Fields::solveFinals: {the task's cell r, its land receiver t or -1}; flags bit4: r's own turn is the LAST event on r, bit5: r's
+                                       // deposit is the last event on t — the solve launch then writes those heights itself and the final pass is not run
 };
 static_assert(sizeof(SolveTask) == 48, "one 48-byte record per task");
 #ifndef WO_PATCH_CELLS
@@ -109,6 +110,7 @@ struct Fields {
     const int32_t* slotOf;              // position of a land cell in the Morton-ordered patch list, -1 for ocean [N]; nullptr: store index = cell
     SolveOut* out;                      // per-task event outputs {own turn, deposit on receiver} [N], at the store index
     double solveK, solveM, solveDt;     // the pass's constants (K, m, dt): solve_setup folds them into SolveTask::factor
+    int32_t solveFinals;                // 1: records carry the finality flags and cells (SolveTask::pad_), cells without any event get their height copied by the setup
     int32_t solveLean;                  // 1: solve_setup writes the task record only — the outputs were cleared by a memset and the blocker hints are
                                         //    made from the records if a launch ever leaves tasks pending (basin-local solve: 20 of the 68 scattered bytes per task)
     uint8_t* lateDonor;                 // [N] set by the receivers pass on a land cell that has a donor ranked after it (its total reaches the cell's flow only in the totals pass); all zero between iterations; nullptr: off
@@ -734,19 +736,8 @@ WO_HD inline bool solve_task(const Fields& F, int32_t r, int32_t round, double K
     return true;
 }
 
-// final height of land cell x after the pass = value left by the latest event on x
-WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
-    if (F.ocean[x]) return F.e[x];
-    if (F.ev) {
-        const EventList E = F.ev[x];
-        if (E.rank[0] != -2) {
-            int32_t last = -1;
-#pragma unroll
-            for (int q = 0; q < WO_EVENTS; ++q) if (E.rank[q] >= 0) last = E.cell[q];           // descending ranks: the last one is the latest
-            if (last < 0) return F.e[x];
-            return (last == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, last)].dep.v;
-        }
-    }
+// the task that leaves the LAST event on land cell x in a pass (x itself: its own turn; a donor: its deposit), by the row scan; -1: no event
+WO_HD inline int32_t latest_event_cell(const Fields& F, int32_t x) {
     int32_t best = -1, bestRank = 0x7fffffff;      // latest == smallest rank
     { const TargetRank v = F.tr[x]; if (v.target >= 0) { best = x; bestRank = v.rank; } }
     int32_t b, nbs[WO_ROW];
@@ -765,6 +756,22 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
             if (v.rank < bestRank) { best = n; bestRank = v.rank; }
         }
     }
+    return best;
+}
+// final height of land cell x after the pass = value left by the latest event on x
+WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
+    if (F.ocean[x]) return F.e[x];
+    if (F.ev) {
+        const EventList E = F.ev[x];
+        if (E.rank[0] != -2) {
+            int32_t last = -1;
+#pragma unroll
+            for (int q = 0; q < WO_EVENTS; ++q) if (E.rank[q] >= 0) last = E.cell[q];           // descending ranks: the last one is the latest
+            if (last < 0) return F.e[x];
+            return (last == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, last)].dep.v;
+        }
+    }
+    const int32_t best = latest_event_cell(F, x);
     if (best < 0) return F.e[x];
     return (best == x) ? F.out[store_index(F, x)].self.v : F.out[store_index(F, best)].dep.v;
 }

@@ -455,6 +455,16 @@ __device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
             }
         }
     }
+    if (F.solveFinals) {
+        // which task leaves the last event on r and on t: the last valid entry of the (descending-rank) lists
+        int32_t lastR = -1, lastT = -1;
+#pragma unroll
+        for (int q = 0; q < WO_EVENTS; ++q) { if (Er.rank[q] >= 0) lastR = Er.cell[q]; if (tLand && EtL.rank[q] >= 0) lastT = EtL.cell[q]; }
+        T.pad_[0] = r; T.pad_[1] = tLand ? t : -1;
+        if (lastR == r) T.flags |= 16u;
+        if (tLand && lastT == r) T.flags |= 32u;
+        if (lastR < 0) { F.e2[r] = e0r; F.me[r] = e0r; }                  // no event on r at all: its height stays
+    }
     F.task[si] = T;
     if (!F.solveLean) {
         SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0;
@@ -462,6 +472,19 @@ __device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
         if (F.blk) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
     }
     return true;
+}
+// the same finality flags for a task set up by the row scans (deferred tasks: an event list involved overflowed)
+__device__ inline void solve_setup_finals_by_rows(const Fields& F, int32_t r) {
+    const int32_t si = F.slotOf ? F.slotOf[r] : r;
+    SolveTask T = F.task[si];
+    const int32_t t = F.tr[r].target;
+    const bool tLand = t >= 0 && F.tr[t].rank >= 0;
+    const int32_t lastR = latest_event_cell(F, r), lastT = tLand ? latest_event_cell(F, t) : -1;
+    T.pad_[0] = r; T.pad_[1] = tLand ? t : -1;
+    if (lastR == r) T.flags |= 16u;
+    if (tLand && lastT == r) T.flags |= 32u;
+    if (lastR < 0) { const float e0 = F.e[r]; F.e2[r] = e0; F.me[r] = e0; }
+    F.task[si] = T;
 }
 // Tasks that need the row scans are collected per workgroup (LDS) and set up by the workgroup's first lanes once its main pass is
 // over: the slow path then runs in one partly filled wave per workgroup instead of inside nearly every wave, and no global
@@ -487,7 +510,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_solve_setup_batched(Fields F, int3
         if (defer) s_deferred[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
     }
     __syncthreads();
-    if ((int32_t)threadIdx.x < s_n) solve_setup_cell_rows(F, s_deferred[threadIdx.x]);
+    if ((int32_t)threadIdx.x < s_n) { solve_setup_cell_rows(F, s_deferred[threadIdx.x]); if (F.solveFinals) solve_setup_finals_by_rows(F, s_deferred[threadIdx.x]); }
 }
 
 // One synchronous round of the solve dataflow.  Tasks come from two places: the leftovers of earlier rounds

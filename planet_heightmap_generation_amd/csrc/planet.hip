@@ -1014,8 +1014,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             }
             // WO_SETUP_BATCHED=0: the setup that decides load by load (solve_setup_cell) instead of k_solve_setup_batched
             static const bool setupBatched = !(getenv("WO_SETUP_BATCHED") && atoi(getenv("WO_SETUP_BATCHED")) == 0);
-            bool countersCleared = false;
+            bool countersCleared = false, solveFinals = false;
             if (setupBatched && F.ev) {
+                // the solve launch writes the final heights itself (SolveTask finality flags) when its result is not looked at pass by pass and
+                // it is the cooperative kernel: no k_solve_final then.  WO_SOLVE_FINALS=0: the final pass as before.
+                static const bool finalsEnv = !(getenv("WO_SOLVE_FINALS") && atoi(getenv("WO_SOLVE_FINALS")) == 0);
+                static const int coopWavesEnv = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
+                solveFinals = finalsEnv && basin && !checkEveryPass && coopWavesEnv >= 2;
+                F.solveFinals = solveFinals ? 1 : 0;
                 // (with the basin solve the setup launch also clears the counters of the solve launch: run_solve_patches' countersCleared)
                 int32_t* zA = basin ? p->d_patchPending : nullptr; const int32_t nA = basin ? p->numPatches : 0;
                 int32_t* zB = basin ? p->d_patchTotals : nullptr; const int32_t nB = basin ? (int32_t)WO_PATCH_TOTAL_SLOTS : 0;
@@ -1033,7 +1039,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
             }
-            launch(p, FAM_SOLVE_FINAL, k_solve_final, gridL, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
+            if (!solveFinals) launch(p, FAM_SOLVE_FINAL, k_solve_final, gridL, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
             swap_elev(p);
             clk.end();
         }
