@@ -2,8 +2,8 @@
 cd /root/repo; mkdir -p gpurun_out/r03ba
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "golden or against_oracle_large or ties or edge_cases or flow_accumulation or mirror_layout or basin_leftovers or sort_routes or glacial_step or pipeline_matches" 2>&1 | tail -2
-for V in finals nofinals finals2 nofinals2; do
-  unset WO_SOLVE_FINALS; case $V in nofinals*) export WO_SOLVE_FINALS=0;; esac
+for V in keys nokeys keys2 nokeys2; do
+  unset WO_KEYS_FROM_APPLY; case $V in nokeys*) export WO_KEYS_FROM_APPLY=0;; esac
   timeout 300 python bench.py --no-cpu --no-profile --in-flight 0 --steps 3 --warmup 1 > gpurun_out/r03ba/$V.json 2> gpurun_out/r03ba/$V.err
   python - $V <<'PY'
 import json,sys
