@@ -856,6 +856,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                             WO_HIP(hipGetDevice(&dev)); WO_HIP(hipGetDeviceProperties(&prop, dev));
                             flowBlocks = std::max(1, std::min(perCu, 8) - 1) * prop.multiProcessorCount;
                         }
+                        // WO_CARVE_FLOW_BLOCKS=<n> (test hook, read per step): at most n workgroups, so that every thread takes many tasks in turn
+                        const int blocksNow = getenv("WO_CARVE_FLOW_BLOCKS") ? std::max(1, std::min(flowBlocks, atoi(getenv("WO_CARVE_FLOW_BLOCKS")))) : flowBlocks;
                         static const int32_t flowWatch = getenv("WO_CARVE_FLOW_WATCH") ? atoi(getenv("WO_CARVE_FLOW_WATCH")) : 1;
                         static const int32_t flowSleep = getenv("WO_CARVE_FLOW_SLEEP") ? atoi(getenv("WO_CARVE_FLOW_SLEEP")) : 0;
                         const long long flowBudget = (getenv("WO_CARVE_FLOW_BUDGET_MS") ? atoll(getenv("WO_CARVE_FLOW_BUDGET_MS")) : 200) * 100000ll;   // 100 MHz ticks
@@ -863,11 +865,11 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                             if (!p->d_carveG) p->d_carveG = dalloc<unsigned long long>((size_t)N);
                             launch(p, FAM_CARVE_SETUP, k_carve_expect, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const int32_t*)(c + 3), p->d_carveExpect);
                             launch(p, FAM_CARVE_SETUP, k_carve_pack, blocks_for(N, 4096), WO_BLOCK, (const float*)F.e, p->d_carveG, N);
-                            launch(p, FAM_CARVE_ROUND, k_carve_granules, std::min(grid, flowBlocks), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const CarveExpect*)p->d_carveExpect, p->d_carveG,
+                            launch(p, FAM_CARVE_ROUND, k_carve_granules, std::min(grid, blocksNow), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const CarveExpect*)p->d_carveExpect, p->d_carveG,
                                    p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget);
                             launch(p, FAM_CARVE_SETUP, k_carve_unpack, blocks_for(N, 4096), WO_BLOCK, (const unsigned long long*)p->d_carveG, F.e, N);
                         } else
-                        launch(p, FAM_CARVE_ROUND, k_carve_flow, std::min(grid, flowBlocks), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget, flowWatch, flowSleep);
+                        launch(p, FAM_CARVE_ROUND, k_carve_flow, std::min(grid, blocksNow), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget, flowWatch, flowSleep);
                         ++k;
                         const int32_t fin = read_count(p, done);
                         allDone = fin >= active;

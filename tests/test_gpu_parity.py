@@ -697,6 +697,15 @@ def test_glacial_step_routes_agree(TP, oracle, monkeypatch):
         st = pl.last_erode_stats()
         assert st["carve_flow_launches_with_leftovers"] > 0, (mode, st)
         assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
+        # two workgroups for thousands of tasks: every thread takes many positions of the (rank-ordered) activation list in turn, which is
+        # how a planet with more active tasks than resident threads runs (40 M cells); the launch must still finish everything itself
+        monkeypatch.delenv("WO_CARVE_FLOW_BUDGET_MS")
+        monkeypatch.setenv("WO_CARVE_FLOW_BLOCKS", "2")
+        got = e0.copy(); pl.erode_composite(got, oc, *args)
+        st = pl.last_erode_stats()
+        assert st["carve_flow_launches_with_leftovers"] == 0 and st["carve_rounds_total"] == 4, (mode, st)
+        assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
+        monkeypatch.delenv("WO_CARVE_FLOW_BLOCKS")
     pl.close()
 
 
