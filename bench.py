@@ -197,6 +197,12 @@ class Decomposition:
             self.mask = self.plan.rank_mask(self.rank, oc)
             self.true_oc = oc
             self.link = D.ResidentLandmass(self.plan, self.rank, self.pl)
+            # equal flood keys that matter (every flood call at 40 M cells): the ranks pool their heights and the undecided rank
+            # floods the whole planet (include/worogen.h: wo_planet_set_flood_exchange)
+            if self.comm is not None:
+                self.pl.set_flood_exchange(oc, comm=self.comm, counts=[int(c.size) for c in self.plan.cells], cells_by_rank=np.concatenate(self.plan.cells))
+            else:
+                self.pl.set_flood_exchange(oc, D.TorchFloodExchange(self.plan, self.rank, self.dist, self.device))
             self.plan_ms = (time.perf_counter() - t0) * 1e3
         self.pl.upload(None, self.mask)
 

@@ -191,6 +191,24 @@ int wo_comm_size(const wo_comm* comm);
 int wo_planet_exchange_allgather(wo_planet* planet, wo_comm* comm, const int32_t* counts);
 int wo_planet_exchange_neighbors(wo_planet* planet, wo_comm* comm, int32_t nToPrev, int32_t nFromPrev);
 
+/* The flood exchange of the landmass decomposition.  priorityFloodCarve pops ONE heap over the whole planet
+ * (js/terrain-post.js:131-147); how that heap orders EQUAL keys depends on everything in it, the other ranks' landmasses at
+ * their current heights included.  A rank's flood proves for each of its landmasses that no equal-key decision matters, or
+ * reports it undecided (csrc/flood_host.cc).  With an exchange set, every flood call of erodeComposite then (phase 0) agrees
+ * with the other ranks whether any rank is undecided and, if so, (phase 1) pools the heights of all land cells at that call;
+ * an undecided rank floods the whole planet on the true mask exactly as the unpartitioned run does and keeps its own cells.
+ * Never needed at 10 M cells; at 40 M cells in every call.  All ranks make the same calls.
+ *   fn(user, 0, int32_t flag[1], 1)        flag := max over the ranks
+ *   fn(user, 1, float field[numRegions], numRegions)   in: the rank's own land cells hold their heights; out: every land cell does
+ * fn returns 0 on success; a non-zero status fails the erodeComposite call.  r_isOcean_true: the planet's real mask (the
+ * resident mask is the rank's: other ranks' landmasses are ocean).  fn == NULL switches the exchange off.
+ * wo_planet_set_flood_exchange_comm: the same over RCCL — counts[j] land cells of rank j, their region ids concatenated in
+ * rank order in cellsByRank (ncclAllReduce of the flag, ncclAllGather of the heights). */
+typedef int (*wo_flood_exchange_fn)(void* user, int32_t phase, void* buf, int64_t n);
+int wo_planet_set_flood_exchange(wo_planet* planet, const uint8_t* r_isOcean_true, wo_flood_exchange_fn fn, void* user);
+int wo_planet_set_flood_exchange_comm(wo_planet* planet, const uint8_t* r_isOcean_true, wo_comm* comm, const int32_t* counts,
+                                      const int32_t* cellsByRank);
+
 /* ------------------------------------------------ landmass decomposition --------- */
 /* Connected components of the land cells (cells with r_isOcean == 0, joined along mesh edges).  label[r] = smallest
  * region id of r's landmass, -1 for ocean cells.  Every order-defined pass of erodeComposite (js/terrain-post.js:369-707:

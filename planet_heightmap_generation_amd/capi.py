@@ -70,6 +70,8 @@ SIGNATURES = {
     "wo_comm_size": (C.c_int, [_p]),
     "wo_planet_exchange_allgather": (C.c_int, [_p, _p, _p]),
     "wo_planet_exchange_neighbors": (C.c_int, [_p, _p, _c_i32, _c_i32]),
+    "wo_planet_set_flood_exchange": (C.c_int, [_p, _p, _p, _p]),
+    "wo_planet_set_flood_exchange_comm": (C.c_int, [_p, _p, _p, _p, _p]),
     "wo_planet_ocean_from_elevation": (C.c_int, [_p]),
     "wo_planet_download_ocean": (C.c_int, [_p, _p]),
     "wo_planet_sync": (C.c_int, [_p]),
@@ -90,6 +92,9 @@ SIGNATURES = {
     "wo_last_stage_timing": (C.c_int, [_p, _c_i32, _p, _p, _p]),
     "wo_last_erode_stats": (C.c_int, [_p, _c_i32, _p, _p, _p]),
 }
+
+# wo_flood_exchange_fn: int fn(void* user, int32_t phase, void* buf, int64_t n)
+FLOOD_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64)
 
 _lib = None
 MISSING: list[str] = []

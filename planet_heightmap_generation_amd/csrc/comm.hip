@@ -14,6 +14,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/worogen.h"
 #include "device.h"
@@ -38,6 +39,83 @@ bool nccl_ok(ncclResult_t r, const char* what) {
     wo::set_error(std::string(what) + ": " + ncclGetErrorString(r));
     return false;
 }
+// every exchange entry point: the planet's device current, and the communicator living on that device
+bool comm_ready(wo_planet* p, wo_comm* c, const char* fn) {
+    if (!p || !c || !p->ctx) { wo::set_error(std::string(fn) + ": bad arguments"); return false; }
+    if (c->device != p->ctx->device) { wo::set_error(std::string(fn) + ": the communicator was created on another device than the planet's"); return false; }
+    const hipError_t e = hipSetDevice(p->ctx->device);
+    if (e != hipSuccess) { wo::set_error(std::string(fn) + ": hipSetDevice failed: " + hipGetErrorString(e)); return false; }
+    return true;
+}
+// ncclGroupStart is always answered by ncclGroupEnd, whatever happens in between
+struct GroupGuard {
+    bool open = false;
+    bool start() { open = nccl_ok(ncclGroupStart(), "ncclGroupStart"); return open; }
+    bool end() { if (!open) return true; open = false; return nccl_ok(ncclGroupEnd(), "ncclGroupEnd"); }
+    ~GroupGuard() { if (open) (void)ncclGroupEnd(); }
+};
+
+// RCCL form of the landmass decomposition's flood exchange (wo_planet_set_flood_exchange_comm)
+struct FloodLink {
+    wo_planet* planet = nullptr; wo_comm* comm = nullptr;
+    std::vector<int32_t> counts, cells;              // cells: every rank's land cells, concatenated in rank order
+    std::vector<int64_t> start;
+    int32_t maxCount = 1;
+    int32_t* d_flag = nullptr; int32_t* h_flag = nullptr;
+    float *d_send = nullptr, *d_all = nullptr, *h_send = nullptr, *h_all = nullptr;
+};
+void flood_link_free(void* v) {
+    FloodLink* k = (FloodLink*)v;
+    if (!k) return;
+    if (k->d_flag) (void)hipFree(k->d_flag);
+    if (k->h_flag) (void)hipHostFree(k->h_flag);
+    if (k->d_send) (void)hipFree(k->d_send);
+    if (k->d_all) (void)hipFree(k->d_all);
+    if (k->h_send) (void)hipHostFree(k->h_send);
+    if (k->h_all) (void)hipHostFree(k->h_all);
+    delete k;
+}
+int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
+    FloodLink* k = (FloodLink*)user;
+    wo_comm* c = k->comm;
+    hipStream_t s = k->planet->ctx->stream;
+    try {
+        if (hipSetDevice(k->planet->ctx->device) != hipSuccess) { wo::set_error("flood exchange: hipSetDevice failed"); return 1; }
+        if (phase == 0) {
+            *k->h_flag = *(int32_t*)buf;
+            WO_HIP(hipMemcpyAsync(k->d_flag, k->h_flag, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            if (!nccl_ok(ncclAllReduce(k->d_flag, k->d_flag, 1, ncclInt32, ncclMax, c->comm, s), "ncclAllReduce")) return 1;
+            WO_HIP(hipMemcpyAsync(k->h_flag, k->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            WO_HIP(hipStreamSynchronize(s));
+            *(int32_t*)buf = *k->h_flag;
+            return 0;
+        }
+        float* field = (float*)buf;
+        const size_t M = (size_t)k->maxCount;
+        if (!k->d_send) {
+            WO_HIP(hipMalloc((void**)&k->d_send, M * sizeof(float)));
+            WO_HIP(hipMalloc((void**)&k->d_all, M * (size_t)c->nranks * sizeof(float)));
+            WO_HIP(hipHostMalloc((void**)&k->h_send, M * sizeof(float)));
+            WO_HIP(hipHostMalloc((void**)&k->h_all, M * (size_t)c->nranks * sizeof(float)));
+        }
+        const int32_t* mine = k->cells.data() + k->start[c->rank];
+        const int32_t nMine = k->counts[c->rank];
+        for (int32_t i = 0; i < nMine; ++i) { if (mine[i] >= n) { wo::set_error("flood exchange: cell id out of range"); return 1; } k->h_send[i] = field[mine[i]]; }
+        for (size_t i = (size_t)nMine; i < M; ++i) k->h_send[i] = 0.0f;
+        WO_HIP(hipMemcpyAsync(k->d_send, k->h_send, M * sizeof(float), hipMemcpyHostToDevice, s));
+        if (!nccl_ok(ncclAllGather(k->d_send, k->d_all, M, ncclFloat, c->comm, s), "ncclAllGather")) return 1;
+        WO_HIP(hipMemcpyAsync(k->h_all, k->d_all, M * (size_t)c->nranks * sizeof(float), hipMemcpyDeviceToHost, s));
+        WO_HIP(hipStreamSynchronize(s));
+        for (int32_t j = 0; j < c->nranks; ++j) {
+            if (j == c->rank) continue;
+            const int32_t* cj = k->cells.data() + k->start[j];
+            const float* vj = k->h_all + (size_t)j * M;
+            wo::parallel_ranges(k->counts[j], [&](int64_t b, int64_t e, int) { for (int64_t i = b; i < e; ++i) field[cj[i]] = vj[i]; });
+        }
+        return 0;
+    } catch (const wo::HipError& e) { wo::set_error(std::string("flood exchange: ") + e.msg); return 1; }
+}
+
 template <class T> void grow(T*& p, size_t& cap, size_t need) {
     if (need <= cap) return;
     if (p) (void)hipFree(p);
@@ -85,7 +163,8 @@ int wo_comm_size(const wo_comm* c) { return c ? c->nranks : 0; }
 // counts[j] = length of rank j's send list (counts[rank] must equal this planet's); the receive list (set_halo) is the
 // concatenation of the other ranks' contributions in rank order.
 int wo_planet_exchange_allgather(wo_planet* p, wo_comm* c, const int32_t* counts) {
-    if (!p || !c || !counts) { wo::set_error("wo_planet_exchange_allgather: bad arguments"); return 1; }
+    if (!counts) { wo::set_error("wo_planet_exchange_allgather: bad arguments"); return 1; }
+    if (!comm_ready(p, c, "wo_planet_exchange_allgather")) return 1;
     int64_t others = 0; int32_t maxCount = 1;
     for (int32_t j = 0; j < c->nranks; ++j) { if (counts[j] < 0) { wo::set_error("wo_planet_exchange_allgather: negative count"); return 1; } if (j != c->rank) others += counts[j]; maxCount = std::max(maxCount, counts[j]); }
     if (counts[c->rank] != p->nHaloSend || others != p->nHaloRecv) { wo::set_error("wo_planet_exchange_allgather: counts do not match the planet's halo lists (wo_planet_set_halo)"); return 1; }
@@ -113,7 +192,7 @@ int wo_planet_exchange_allgather(wo_planet* p, wo_comm* c, const int32_t* counts
 // Chain neighbours: the first nToPrev entries of the send list go to rank - 1, the rest to rank + 1; the first nFromPrev
 // entries of the receive list come from rank - 1, the rest from rank + 1.  A missing neighbour (ends of the chain) has count 0.
 int wo_planet_exchange_neighbors(wo_planet* p, wo_comm* c, int32_t nToPrev, int32_t nFromPrev) {
-    if (!p || !c) { wo::set_error("wo_planet_exchange_neighbors: bad arguments"); return 1; }
+    if (!comm_ready(p, c, "wo_planet_exchange_neighbors")) return 1;
     const int32_t nToNext = p->nHaloSend - nToPrev, nFromNext = p->nHaloRecv - nFromPrev;
     const bool hasPrev = c->rank > 0, hasNext = c->rank + 1 < c->nranks;
     if (nToPrev < 0 || nFromPrev < 0 || nToNext < 0 || nFromNext < 0 || (!hasPrev && (nToPrev || nFromPrev)) || (!hasNext && (nToNext || nFromNext))) {
@@ -124,17 +203,40 @@ int wo_planet_exchange_neighbors(wo_planet* p, wo_comm* c, int32_t nToPrev, int3
         grow(c->send, c->sendCap, (size_t)std::max(p->nHaloSend, 1));
         if (!c->send) { wo::set_error("wo_planet_exchange_neighbors: out of device memory"); return 1; }
         if (p->nHaloSend > 0) wo::launch(p, wo::FAM_MISC, k_comm_pack, wo::blocks_for(p->nHaloSend), wo::WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_haloSend, p->nHaloSend, c->send);
-        if (!nccl_ok(ncclGroupStart(), "ncclGroupStart")) return 1;
+        GroupGuard group;
+        if (!group.start()) return 1;
         bool ok = true;
         if (hasPrev && nToPrev) ok = ok && nccl_ok(ncclSend(c->send, (size_t)nToPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclSend");
         if (hasNext && nToNext) ok = ok && nccl_ok(ncclSend(c->send + nToPrev, (size_t)nToNext, ncclFloat, c->rank + 1, c->comm, s), "ncclSend");
         if (hasPrev && nFromPrev) ok = ok && nccl_ok(ncclRecv(p->d_haloBuf, (size_t)nFromPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclRecv");
         if (hasNext && nFromNext) ok = ok && nccl_ok(ncclRecv(p->d_haloBuf + nFromPrev, (size_t)nFromNext, ncclFloat, c->rank + 1, c->comm, s), "ncclRecv");
-        if (!nccl_ok(ncclGroupEnd(), "ncclGroupEnd") || !ok) return 1;
+        if (!group.end() || !ok) { (void)ncclCommAbort(c->comm); c->comm = nullptr; wo::set_error("wo_planet_exchange_neighbors: send / receive failed, the communicator was aborted"); return 1; }
         if (p->nHaloRecv > 0) wo::launch(p, wo::FAM_MISC, k_comm_unpack, wo::blocks_for(p->nHaloRecv), wo::WO_BLOCK, p->d_e, (const int32_t*)p->d_haloRecv, p->nHaloRecv, (const float*)p->d_haloBuf);
         WO_HIP(hipStreamSynchronize(s));
         return 0;
     } catch (const wo::HipError& e) { wo::set_error(std::string("wo_planet_exchange_neighbors: ") + e.msg); return 1; }
+}
+
+int wo_planet_set_flood_exchange_comm(wo_planet* p, const uint8_t* trueOcean, wo_comm* c, const int32_t* counts, const int32_t* cellsByRank) {
+    if (!counts || !cellsByRank || !trueOcean) { wo::set_error("wo_planet_set_flood_exchange_comm: bad arguments"); return 1; }
+    if (!comm_ready(p, c, "wo_planet_set_flood_exchange_comm")) return 1;
+    FloodLink* k = new FloodLink;
+    k->planet = p; k->comm = c;
+    k->counts.assign(counts, counts + c->nranks);
+    k->start.assign((size_t)c->nranks + 1, 0);
+    for (int32_t j = 0; j < c->nranks; ++j) {
+        if (counts[j] < 0) { delete k; wo::set_error("wo_planet_set_flood_exchange_comm: negative count"); return 1; }
+        k->start[j + 1] = k->start[j] + counts[j];
+        k->maxCount = std::max(k->maxCount, counts[j]);
+    }
+    k->cells.assign(cellsByRank, cellsByRank + k->start[c->nranks]);
+    for (int32_t v : k->cells) if (v < 0 || v >= p->N) { delete k; wo::set_error("wo_planet_set_flood_exchange_comm: cell id out of range"); return 1; }
+    if (hipMalloc((void**)&k->d_flag, sizeof(int32_t)) != hipSuccess || hipHostMalloc((void**)&k->h_flag, sizeof(int32_t)) != hipSuccess) {
+        flood_link_free(k); wo::set_error("wo_planet_set_flood_exchange_comm: out of memory"); return 1;
+    }
+    if (wo_planet_set_flood_exchange(p, trueOcean, flood_link_exchange, k) != 0) { flood_link_free(k); return 1; }     // (frees a previous link)
+    p->floodLink = k; p->floodLinkFree = flood_link_free;
+    return 0;
 }
 
 }  // extern "C"

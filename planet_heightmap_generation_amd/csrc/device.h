@@ -95,6 +95,8 @@ struct wo_planet {
     float* d_redoE = nullptr; int32_t* d_pendingEver = nullptr; int64_t redoCalls = 0;   // erode_composite_checked: the field at entry, tasks any basin launch of the call left pending, calls that had to run again
     unsigned long long *h_word = nullptr, *d_word = nullptr; uint32_t wordSerial = 0;   // host-mapped {serial, value} word the host polls (planet.hip: publish_and_wait)
     wo::FloodScratch flood;
+    wo::FloodExchange floodX;           // landmass decomposition: the shares pool their heights when a flood call needs the whole planet's heap (wo_planet_set_flood_exchange)
+    void* floodLink = nullptr; void (*floodLinkFree)(void*) = nullptr;   // comm.hip: state of the RCCL form of that exchange
     wo_flood_gpu fgpu;
 
     // resident mesh

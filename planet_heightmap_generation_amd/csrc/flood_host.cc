@@ -912,7 +912,7 @@ void replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
 // its walk, the carving of all the others is already done.  Landmasses whose walk met an equal-key decision that matters
 // are left out of the first round, re-walked inside the replay of the single heap (above) and carved in a second round.
 // On return e holds the reference's result; FloodScratch is consumed (the caller gathers again before another call).
-bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo) {
+bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo, bool replayAllowed) {
     const double EPS = 1e-7;
     FloodTimer T;
     const int32_t nComp = (int32_t)S.compSize.size();
@@ -1064,7 +1064,17 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     for (const Local& l : loc) { rep.groups += l.groups; rep.nested += l.nested; rep.contested += l.contested; rep.unresolved += l.unresolved; rep.openParents += (int64_t)l.alt.size(); }
     std::vector<int32_t> redo;
     for (int32_t k = 0; k < nComp; ++k) if (dirty[k]) redo.push_back(k);
+    if (!redo.empty()) {
+        // A replay is going to run.  A landmass that is otherwise decided but holds an open parent x (claimants p0, p1 with equal
+        // keys) would push x when the walk's claimant p0 pops; the reference may push it when p1 pops — same result for the
+        // landmass, but a different heap array from then on, i.e. possibly a different choice between equal keys elsewhere.
+        // Such landmasses are walked for real inside the replay as well (they are rare and the replay's cost is the bare heap's).
+        bool added = false;
+        for (const Local& l : loc) for (int32_t k : l.altComp) if (!dirty[k]) { dirty[k] = 1; added = true; }
+        if (added) { redo.clear(); for (int32_t k = 0; k < nComp; ++k) if (dirty[k]) redo.push_back(k); }
+    }
     rep.replayed = (int32_t)redo.size();
+    if (!redo.empty() && !replayAllowed) return false;
     if (T.on) std::fprintf(stderr, "[flood] landmasses %d, workers %d, tie groups %lld (nested %lld), contested %lld, open parents %lld, undecided %lld -> %d landmasses through the replay\n",
                            rep.landmasses, rep.workers, (long long)rep.groups, (long long)rep.nested, (long long)rep.contested, (long long)rep.openParents, (long long)rep.unresolved, rep.replayed);
     if (!redo.empty()) {
@@ -1120,6 +1130,48 @@ void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHos
         st.pass1Ms += ms(t0, t1); st.pass23Ms += ms(t1, clock::now());
         ++st.serialPass1;
     }
+}
+
+int flood_host_passes_exchange(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, double carveStrength,
+                               FloodScratch& S, FloodHostStats* stats, FloodExchange& X) {
+    using clock = std::chrono::steady_clock;
+    auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    FloodHostStats local;
+    FloodHostStats& st = stats ? *stats : local;
+    ++st.calls; ++X.calls;
+    // the heights at this call, before anything is carved: what this share contributes to the pool
+    X.snapshot.resize((size_t)N);
+    float* snap = X.snapshot.data();
+    parallel_ranges(N, [&](int64_t b, int64_t en, int) { std::memcpy(snap + b, e + b, sizeof(float) * (size_t)(en - b)); });
+    int32_t flag = 0;
+    if (S.L > 0) {
+        flood_gather(e, S);
+        FloodTieReport rep;
+        auto t0 = clock::now();
+        const bool done = flood_landmass_pipeline(e, carveStrength, S, rep, st.pathRedo, false);
+        st.pass1Ms += ms(t0, clock::now());
+        st.tieGroups += rep.groups; st.contested += rep.contested; st.openParents += rep.openParents; st.unresolved += rep.unresolved;
+        flag = done ? 0 : 1;
+    }
+    const int32_t mine = flag;
+    if (int rc = X.fn(X.user, 0, &flag, 1)) return rc;
+    if (!flag) return 0;
+    ++X.gathers;
+    if (int rc = X.fn(X.user, 1, snap, N)) return rc;
+    if (!mine) return 0;
+    // undecided here: the whole planet, as the unpartitioned run floods it
+    ++X.globalFloods;
+    FloodScratch& G = X.global;
+    if (!G.staticValid || G.staticN != N) flood_build_static(N, off, adj, xyz, X.trueOcean.data(), G);
+    flood_gather(snap, G);
+    FloodTieReport rep;
+    auto t0 = clock::now();
+    flood_landmass_pipeline(snap, carveStrength, G, rep, st.pathRedo, true);
+    st.pass1Ms += ms(t0, clock::now());
+    if (rep.replayed) { ++st.replays; st.replayedLandmasses += rep.replayed; }
+    const int32_t* landCell = S.landCell.data();
+    parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = snap[landCell[i]]; });
+    return 0;
 }
 
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,

@@ -510,9 +510,9 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     if (!S.staticValid || S.staticN != p->N)
         flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S);
     lap("static");
-    if (S.L == 0) return;
+    if (S.L == 0 && !p->floodX.on) return;       // (a share without land still takes part in the exchange)
     const char* fe = std::getenv("WO_FLOOD");
-    const bool hostOnly = !(fe && std::string(fe) == "device");
+    const bool hostOnly = p->floodX.on || !(fe && std::string(fe) == "device");
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     const bool useDevice = !hostOnly && flood_device_pass1(p, R);       // synchronises the stream
     if (hostOnly) WO_HIP(hipStreamSynchronize(s));
@@ -521,6 +521,10 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
         flood_gather(p->h_pinned, S);
         flood_import_pass1(p->fgpu.h_par, p->fgpu.h_surf, p->fgpu.h_root, S);
         flood_pass23_host(p->h_pinned, carveStrength, S);
+    } else if (p->floodX.on) {
+        if (p->floodX.trueOcean.size() != (size_t)p->N) throw HipError{"flood exchange: the true ocean mask does not fit the planet"};
+        const int rc = flood_host_passes_exchange(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, carveStrength, S, &R.host, p->floodX);
+        if (rc) throw HipError{"flood exchange: the host's exchange function failed (status " + std::to_string(rc) + ")"};
     } else {
         flood_host_passes(p->h_pinned, carveStrength, S, &R.host);
     }
@@ -687,7 +691,23 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             L = (int32_t)cnt.back();
         }
         p->L = L;
-        if (L == 0) { clk.end(); clk.finish(); return; }
+        if (L == 0) {
+            // a share without land (landmass decomposition of a small planet) still answers the other shares' flood exchanges
+            if (p->floodX.on) {
+                const int32_t midIter0 = (int32_t)std::floor(total * 0.75 + 0.5);
+                const int calls = (hIters > 0 ? 1 : 0) + (midIter0 < total ? 1 : 0);
+                WO_HIP(hipMemcpyAsync(p->h_pinned, mir.on ? p->mirror.o_e : p->d_e, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, s));
+                WO_HIP(hipStreamSynchronize(s));
+                if (!p->flood.staticValid || p->flood.staticN != N)
+                    flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), p->flood);
+                for (int k = 0; k < calls; ++k) {
+                    const int rc = flood_host_passes_exchange(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, 0.5, p->flood, nullptr, p->floodX);
+                    if (rc) throw HipError{"flood exchange: the host's exchange function failed (status " + std::to_string(rc) + ")"};
+                }
+            }
+            mir.finish();
+            clk.end(); clk.finish(); return;
+        }
         if (mir.on) {
             // initial landCells: the same cells in the same (ascending-r) order, under their mirror names
             WO_HIP(hipMemcpyAsync(p->d_listA, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -1086,7 +1106,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"flood_host_tie_groups", (double)floodRun.host.tieGroups}, {"flood_host_contested", (double)floodRun.host.contested},
                      {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
                      {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_replays", (double)floodRun.host.replays}, {"flood_host_replayed_landmasses", (double)floodRun.host.replayedLandmasses}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
-                     {"flood_host_pass23_ms", floodRun.host.pass23Ms}};
+                     {"flood_host_pass23_ms", floodRun.host.pass23Ms},
+                     {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
@@ -1297,6 +1318,8 @@ void wo_planet_destroy(wo_planet* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     dfree(p->d_off); dfree(p->d_adj); dfree(p->d_dist); dfree(p->d_xyz); dfree(p->d_e); dfree(p->d_e2); dfree(p->d_hot); dfree(p->d_orig);
     flood_gpu_free(p->fgpu);
+    if (p->floodLink && p->floodLinkFree) p->floodLinkFree(p->floodLink);
+    p->floodLink = nullptr;
     basin_free(p);
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); p->side = nullptr; }
     if (p->evFork) { (void)hipEventDestroy(p->evFork); p->evFork = nullptr; }
@@ -1362,6 +1385,23 @@ int wo_planet_set_halo(wo_planet* p, const int32_t* sendIdx, int32_t nSend, cons
     return 0;
     WO_CATCH("wo_planet_set_halo")
 }
+// ---- landmass decomposition: the shares' flood exchange (flood_host.cc: flood_host_passes_exchange) ----
+int wo_planet_set_flood_exchange(wo_planet* p, const uint8_t* trueOcean, wo_flood_exchange_fn fn, void* user) {
+    if (!check_planet(p, "wo_planet_set_flood_exchange")) return 1;
+    try {
+        if (p->floodLink && p->floodLinkFree) { p->floodLinkFree(p->floodLink); }
+        p->floodLink = nullptr; p->floodLinkFree = nullptr;
+        FloodExchange& X = p->floodX;
+        if (!fn) { X.on = false; X.fn = nullptr; X.user = nullptr; X.trueOcean.clear(); X.global = FloodScratch{}; return 0; }
+        if (!trueOcean) { set_error("wo_planet_set_flood_exchange: the planet's true ocean mask is required"); return 1; }
+        const bool same = X.trueOcean.size() == (size_t)p->N && std::memcmp(X.trueOcean.data(), trueOcean, (size_t)p->N) == 0;
+        if (!same) { X.trueOcean.assign(trueOcean, trueOcean + p->N); X.global.staticValid = false; }
+        X.fn = fn; X.user = user; X.on = true;
+        X.calls = X.gathers = X.globalFloods = 0;
+        return 0;
+    WO_CATCH("wo_planet_set_flood_exchange")
+}
+
 int wo_planet_pack_halo(wo_planet* p, float* hostOut, void* deviceOut) {
     if (!check_planet(p, "wo_planet_pack_halo")) return 1;
     if ((hostOut == nullptr) == (deviceOut == nullptr)) { set_error("wo_planet_pack_halo: pass exactly one of hostOut / deviceOut"); return 1; }

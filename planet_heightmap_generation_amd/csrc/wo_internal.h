@@ -69,10 +69,33 @@ bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep);
 // inside a replay of the reference's single heap (bare heap operations for everything else) and carved afterwards, so the
 // call always ends with the reference's result in e.  FloodScratch's per-call arrays are consumed: flood_gather() before
 // the next use.
-bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo);
+// replayAllowed == false: a call that would need the replay returns false instead and leaves e untouched (the caller has a
+// better heap to replay: flood_host_passes_exchange)
+bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo, bool replayAllowed = true);
 // pass 1 (landmass-parallel when exact, else the serial walk) + passes 2/3; stats: see flood_host.cc
 struct FloodHostStats { int64_t calls = 0, serialPass1 = 0, tieGroups = 0, contested = 0, openParents = 0, unresolved = 0, pathRedo = 0, replays = 0, replayedLandmasses = 0; double pass1Ms = 0, pass23Ms = 0; };
 void flood_host_passes(float* e, double carveStrength, FloodScratch& S, FloodHostStats* stats);
+// The flood of ONE SHARE of a planet (landmass decomposition, decomposed.py: the other shares' landmasses are ocean to S).  A share's
+// landmasses flood exactly as in the whole planet as long as no equal-key decision matters; when one does, only the reference's
+// single heap over the WHOLE planet knows the answer (js/terrain-post.js:131-147), and that heap holds the other shares' cells at
+// their CURRENT heights.  So the shares agree (phase 0: any share undecided?) and, if so, pool the heights their land cells have
+// at this flood call (phase 1); an undecided share then floods the whole planet on the true mask — landmass pipeline + replay,
+// exactly what the unpartitioned run does — and keeps its own cells of the result.
+//   fn(user, 0, int32_t flag[1], 1)          flag := max over the shares                                  (collective)
+//   fn(user, 1, float field[N], N)           in: own land cells hold their heights; out: every land cell (collective)
+// Both return 0 on success.  trueOcean: the planet's real mask (N bytes); off / adj / xyz: the mesh (borrowed).
+using FloodExchangeFn = int (*)(void* user, int32_t phase, void* buf, int64_t n);
+struct FloodExchange {
+    bool on = false;
+    FloodExchangeFn fn = nullptr; void* user = nullptr;
+    hvec<uint8_t> trueOcean;
+    hvec<float> snapshot;
+    FloodScratch global;                     // tables of the true mask, built when first needed
+    int64_t calls = 0, gathers = 0, globalFloods = 0;
+};
+// returns 0, or the non-zero status of fn
+int flood_host_passes_exchange(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, double carveStrength,
+                               FloodScratch& S, FloodHostStats* stats, FloodExchange& X);
 void flood_import_pass1(const int32_t* par, const float* surface, const int32_t* root, FloodScratch& S);
 // openAlt: cells whose parent pass 1 could not decide between equal keys (same surface either way); returns false when
 // the carve / fix-up result depends on that choice (nothing is written back to e then)

@@ -178,3 +178,128 @@ class ResidentLandmass:
             parts = [out[j][:sizes[j]] for j in range(plan.world) if j != rank and sizes[j]]
             if parts:
                 self.planet.unpack_halo(torch.cat(parts).numpy())
+
+
+class TorchFloodExchange:
+    """Planet.set_flood_exchange over torch.distributed (gloo in the CPU tests and rehearsals; host-staged, the data is a few MB
+    and only moves when a rank's flood is undecided): the flag by all_reduce(MAX), the heights by all_gather of each rank's land
+    cells (plan.cells)."""
+
+    def __init__(self, plan: LandmassPlan, rank: int, dist, device=None):
+        self.plan, self.rank, self.dist, self.device = plan, rank, dist, device      # device: tensors must live there (nccl backend)
+
+    def allreduce_max(self, flag: int) -> int:
+        import torch
+        t = torch.tensor([int(flag)], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def allgather(self, field: np.ndarray) -> None:
+        if self.device is None:
+            merge_land(self.plan, self.rank, field, self.dist)
+            return
+        import torch
+        plan, rank = self.plan, self.rank
+        n_max = max(1, plan.max_cells)
+        send = torch.zeros(n_max, dtype=torch.float32)
+        mine = plan.cells[rank]
+        send[:mine.size] = torch.from_numpy(np.ascontiguousarray(field[mine]))
+        out = torch.empty(plan.world * n_max, dtype=torch.float32, device=self.device)
+        self.dist.all_gather_into_tensor(out, send.to(self.device))
+        host = out.cpu().numpy()
+        for j in range(plan.world):
+            if j != rank and plan.cells[j].size:
+                field[plan.cells[j]] = host[j * n_max: j * n_max + plan.cells[j].size]
+
+
+class ThreadFloodExchange:
+    """The same between the shares of ONE process (one host thread, context and planet per share: the partitioned code path
+    rehearsed on a single GPU).  One instance per share from ThreadFloodExchange.group(plan)."""
+
+    class _Shared:
+        def __init__(self, world):
+            import threading
+            self.barrier = threading.Barrier(world)
+            self.flags = [0] * world
+            self.fields = [None] * world
+
+    def __init__(self, plan: LandmassPlan, rank: int, shared):
+        self.plan, self.rank, self.shared = plan, rank, shared
+
+    @classmethod
+    def group(cls, plan: LandmassPlan):
+        sh = cls._Shared(plan.world)
+        return [cls(plan, k, sh) for k in range(plan.world)]
+
+    def abort(self):
+        self.shared.barrier.abort()
+
+    def allreduce_max(self, flag: int) -> int:
+        sh = self.shared
+        sh.flags[self.rank] = int(flag)
+        sh.barrier.wait()
+        out = max(sh.flags)
+        sh.barrier.wait()                  # nobody overwrites its flag for the next call before everybody has read
+        return out
+
+    def allgather(self, field: np.ndarray) -> None:
+        sh = self.shared
+        sh.fields[self.rank] = field
+        sh.barrier.wait()
+        for j in range(self.plan.world):
+            if j != self.rank and self.plan.cells[j].size:
+                field[self.plan.cells[j]] = sh.fields[j][self.plan.cells[j]]
+        sh.barrier.wait()
+
+
+def erode_shares_concurrently(TP, mesh, r_xyz, neighborDist, field, r_isOcean, shares: int, erode_args, creep_args=None, device: int = 0,
+                              planets=None):
+    """The S-rank landmass decomposition executed by S host threads of ONE process on ONE GPU (a context, stream and planet per
+    share): every share erodes `field` with the other shares' landmasses masked as ocean — erodeComposite(*erode_args), then
+    applySoilCreep(*creep_args) — with the flood exchange between the shares (ThreadFloodExchange), and the land elevations are
+    merged.  This is the partitioned code path of an S-GPU run, flood exchange included; shares of one planet cannot run one after
+    the other once a flood call needs the other shares' CURRENT heights.  Returns (merged field, per-share erode stats,
+    per-share wall seconds, plan).  planets: reuse a list of S planets of this mesh (else they are created and closed here)."""
+    import threading
+    import time
+    oc = np.ascontiguousarray(r_isOcean, np.uint8)
+    plan = plan_landmasses(mesh, oc, shares)
+    own = planets is None
+    if own:
+        planets = [TP.Planet(mesh, r_xyz, neighborDist, ctx=TP.Context(device)) for _ in range(shares)]
+    links = ThreadFloodExchange.group(plan)
+    out, stats, secs, errors = [None] * shares, [None] * shares, [0.0] * shares, []
+
+    def work(k):
+        try:
+            pl = planets[k]
+            pl.upload(field, plan.rank_mask(k, oc))
+            pl.set_flood_exchange(oc, links[k])
+            pl.sync()
+            t0 = time.perf_counter()
+            pl.erode_composite_resident(*erode_args)
+            stats[k] = pl.last_erode_stats()
+            if creep_args is not None:
+                pl.apply_soil_creep_resident(*creep_args)
+            pl.sync()
+            secs[k] = time.perf_counter() - t0
+            out[k] = pl.download()
+            pl.set_flood_exchange(None)
+        except Exception as e:              # a share that fails must not leave the others waiting at the barrier
+            errors.append((k, e))
+            links[k].abort()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(shares)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if own:
+        for pl in planets:
+            pl.close()
+    if errors:
+        raise RuntimeError(f"share {errors[0][0]} failed: {errors[0][1]!r}")
+    merged = np.array(field, np.float32, copy=True)
+    for k in range(shares):
+        if plan.cells[k].size:
+            merged[plan.cells[k]] = out[k][plan.cells[k]]
+    return merged, stats, secs, plan

@@ -167,6 +167,49 @@ class Planet:
         """One-ring halo swap with rank - 1 / rank + 1 of a band chain (set_halo lists: [to prev | to next], [from prev | from next])."""
         capi.check(capi.lib().wo_planet_exchange_neighbors(self.handle, comm.handle, int(n_to_prev), int(n_from_prev)), "wo_planet_exchange_neighbors")
 
+    def set_flood_exchange(self, true_ocean, exchange=None, comm: "Comm | None" = None, counts=None, cells_by_rank=None) -> None:
+        """The flood exchange of the landmass decomposition (include/worogen.h: wo_planet_set_flood_exchange): every flood call of
+        erodeComposite agrees with the other ranks whether any of them met an equal-key decision that matters and, if so, pools the
+        heights of all land cells so that an undecided rank can flood the whole planet like the unpartitioned run does.
+        exchange: an object with allreduce_max(flag: int) -> int and allgather(field: np.ndarray[numRegions]) -> None (in place;
+        own land cells valid on entry, every land cell on return) — decomposed.TorchFloodExchange / ThreadFloodExchange; or
+        comm + counts + cells_by_rank: the same over RCCL behind the C ABI.  true_ocean None: off."""
+        import ctypes as C
+        L = capi.lib()
+        if true_ocean is None:
+            capi.check(L.wo_planet_set_flood_exchange(self.handle, None, None, None), "wo_planet_set_flood_exchange")
+            self._flood_cb = None
+            return
+        oc = np.ascontiguousarray(true_ocean, np.uint8)
+        if oc.size != self.numRegions:
+            raise ValueError("true_ocean length must equal mesh.numRegions")
+        if comm is not None:
+            cnt = np.ascontiguousarray(counts, np.int32)
+            cells = np.ascontiguousarray(cells_by_rank, np.int32)
+            if cnt.size != comm.size or cells.size != int(cnt.sum()):
+                raise ValueError("one count per rank, and the ranks' cells concatenated in rank order")
+            capi.check(L.wo_planet_set_flood_exchange_comm(self.handle, capi.ptr(oc), comm.handle, capi.ptr(cnt), capi.ptr(cells)), "wo_planet_set_flood_exchange_comm")
+            self._flood_cb = None
+            return
+        N = self.numRegions
+        errors = []
+
+        def _cb(_user, phase, buf, n):
+            try:
+                if phase == 0:
+                    flag = C.cast(buf, C.POINTER(C.c_int32))
+                    flag[0] = int(exchange.allreduce_max(int(flag[0])))
+                else:
+                    field = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(int(n),))
+                    exchange.allgather(field)
+                return 0
+            except Exception as e:          # never let an exception cross the C boundary
+                errors.append(e)
+                return 1
+        self._flood_cb = capi.FLOOD_EXCHANGE_FN(_cb)       # keep the thunk alive as long as the planet uses it
+        self._flood_errors = errors
+        capi.check(L.wo_planet_set_flood_exchange(self.handle, capi.ptr(oc), self._flood_cb, None), "wo_planet_set_flood_exchange")
+
     # ---- band-decomposed Jacobi passes (banded.py) ----
     def set_halo(self, send_idx, recv_idx):
         s = np.ascontiguousarray(send_idx, np.int32); r = np.ascontiguousarray(recv_idx, np.int32)

@@ -49,6 +49,7 @@ def main():
         from planet_heightmap_generation_amd import terrain_post as TP
         pl = TP.Planet(M, xyz, nd)
         pl.upload(e, mask)
+        pl.set_flood_exchange(oc, decomposed.TorchFloodExchange(plan, rank, dist))      # equal flood keys that matter: the shares pool their heights
         pl.erode_composite_resident(h, 3e-4, 0.5, 1.0, t, 1.16, 0.015, g, 0.5)
         pl.apply_soil_creep_resident(3, 0.1125)
         if engine == "planet-device":

@@ -303,6 +303,64 @@ extern "C" void emu_flood_host(int32_t N, const int32_t* off, const int32_t* adj
     }
 }
 
+// The flood call of a planet split into landmass shares (decomposed.py): share k sees the other shares' landmasses as ocean and
+// floods with flood_host_passes_exchange; the shares run as threads and exchange through a barrier, as ranks would through a
+// collective.  useExchange == 0: every share floods on its own with flood_host_passes (the pre-round-4 behaviour, for contrast).
+// e: in the initial field, out the merged result.  stats: [exchange gathers, whole-planet floods, replays] summed over the shares.
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+namespace {
+struct ShareBarrier {
+    std::mutex m; std::condition_variable cv; int n, waiting = 0; long gen = 0;
+    explicit ShareBarrier(int n_) : n(n_) {}
+    void wait() { std::unique_lock<std::mutex> l(m); const long g = gen; if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); } else cv.wait(l, [&] { return gen != g; }); }
+};
+struct ShareGroup { ShareBarrier bar; std::vector<int32_t> flags; std::vector<float*> fields; const int32_t* owner; int32_t N; explicit ShareGroup(int n) : bar(n), flags(n, 0), fields(n, nullptr) {} };
+struct ShareCtx { ShareGroup* g; int rank; };
+int share_exchange(void* user, int32_t phase, void* buf, int64_t n) {
+    ShareCtx* c = (ShareCtx*)user; ShareGroup& G = *c->g;
+    if (phase == 0) {
+        G.flags[c->rank] = *(int32_t*)buf;
+        G.bar.wait();
+        int32_t m = 0; for (int32_t f : G.flags) m = std::max(m, f);
+        G.bar.wait();
+        *(int32_t*)buf = m;
+        return 0;
+    }
+    float* field = (float*)buf;
+    G.fields[c->rank] = field;
+    G.bar.wait();
+    for (int64_t r = 0; r < n; ++r) { const int32_t o = G.owner[r]; if (o >= 0 && o != c->rank) field[r] = G.fields[o][r]; }
+    G.bar.wait();
+    return 0;
+}
+}  // namespace
+extern "C" void emu_flood_shares(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, const uint8_t* trueOcean, const int32_t* owner,
+                                 int32_t nShares, double cs, int32_t useExchange, double* stats) {
+    ShareGroup G(nShares); G.owner = owner; G.N = N;
+    std::vector<std::vector<float>> field(nShares, std::vector<float>(e, e + N));
+    std::vector<FloodHostStats> hs(nShares);
+    std::vector<FloodExchange> X(nShares);
+    std::vector<ShareCtx> ctx(nShares);
+    std::vector<std::thread> th;
+    for (int k = 0; k < nShares; ++k) th.emplace_back([&, k]() {
+        std::vector<uint8_t> mask(N);
+        for (int32_t r = 0; r < N; ++r) mask[r] = (trueOcean[r] || owner[r] != k) ? 1 : 0;
+        FloodScratch S;
+        flood_build_static(N, off, adj, xyz, mask.data(), S);
+        if (!useExchange) { if (S.L > 0) flood_host_passes(field[k].data(), cs, S, &hs[k]); return; }
+        ctx[k] = ShareCtx{&G, k};
+        X[k].on = true; X[k].fn = share_exchange; X[k].user = &ctx[k]; X[k].trueOcean.assign(trueOcean, trueOcean + N);
+        flood_host_passes_exchange(N, off, adj, xyz, field[k].data(), cs, S, &hs[k], X[k]);
+    });
+    for (auto& t : th) t.join();
+    double gathers = 0, globals = 0, replays = 0;
+    for (int k = 0; k < nShares; ++k) { gathers += (double)X[k].gathers; globals += (double)X[k].globalFloods; replays += (double)hs[k].replays; }
+    for (int32_t r = 0; r < N; ++r) if (owner[r] >= 0) e[r] = field[owner[r]][r];
+    if (stats) { stats[0] = gathers; stats[1] = globals; stats[2] = replays; }
+}
+
 extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, float* e, const uint8_t* ocean, double cs) {
     FloodScratch fs;
     priority_flood_carve_host(N, off, adj, nullptr, e, ocean, cs, fs);

@@ -25,6 +25,7 @@ def emu():
     L = C.CDLL(str(EMU_DIR / "_build" / "libemu.so"))
     p = C.c_void_p
     L.emu_flood_host.argtypes = [C.c_int32, p, p, p, p, p, C.c_double, C.c_int32, C.c_int32, p]
+    L.emu_flood_shares.argtypes = [C.c_int32, p, p, p, p, p, p, C.c_int32, C.c_double, C.c_int32, p]
     return L
 
 
@@ -210,3 +211,54 @@ def test_open_parents_are_vouched_for_or_redone(emu, oracle):
         if tried >= 25:
             break
     assert accepted > 0 and redone > 0, (accepted, redone, tried)
+
+
+def flood_shares(emu, mesh, xyz, e0, oc, shares, cs, exchange=True):
+    """one flood call of a planet dealt to `shares` landmass shares (decomposed.plan_landmasses), merged"""
+    from planet_heightmap_generation_amd import decomposed as D
+    plan = D.plan_landmasses(mesh, oc, shares)
+    e = e0.copy()
+    st = np.zeros(3)
+    owner = np.ascontiguousarray(plan.owner, np.int32)
+    emu.emu_flood_shares(mesh.numRegions, P(mesh.adjOffset), P(mesh.adjList), P(xyz), P(e), P(oc), P(owner), shares, cs, 1 if exchange else 0, P(st))
+    return e, dict(gathers=st[0], whole_planet_floods=st[1], replays=st[2])
+
+
+@pytest.mark.parametrize("shares", [2, 5])
+def test_shares_pool_their_heights_when_equal_keys_matter(emu, oracle, shares):
+    """The landmass decomposition's flood (flood_host.cc: flood_host_passes_exchange).  A share's flood is the planet's as long
+    as no equal-key decision matters; when one does, the answer lies in the reference's single heap over the WHOLE planet
+    (js/terrain-post.js:131-147), other shares' landmasses included.  Constructed terrain on which thousands of decisions
+    matter: with the exchange the merged field is the oracle's bit for bit; a share that replays only its own landmasses
+    (no exchange) is NOT — the case round 3 measured at 40 M cells."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(12000, 0.75, 2)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    base = oracle.synthetic_terrain(xyz, 2)
+    noise = _cell_noise(np.arange(mesh.numRegions))
+    differs_without = 0
+    for level in (0.05, 0.3):
+        e0 = np.where(base > 0, np.float32(level) - noise.astype(np.float32), np.float32(-0.1)).astype(np.float32)
+        e0 = np.where((base > 0) & (e0 <= 0), np.float32(1e-3), e0).astype(np.float32)
+        oc = (e0 <= 0).astype(np.uint8)
+        ref = oracle.priority_flood_carve(om, e0, oc, 0.5)
+        got, st = flood_shares(emu, mesh, xyz, e0, oc, shares, 0.5)
+        assert np.array_equal(got, ref), (level, int((got != ref).sum()), st)
+        assert st["gathers"] == shares and 1 <= st["whole_planet_floods"] <= shares and st["replays"] >= 1, st
+        alone, _ = flood_shares(emu, mesh, xyz, e0, oc, shares, 0.5, exchange=False)
+        differs_without += int((alone != ref).sum())
+    assert differs_without > 0
+
+
+@pytest.mark.parametrize("shares", [3, 8])
+def test_shares_without_open_decisions_do_not_gather(emu, oracle, shares):
+    """ordinary terrain: every share vouches for its landmasses, one flag round, no heights move"""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(60000, 0.75, 4)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    e0 = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, 4), xyz, 4, 0.75)
+    oc = (e0 <= 0).astype(np.uint8)
+    ref = oracle.priority_flood_carve(om, e0, oc, 0.85)
+    got, st = flood_shares(emu, mesh, xyz, e0, oc, shares, 0.85)
+    assert np.array_equal(got, ref), (int((got != ref).sum()), st)
+    assert st["gathers"] == 0 and st["whole_planet_floods"] == 0, st

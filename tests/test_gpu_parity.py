@@ -556,6 +556,52 @@ def test_config4_size_checksum_on_one_gpu(TP):
     assert stats["solve_basin_passes_with_leftovers"] == 0
 
 
+def test_config4_decomposed_8_shares_checksum(TP):
+    """BASELINE config 4 as its 8-rank plan: the 40 M-cell planet dealt to 8 landmass shares (one host thread, context and
+    planet per share on this GPU), 20 composite iterations, the flood exchange between the shares.  Both flood calls meet
+    equal keys that matter at this size, so a share that replayed a heap of its own landmasses only would not end on the
+    oracle's field (round 3: CRC 1594252700); with the shares pooling their heights the merged field's CRC == the oracle's."""
+    import json
+    import zlib
+    from conftest import GOLDEN
+    from planet_heightmap_generation_amd import decomposed as D
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    gold = json.loads((GOLDEN / "crc_config3.json").read_text())["40000000"]
+    cells, seed, iters, g = 40_000_000, 1, 20, 1
+    assert (gold["cells"], gold["seed"], gold["iterations"], gold["gIters"]) == (cells, seed, iters, g)
+    mesh, xyz, nd = S.build_sphere(cells, 0.75, seed)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(seed)
+    pl.warp_terrain_resident(seed, 0.75)
+    pl.ocean_from_elevation()
+    warped, oc = pl.download(), pl.download_ocean()
+    pl.close()
+    merged, stats, secs, plan = D.erode_shares_concurrently(TP, mesh, xyz, nd, warped, oc, 8, (iters, 3e-4, 0.5, 1.0, iters, 1.16, 0.015, g, 0.5), (3, 0.1125))
+    print("share seconds", [round(v, 2) for v in secs], "whole-planet floods per share", [st["flood_exchange_whole_planet_floods"] for st in stats],
+          "gathers", stats[0]["flood_exchange_gathers"])
+    assert sum(st["flood_exchange_whole_planet_floods"] for st in stats) >= 1            # the exchange was needed (else the test has no power)
+    assert all(st["flood_host_serial_pass1"] == 0 for st in stats)
+    assert int(zlib.crc32(merged.tobytes())) == gold["crc32"], "merged field differs from the oracle's"
+
+
+def test_decomposed_shares_with_flood_exchange_small(TP, oracle):
+    """The same machinery where the oracle can check every cell: 300 k cells quantised so that equal keys matter, 5 shares as
+    threads with the flood exchange, glacial + both floods: merged == oracle bit for bit (and the exchange did run)."""
+    from planet_heightmap_generation_amd import decomposed as D
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(300000, 0.75, 6)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    e0 = oracle.synthetic_terrain(xyz, 6)
+    e0 = (np.round(e0 * 4096) / 4096).astype(np.float32)
+    oc = (e0 <= 0).astype(np.uint8)
+    args = (8, 3e-4, 0.5, 1.0, 8, 1.16, 0.015, 2, 0.5)
+    ref = oracle.soil_creep(om, oracle.erode_composite(om, e0, xyz, oc, *args, nd), oc, 3, 0.1125)
+    merged, stats, secs, plan = D.erode_shares_concurrently(TP, mesh, xyz, nd, e0, oc, 5, args, (3, 0.1125))
+    print("gathers", stats[0]["flood_exchange_gathers"], "whole-planet floods", [st["flood_exchange_whole_planet_floods"] for st in stats])
+    assert np.array_equal(merged, ref), int((merged != ref).sum())
+    assert stats[0]["flood_exchange_calls"] == 2
+
+
 @pytest.mark.parametrize("seed", [2, 3])
 def test_config5_seeds_checksum(TP, seed):
     """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 and 3, 20 composite iterations (1 glacial),
