@@ -424,17 +424,106 @@ def host_thread_usage():
                      "reference's heap (erode_stats.flood_host_replays: 0 at 10 M cells; flood_host_serial_pass1, round 2's serial walk, stays 0)")
 
 
-def parity_crc(pl, cells: int, iters: int):
-    """CRC32 of the field the timed steps produced against the oracle's for the same workload (tests/golden/crc_config3.json)."""
+def parity_crc(pl, cells: int, iters: int, seed: int = 1):
+    """CRC32 of the field the timed steps produced against the oracle's for the same workload (tests/golden/crc_config3.json:
+    any entry with the same cells / seed / iterations)."""
     import zlib
     f = REPO / "tests" / "golden" / "crc_config3.json"
-    out = dict(crc32=int(zlib.crc32(pl.download().tobytes())), parity_crc_ok=None)
+    field = pl if isinstance(pl, np.ndarray) else pl.download()
+    out = dict(crc32=int(zlib.crc32(np.ascontiguousarray(field, np.float32).tobytes())), parity_crc_ok=None)
     if f.exists():
-        gold = json.loads(f.read_text()).get(str(cells))
-        if gold and gold["iterations"] == iters and gold["seed"] == 1:
-            out["parity_crc_ok"] = out["crc32"] == gold["crc32"]
-            out["oracle_crc32"] = gold["crc32"]
+        for gold in json.loads(f.read_text()).values():
+            if gold["cells"] == cells and gold["iterations"] == iters and gold["seed"] == seed:
+                out["parity_crc_ok"] = out["crc32"] == gold["crc32"]
+                out["oracle_crc32"] = gold["crc32"]
+                break
     return out
+
+
+def with_transfers_ms(pl, seed, params):
+    """the same step through the JS call surface's entry points, which take and return HOST arrays (every call
+    copies r_elevation in and out and r_isOcean in: 2 x 4 B + 1 B per cell per call over PCIe).  One step, wall time in ms."""
+    pl.restore_state()
+    e = pl.download()
+    pl.sync()
+    t0 = time.perf_counter()
+    pl.warp_terrain(e, seed, WARP)
+    oc = (e <= 0).astype(np.uint8)
+    pl.erode_composite(e, oc, params["hIters"], params["K"], params["m"], params["dt"], params["tIters"], params["talusSlope"], params["kThermal"],
+                       params["gIters"], params["glacialStrength"])
+    pl.apply_soil_creep(e, oc, *CREEP)
+    return (time.perf_counter() - t0) * 1e3, e
+
+
+def one_planet_leg(TP, args, rank, world, dist, local_rank):
+    """North_star's multi-GPU workload (BASELINE config 4): ONE planet of --one-planet-cells cells (seed 1) eroded by all ranks —
+    landmass decomposition with the flood exchange (decomposed.py), merged over RCCL — timed like the main region (barrier,
+    max over ranks).  Returns the nested object of the bench line (rank 0) or None."""
+    import torch
+    cells, iters = args.one_planet_cells, args.one_planet_iters
+    params = dict(PARAMS)
+    if iters != 200:
+        params.update(hIters=iters, tIters=iters, gIters=min(10, max(1, iters // 20)))
+    mesh, xyz, nd, t_mesh = build_inputs(cells, 1)
+    pl = TP.Planet(mesh, xyz, nd, device=local_rank)
+    pl.synthetic_terrain(1)
+    pl.save_state()
+    pl.sync()
+    comm = make_comm(TP, pl, args, rank, world, dist)
+    dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}" if args.backend == "nccl" else None, comm)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+        pl.sync()
+    for _ in range(max(1, args.one_planet_warmup)):
+        one_step_decomposed(pl, 1, params, dec)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.one_planet_steps):
+        one_step_decomposed(pl, 1, params, dec)
+    barrier()
+    wall = dist_max(dist, time.perf_counter() - t0, "cuda" if args.backend == "nccl" else "cpu")
+    stats, stages = pl.last_erode_stats(), pl.last_stage_timing()
+    busy = [None] * world
+    dist.all_gather_object(busy, dict(rank=rank, land_cells=int(stats.get("land_cells", 0)), flood_stage_ms=round(stats.get("flood_stage_ms", 0.0), 1),
+                                      whole_planet_floods=int(stats.get("flood_exchange_whole_planet_floods", 0)), exchange_gathers=int(stats.get("flood_exchange_gathers", 0)),
+                                      erode_ms=round(sum(stages.values()), 1)))
+    out = None
+    if rank == 0:
+        N = mesh.numRegions
+        out = dict(metric="Mcells·iter/s, terrain-post erosion stack, ONE planet over all GPUs", value=whole_job_value(N, iters, args.one_planet_steps, 1, wall), unit="Mcells·iter/s",
+                   n_gpus=world, steps=args.one_planet_steps, ms_per_step=wall * 1e3 / args.one_planet_steps, scaling="strong",
+                   config=dict(workload=f"BASELINE config 4: {N} cells (Fibonacci sphere {cells}+pole, jitter 0.75, seed 1), warp 0.75 + erodeComposite(h={params['hIters']},"
+                                        f"t={params['tIters']},g={params['gIters']}) + creep x3, ONE planet over {world} GPUs", cells=N, iterations=iters,
+                               parallelism=f"landmass decomposition x{world} with the flood exchange (flag all-reduce per flood call; heights pooled and the whole planet flooded "
+                                           f"on the undecided rank when equal keys matter), one all-gather of the land elevations per step"),
+                   parity=parity_crc(pl, cells, iters), decomposition=dec.summary(), per_rank=busy, mesh_build_s=round(t_mesh, 1),
+                   note="strong scaling of one planet in exact mode is bounded by the largest landmass and by the flood (DESIGN.md section 7); the ensemble line above is how the path's units of work shard")
+    if comm is not None:
+        comm.close()
+    pl.close()
+    return out
+
+
+def make_comm(TP, pl, args, rank, world, dist):
+    """the exchange behind the C ABI: rank 0's RCCL id goes round through torch.distributed, every rank joins with it (None: torch.distributed carries the exchange)"""
+    if args.backend != "nccl" or os.environ.get("WO_BENCH_TORCH_EXCHANGE") == "1":
+        return None
+    try:
+        box = [TP.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = TP.Comm(pl.ctx, box[0], world, rank)
+    except Exception as ex:          # never lose the run over the communicator: torch.distributed carries the exchange then
+        print(f"[bench] rank {rank}: wo_comm unavailable ({ex}); exchanging through torch.distributed", file=sys.stderr)
+        comm = None
+    gathered = [None] * world
+    dist.all_gather_object(gathered, comm is not None)
+    if not all(gathered):
+        if comm is not None:
+            comm.close()
+        comm = None
+    return comm
 
 
 def main():
@@ -454,6 +543,11 @@ def main():
                     help="N > 1: 'ensemble' = one planet per GPU (weak scaling, BASELINE config 5, default), 'decomposed' = one planet over all GPUs by landmass (strong); "
                          "N = 1 with 'decomposed': the partitioned code path, --shares landmass shares one after the other")
     ap.add_argument("--shares", type=int, default=8, help="N = 1, --mode decomposed: number of landmass shares")
+    ap.add_argument("--one-planet-cells", type=int, default=40_000_000, help="N > 1, default mode: after the ensemble region, ONE planet of this many cells over all GPUs "
+                                                                              "(BASELINE config 4; nested object `one_planet` of the line); 0 = skip")
+    ap.add_argument("--one-planet-iters", type=int, default=200)
+    ap.add_argument("--one-planet-steps", type=int, default=1)
+    ap.add_argument("--one-planet-warmup", type=int, default=1)
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
@@ -496,21 +590,7 @@ def main():
         torch.cuda.synchronize()
         pl.sync()
 
-    comm = None
-    if decomposed_mode and args.backend == "nccl" and os.environ.get("WO_BENCH_TORCH_EXCHANGE") != "1":
-        # the exchange behind the C ABI: rank 0's RCCL id goes round through torch.distributed, every rank joins with it
-        try:
-            box = [TP.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            comm = TP.Comm(pl.ctx, box[0], world, rank)
-        except Exception as ex:          # never lose the run over the communicator: torch.distributed carries the exchange then
-            print(f"[bench] rank {rank}: wo_comm unavailable ({ex}); exchanging through torch.distributed", file=sys.stderr)
-            comm = None
-        flags = [comm is not None]
-        gathered = [None] * world
-        dist.all_gather_object(gathered, flags[0])
-        if not all(gathered):
-            comm = None
+    comm = make_comm(TP, pl, args, rank, world, dist) if decomposed_mode else None
     dec = Decomposition(mesh, pl, rank, world, dist, f"cuda:{local_rank}" if args.backend == "nccl" else None, comm) if decomposed_mode else None
     step = (lambda: one_step_decomposed(pl, seed, params, dec)) if decomposed_mode else (lambda: one_step(pl, seed, params))
     virt = VirtualShares(mesh, pl, max(1, args.shares)) if (world == 1 and args.mode == "decomposed") else None
@@ -610,6 +690,19 @@ def main():
         elif PMC_FILE.exists() and args.cells == 10_000_000 and iters == 200:
             pmc_all = json.loads(PMC_FILE.read_text())
             src = "committed file profiles/" + PMC_FILE.name + " (rocprofv3 --pmc, separate passes per counter, this workload at the full 200 iterations, one planet), not measured in this run"
+        if pmc_all:
+            # the counter file must describe THIS build's launches: every kernel family the profiled step ran (and that the table
+            # below can name) has to be in it, else the file is stale — fail instead of quoting another build's traffic
+            have = [k.replace("(anonymous namespace)::", "") for k, v in pmc_all.items() if isinstance(v, dict)]
+            missing = []
+            for f_, (ms_, _n) in rep.items():
+                if ms_ > 0 and f_ in FAMILY_KERNEL and f_ in kernel_pass:
+                    names_ = FAMILY_KERNEL[f_] if isinstance(FAMILY_KERNEL[f_], tuple) else (FAMILY_KERNEL[f_],)
+                    if not any(h.startswith(names_) for h in have):
+                        missing.append(f"{f_} ({' / '.join(names_)})")
+            if missing and os.environ.get("WO_BENCH_ALLOW_STALE_PMC") != "1":
+                raise SystemExit(f"bench.py: {PMC_FILE.name if os.environ.get('WO_BENCH_PMC') != '1' else 'the live PMC collection'} has no counters for kernels this run launched: "
+                                 + ", ".join(missing) + " — re-collect with profiles/collect_pmc.sh (or WO_BENCH_PMC=1 / WO_BENCH_ALLOW_STALE_PMC=1)")
         if pmc_all and fam in FAMILY_KERNEL:
             names = FAMILY_KERNEL[fam] if isinstance(FAMILY_KERNEL[fam], tuple) else (FAMILY_KERNEL[fam],)
             pmc = next((v for k, v in pmc_all.items() if isinstance(v, dict) and k.replace("(anonymous namespace)::", "").startswith(names)), None)
@@ -634,6 +727,15 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu and not virt:
         cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters, iters, pl)
 
+    transfers = None
+    if rank == 0 and world == 1 and not virt:
+        ms_t, field_t = with_transfers_ms(pl, seed, params)
+        transfers = dict(value_with_transfers=N * iters / (ms_t / 1e3) / 1e6, ms_per_step=ms_t, crc32_equals_resident_run=(parity_crc(field_t, args.cells, iters, seed)["crc32"] == crc["crc32"]) if crc else None,
+                         note="one step through the host-array entry points of the JS call surface (wo_warp_terrain, wo_erode_composite, wo_soil_creep: r_elevation H2D + D2H and r_isOcean H2D per call); `value` is the resident rate")
+    one_planet = None
+    if world > 1 and not decomposed_mode and args.mode == "auto" and args.one_planet_cells > 0:
+        pl.close()
+        one_planet = one_planet_leg(TP, args, rank, world, dist, local_rank)
     if rank == 0:
         value = whole_job_value(N, iters, args.steps, 1 if decomposed_mode else world, wall)
         out = {
@@ -648,6 +750,7 @@ def main():
                                       else (f"landmass decomposition, {virt.S} shares executed sequentially on one GPU (partitioned code path)" if virt
                                             else f"ensemble x{world} (no collective on the data path)")},
             "decomposition": dec.summary() if dec else (virt.summary(unpart_ms) if virt else None),
+            "value_with_transfers": transfers["value_with_transfers"] if transfers else None, "with_transfers": transfers, "one_planet": one_planet,
             "roofline": roofline, "cpu_baseline": cpu, "ensemble_in_flight": ensemble,
             "parity": crc, "cold_first_step_ms": cold_ms, "host_threads": host_thread_usage(),
             "hbm_d2d_copy_GBs_measured": round(d2d_bandwidth_GBs(local_rank), 1),

@@ -6,6 +6,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 from conftest import REPO
 
 
@@ -38,3 +40,24 @@ def test_bench_line_schema_helpers():
     alt = {"solve_patch", "solve_round"}                      # alternatives of solve_basin: only one of the three runs in a pass
     for name, p in bench.PASSES.items():
         assert sum(v[0] for k, v in p["kernels"].items() if k not in alt) == p["budget"][0], name
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_emit_the_ensemble_line_and_the_one_planet_leg(tmp_path):
+    """bench.py --gpus 2 as the driver launches it, rehearsed on a one-GPU box (gloo, both ranks on device 0, small planets): the
+    line's `value` is the ensemble (weak scaling, one planet per rank, no collective) and `one_planet` holds north_star's workload
+    — ONE planet over all ranks by landmass with the flood exchange (strong) — each with its own workload, scaling and parity."""
+    import os
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           str(REPO / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--cells", "200000", "--iters", "8", "--steps", "1", "--warmup", "1",
+           "--no-cpu", "--no-profile", "--in-flight", "0", "--one-planet-cells", "300000", "--one-planet-iters", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "one planet per GPU" in out["config"]["workload"]
+    leg = out["one_planet"]
+    assert leg and leg["scaling"] == "strong" and leg["n_gpus"] == 2 and "ONE planet over 2 GPUs" in leg["config"]["workload"]
+    assert leg["config"]["cells"] == 300001 and leg["value"] > 0 and "crc32" in leg["parity"]
+    assert len(leg["per_rank"]) == 2 and sum(x["land_cells"] for x in leg["per_rank"]) > 0
+    assert abs(out["value"] - 200001 * 8 * 1 * 2 / (out["ms_per_step"] / 1e3) / 1e6) < 1e-6 * out["value"]
