@@ -18,7 +18,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "libworogen.so"
+LIB_PATH = Path(os.environ["WO_LIBWOROGEN"]) if os.environ.get("WO_LIBWOROGEN") else _PKG_DIR / "libworogen.so"      # (override: A/B builds of the library in experiments)
 
 
 class WorogenError(RuntimeError):

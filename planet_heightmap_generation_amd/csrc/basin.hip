@@ -101,6 +101,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_jump(const int32_t* __restri
 __global__ __launch_bounds__(WO_BLOCK) void k_basin_keys(const int32_t* __restrict__ land, const uint32_t* __restrict__ keyOfCell, int32_t L,
                                                           uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t scramble, int32_t* rangeStart, int32_t nRangeWords) {
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nRangeWords; i += gridDim.x * blockDim.x) rangeStart[i] = WO_RANGE_NONE;     // k_basin_slots takes minima into it (was a memset launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) rangeStart[nRangeWords] = 0;                                                                     // number of long ranges (k_basin_long)
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
         const int32_t c = land[L - 1 - i];
         keys[i] = (scramble && c % 3 == 0) ? (keyOfCell[c] ^ 1u) : keyOfCell[c];
@@ -115,6 +116,41 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_slots(const int32_t* __restr
         if (slotOf) slotOf[order[q]] = q;           // (the in-tree sort's last pass has written it)
         if (q == 0 || keys[q] != keys[q - 1]) atomicMin(&rangeStart[q / rangeT], q);
     }
+}
+
+// Long ranges first.  A launch of the solve lasts as long as its longest range (one workgroup walking the biggest drainage
+// component), and workgroups are handed out in block order: a long range whose block comes late starts late, with the chip
+// already emptying.  The ranges of at least WO_LONG_RANGE slots are listed here (after all range starts are known), the first
+// WO_LONG_MAX blocks of the solve launch take them, and the block that would have met such a range in its turn skips it.
+// big[0] = count, big[1 + i] = range index; flag[k] = 1: range k is on the list.
+constexpr int32_t WO_LONG_RANGE = 1536, WO_LONG_MAX = 256;
+__device__ inline int32_t range_end(const int32_t* __restrict__ rangeStart, int32_t k, int32_t nRanges, int32_t L) {
+    for (int32_t j = k + 1; j < nRanges; ++j) { const int32_t v = rangeStart[j]; if (v != WO_RANGE_NONE) return v; }
+    return L;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_basin_long(const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t L, int32_t* big, uint8_t* __restrict__ flag) {
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nRanges; k += gridDim.x * blockDim.x) {
+        const int32_t S = rangeStart[k];
+        uint8_t f = 0;
+        if (S != WO_RANGE_NONE && range_end(rangeStart, k, nRanges, L) - S >= WO_LONG_RANGE) {
+            const int32_t at = atomicAdd(&big[0], 1);
+            if (at < WO_LONG_MAX) { big[1 + at] = k; f = 1; }
+        }
+        flag[k] = f;
+    }
+}
+// the range a block of the solve launch walks: blocks 0 .. WO_LONG_MAX-1 take the listed long ranges, block WO_LONG_MAX + k the
+// range k unless it is listed.  false: nothing to do.
+__device__ inline bool block_range(const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t L, const int32_t* __restrict__ big, const uint8_t* __restrict__ flag, int32_t& S, int32_t& E) {
+    int32_t k;
+    if (big) {
+        if ((int32_t)blockIdx.x < WO_LONG_MAX) { const int32_t n = big[0] < WO_LONG_MAX ? big[0] : WO_LONG_MAX; if ((int32_t)blockIdx.x >= n) return false; k = big[1 + blockIdx.x]; }
+        else { k = (int32_t)blockIdx.x - WO_LONG_MAX; if (flag[k]) return false; }
+    } else k = (int32_t)blockIdx.x;
+    S = rangeStart[k];
+    if (S == WO_RANGE_NONE) return false;
+    E = range_end(rangeStart, k, nRanges, L);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -231,15 +267,13 @@ __global__ __launch_bounds__(64, 4) void k_solve_stream(Fields F, int32_t L, con
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
-                                                            int32_t* patchPending, int32_t* totalPending) {
+                                                            int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag, long long* stats) {
     constexpr int SC = 64 * NW;                        // tasks per super-chunk
     constexpr int RING = (2 * SC > 1024) ? 2 * SC : 1024;    // tasks whose granules the workgroup keeps in LDS (power of two, >= 2 super-chunks)
     __shared__ unsigned long long s_ring[2 * RING];
     const int tid = threadIdx.x;
-    const int32_t S = rangeStart[blockIdx.x];
-    if (S == WO_RANGE_NONE) return;
-    int32_t E = L;
-    for (int32_t j = blockIdx.x + 1; j < nRanges; ++j) { const int32_t v = rangeStart[j]; if (v != WO_RANGE_NONE) { E = v; break; } }
+    int32_t S, E;
+    if (!block_range(rangeStart, nRanges, L, big, longFlag, S, E)) return;
     const unsigned long long* G = reinterpret_cast<const unsigned long long*>(F.out);
     // LDS keeps what the last workgroup left: last pass's launch wrote the very tags this one waits for.  Clear the ring first.
     for (int i = tid; i < 2 * RING; i += SC) s_ring[i] = 0;
@@ -264,6 +298,10 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
             if (fPrev & 32u) { F.e2[tPrev] = oPrev.dep.v; F.me[tPrev] = oPrev.dep.v; }
         }
     };
+    // WO_BASIN_STATS (diagnostic): block 0's first lane clocks the three phases of a super-chunk
+    const bool clocked = stats && blockIdx.x == 0 && tid == 0;
+    long long cLoad = 0, cPoll = 0, cBar = 0, nPolls = 0, c0 = clocked ? clock64() : 0;
+    const long long cStart = c0;
     for (int32_t base = S; base < E; base += SC) {
         const int32_t q = base + tid;
         const bool mine = q < E;
@@ -293,7 +331,9 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
         bool open = mine;
         SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
         if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
+        if (clocked) { const long long c = clock64(); cLoad += c - c0; c0 = c; }
         while (__any(open)) {
+            if (clocked) ++nPolls;
             if (open) {
                 auto poll = [&](int32_t& rw, int32_t expect, double& v) {
                     if (rw < 0) return;
@@ -314,9 +354,152 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
         oPrev = o; storePrev = mine && !blocked; fPrev = T.flags; rPrev = T.pad_[0]; tPrev = T.pad_[1];
         if (mine && blocked) { atomicAdd(&patchPending[q / WO_PATCH], 1); atomicAdd(totalPending, 1); }
         a0 = n0; a1 = n1; a2 = n2;
+        if (clocked) { const long long c = clock64(); cPoll += c - c0; c0 = c; }
         __syncthreads();
+        if (clocked) { const long long c = clock64(); cBar += c - c0; c0 = c; }
     }
     if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
+    if (clocked) { stats[0] = E - S; stats[1] = cLoad; stats[2] = cPoll; stats[3] = cBar; stats[4] = nPolls; stats[5] = clock64() - cStart; stats[6] = wall_clock64(); }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same walk WITHOUT the barrier.  Phase clocks of k_solve_coop on a 1 600-slot range (WO_BASIN_STATS, profiles/r04c_*): 48 % of
+// a wave's time is the wait at the super-chunk barrier (the waves' in-chunk chains differ in length and the launch pays the
+// SUM over the super-chunks of the longest chain in each), 35 % the polling loop at ~1 500 clocks per pass (three LDS reads,
+// each waited for on its own, then the turn's three divisions).  Here
+//   * a wave moves on to its 64 tasks of the next super-chunk as soon as its own are done: it may run LAG super-chunks ahead
+//     of the slowest wave of the workgroup (progress counters in LDS instead of the barrier).  The ring keeps 8 super-chunks:
+//     a slot of super-chunk k is overwritten by k + 8, whose wave starts only when every wave has finished k + 8 - 1 - LAG
+//     >= k + LOOKBACK, i.e. after the last task that reads super-chunk k through the ring; predecessors further back than
+//     LOOKBACK = LAG + 2 super-chunks come from global memory, where their owner stored them on starting its next
+//     super-chunk — at the latest before the reader issued the load (it starts super-chunk c - 1, where the loads for c go
+//     out, only when everybody has finished c - 2 - LAG);
+//   * a polling pass issues its three LDS reads together (clamped word: the task's own) and waits once.
+// Same tasks, same inputs: bit-identical results (single-assignment dataflow).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW, bool STATS>
+__global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
+                                                               int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag,
+                                                               unsigned long long* stats) {
+    constexpr int SC = 64 * NW;                        // tasks per super-chunk
+    constexpr int LAG = 2, LOOKBACK = LAG + 2;
+    constexpr int RING = 8 * SC;                       // >= (LOOKBACK + LAG + 1) super-chunks, power of two
+    static_assert(LOOKBACK + LAG + 1 <= 8, "ring too small for the lag");
+    __shared__ unsigned long long s_ring[2 * RING];
+    __shared__ int32_t s_prog[NW];                     // super-chunks each wave has finished
+    __shared__ int32_t s_level[STATS ? RING : 1];      // WO_BASIN_STATS (diagnostic): depth of every task in the dependency DAG
+    __shared__ int32_t s_maxLevel;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long cStart = STATS ? clock64() : 0;
+    if (STATS && tid == 0) s_maxLevel = 0;
+    int32_t S, E;
+    if (!block_range(rangeStart, nRanges, L, big, longFlag, S, E)) return;
+    const unsigned long long* G = reinterpret_cast<const unsigned long long*>(F.out);
+    for (int i = tid; i < 2 * RING; i += SC) s_ring[i] = 0;        // last pass's launch left the very tags this one waits for
+    if (tid < NW) s_prog[tid] = 0;
+    __syncthreads();
+    auto ring_put = [&](int32_t word, float v, int32_t tag) {
+        __hip_atomic_store(&s_ring[word], (unsigned long long)__float_as_uint(v) | ((unsigned long long)(uint32_t)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto ring_get = [&](int32_t word) { return __hip_atomic_load(&s_ring[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto record = [&](int32_t q) { return F.task[q < L ? q : L - 1]; };
+    auto far_index = [&](int32_t g, int32_t cbase) { const int32_t sq = g >> 1; return (g >= 0 && (sq < S || sq < cbase - LOOKBACK * SC)) ? g : 0; };
+    SolveTask T1 = record(S + tid), T2 = record(S + SC + tid);
+    unsigned long long a0 = G[far_index(T1.predSelf, S)], a1 = G[far_index(T1.predT, S)], a2 = G[far_index(T1.predT2, S)];
+    SolveOut oPrev; oPrev.self.v = 0; oPrev.self.tag = 0; oPrev.dep.v = 0; oPrev.dep.tag = 0;
+    bool storePrev = false;
+    uint32_t fPrev = 0; int32_t rPrev = 0, tPrev = 0;
+    auto store_prev = [&](int32_t slot) {
+        F.out[slot] = oPrev;
+        if (F.solveFinals) {
+            if (fPrev & 16u) { F.e2[rPrev] = oPrev.self.v; F.me[rPrev] = oPrev.self.v; }
+            if (fPrev & 32u) { F.e2[tPrev] = oPrev.dep.v; F.me[tPrev] = oPrev.dep.v; }
+        }
+    };
+    int32_t ci = 0;                                    // index of the super-chunk
+    for (int32_t base = S; base < E; base += SC, ++ci) {
+        const int32_t q = base + tid;
+        const bool mine = q < E;
+        // not more than LAG super-chunks ahead of the slowest wave (see above)
+        if (ci > LAG) {
+            for (;;) {
+                int32_t mn = 0x7fffffff;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { const int32_t v = __hip_atomic_load(&s_prog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); mn = v < mn ? v : mn; }
+                if (mn >= ci - LAG) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (storePrev) store_prev(q - SC);                             // a super-chunk late (see k_solve_stream)
+        const SolveTask T = T1;
+        T1 = T2;
+        T2 = record(base + 2 * SC + tid);
+        const unsigned long long n0 = G[far_index(T1.predSelf, base + SC)], n1 = G[far_index(T1.predT, base + SC)], n2 = G[far_index(T1.predT2, base + SC)];
+        double er = T.e0r, et = T.e0t, et2 = T.e0t2;
+        bool blocked = false;
+        const int32_t myWord = (2 * q) & (2 * RING - 1);
+        int32_t r0 = -1, r1 = -1, r2 = -1, x0 = 0, x1 = 0, x2 = 0;     // ring word and expected tag of the predecessors that come through the ring
+        if (mine) {
+            auto classify = [&](int32_t g, unsigned long long far, double& v, int32_t& rw, int32_t& expect) {
+                if (g < 0) return;
+                const int32_t sq = g >> 1;
+                if (sq >= q) { blocked = true; return; }                                         // not in processing order: the layout is off
+                if (sq >= S && sq >= base - LOOKBACK * SC) { rw = g & (2 * RING - 1); expect = sq + 1; return; }
+                const int32_t tag = (int32_t)(far >> 32);
+                const bool own = sq >= S;                                                        // written by this workgroup, long ago
+                if (tag <= 0 || (!own && tag >= launchTag)) { blocked = true; return; }
+                v = __uint_as_float((uint32_t)far);
+            };
+            classify(T.predSelf, a0, er, r0, x0); classify(T.predT, a1, et, r1, x1); classify(T.predT2, a2, et2, r2, x2);
+        }
+        const int32_t l0 = r0, l1 = r1, l2 = r2;       // (STATS) the ring words of the predecessors, before the polling clears them
+        const SolvePrepared pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
+        bool open = mine;
+        SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
+        if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
+        while (__any(open)) {
+            // the three reads go out together; a predecessor that is already in hand reads the task's own word (ignored)
+            const unsigned long long w0 = ring_get(r0 >= 0 ? r0 : myWord), w1 = ring_get(r1 >= 0 ? r1 : myWord), w2 = ring_get(r2 >= 0 ? r2 : myWord);
+            if (open) {
+                auto take = [&](int32_t& rw, int32_t expect, unsigned long long w, double& v) {
+                    if (rw < 0) return;
+                    const int32_t tag = (int32_t)(w >> 32);
+                    if (tag == expect) { v = __uint_as_float((uint32_t)w); rw = -1; }
+                    else if (tag == -expect) { blocked = true; }
+                };
+                take(r0, x0, w0, er); take(r1, x1, w1, et); take(r2, x2, w2, et2);
+                if (blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
+                else if (r0 < 0 && r1 < 0 && r2 < 0) {
+                    o = solve_apply(T, pre, er, et, et2, launchTag);
+                    if (STATS) {        // predecessors beyond the ring window count as depth 0 (they finished long ago)
+                        int32_t lv = 0;
+                        if (l0 >= 0) lv = max(lv, s_level[l0 >> 1]);
+                        if (l1 >= 0) lv = max(lv, s_level[l1 >> 1]);
+                        if (l2 >= 0) lv = max(lv, s_level[l2 >> 1]);
+                        s_level[myWord >> 1] = lv + 1;
+                        atomicMax(&s_maxLevel, lv + 1);
+                    }
+                    ring_put(myWord, o.self.v, q + 1); ring_put(myWord + 1, o.dep.v, q + 1);
+                    open = false;
+                }
+            }
+        }
+        oPrev = o; storePrev = mine && !blocked; fPrev = T.flags; rPrev = T.pad_[0]; tPrev = T.pad_[1];
+        if (mine && blocked) { atomicAdd(&patchPending[q / WO_PATCH], 1); atomicAdd(totalPending, 1); }
+        a0 = n0; a1 = n1; a2 = n2;
+        if (lane == 0) __hip_atomic_store(&s_prog[wave], ci + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // after this wave's ring words (a wave's LDS operations execute in order)
+    }
+    if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
+    if (STATS) {        // the range that took longest: {clocks, slots, DAG depth seen through the ring}
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long c = (unsigned long long)(clock64() - cStart);
+            const unsigned long long packed = (c << 24) | (unsigned long long)(s_maxLevel & 0xffffff);
+            const unsigned long long old = atomicMax(&stats[0], packed);
+            if (packed > old) stats[1] = (unsigned long long)(E - S);       // (racy by design: diagnostic)
+        }
+    }
 }
 
 }  // namespace
@@ -337,7 +520,8 @@ void basin_alloc(wo_planet* p) {
         WO_HIP(hipMalloc((void**)&p->d_basinSlot, (size_t)N * 4));
         WO_HIP(hipMalloc((void**)&p->d_basinKey, (size_t)N * 4));
         WO_HIP(hipMalloc((void**)&p->d_basinVals[0], (size_t)N * 4)); WO_HIP(hipMalloc((void**)&p->d_basinVals[1], (size_t)N * 4));   // own buffers: the layout runs beside the flow accumulation, whose rounds use the planet's lists
-        WO_HIP(hipMalloc((void**)&p->d_basinRange, ((size_t)N / 64 + 4) * 4));
+        WO_HIP(hipMalloc((void**)&p->d_basinRange, ((size_t)N / 64 + 8 + WO_LONG_MAX) * 4));        // range starts, then {count, long ranges}
+        WO_HIP(hipMalloc((void**)&p->d_basinLong, (size_t)N / 64 + 8));
         WO_HIP(hipMemsetAsync(p->d_basinSlot, 0xff, (size_t)N * 4, s));
     }
 }
@@ -377,6 +561,7 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
         if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_BASIN_SORT, a, b}); }
     }
     launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[sorted], (const uint32_t*)p->d_keys[sorted], library ? p->d_basinSlot : (int32_t*)nullptr, L, p->d_basinRange, (int32_t)rangeT);
+    launch(p, FAM_BASIN, k_basin_long, blocks_for(nRanges), WO_BLOCK, (const int32_t*)p->d_basinRange, (int32_t)nRanges, L, p->d_basinRange + nRanges + 1, p->d_basinLong);
 }
 
 // the one launch of the pass; F.slotOf must be d_basinSlot, patchPending zeroed
@@ -386,10 +571,28 @@ void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_
     // WO_BASIN_WAVES: waves per range — 4 (default) / 2: k_solve_coop; 1: k_solve_stream
     static const int coopWaves = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
     ++p->basinLaunches;
-    if (coopWaves >= 16) launch(p, FAM_SOLVE_BASIN, k_solve_coop<16>, nRanges, 1024, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
-    else if (coopWaves >= 8) launch(p, FAM_SOLVE_BASIN, k_solve_coop<8>, nRanges, 512, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
-    else if (coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
-    else if (coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    static const bool longFirst = !(getenv("WO_BASIN_LONG_FIRST") && atoi(getenv("WO_BASIN_LONG_FIRST")) == 0);
+    const int32_t* big = longFirst ? (const int32_t*)(p->d_basinRange + nRanges + 1) : (const int32_t*)nullptr;
+    const uint8_t* flag = longFirst ? (const uint8_t*)p->d_basinLong : (const uint8_t*)nullptr;
+    static const bool flowing = !(getenv("WO_BASIN_KERNEL") && std::string(getenv("WO_BASIN_KERNEL")) == "barrier");      // barrier: k_solve_coop (one barrier per super-chunk)
+    static const bool statsOn = getenv("WO_BASIN_STATS") && atoi(getenv("WO_BASIN_STATS")) != 0;
+    static long long* dstatsBuf = nullptr;
+    if (statsOn && !dstatsBuf) { WO_HIP(hipMalloc((void**)&dstatsBuf, 8 * sizeof(long long))); WO_HIP(hipMemset(dstatsBuf, 0, 8 * sizeof(long long))); }
+    long long* dstats = statsOn ? dstatsBuf : nullptr;
+    struct StatsPrint { wo_planet* p; long long* d; bool flowingKernel; ~StatsPrint() {
+        if (!d) return;
+        long long h[8]; (void)hipStreamSynchronize(cur_stream(p)); (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        if (flowingKernel) fprintf(stderr, "[basin stats] slowest range: %lld slots, %lld clocks, DAG depth (ring window) %lld -> %.0f clocks per level\n", h[1], (long long)((unsigned long long)h[0] >> 24), h[0] & 0xffffff, (double)((unsigned long long)h[0] >> 24) / (double)std::max<long long>(1, h[0] & 0xffffff));
+        else fprintf(stderr, "[basin stats] block 0: range %lld slots, clocks: loads %lld, polling %lld (%lld loop passes), barrier %lld, total %lld\n", h[0], h[1], h[2], h[4], h[3], h[5]);
+    } } statsPrint{p, dstats, flowing && coopWaves >= 4 && coopWaves < 8};
+    if (coopWaves >= 16) launch(p, FAM_SOLVE_BASIN, k_solve_coop<16>, nRanges + (longFirst ? WO_LONG_MAX : 0), 1024, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    else if (coopWaves >= 8) launch(p, FAM_SOLVE_BASIN, k_solve_coop<8>, nRanges + (longFirst ? WO_LONG_MAX : 0), 512, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    else if (coopWaves >= 4 && flowing) {
+        if (dstats) { WO_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(long long), cur_stream(p))); launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, true>, nRanges + (longFirst ? WO_LONG_MAX : 0), 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)dstats); }
+        else launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, false>, nRanges + (longFirst ? WO_LONG_MAX : 0), 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
+    }
+    else if (coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges + (longFirst ? WO_LONG_MAX : 0), 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    else if (coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges + (longFirst ? WO_LONG_MAX : 0), 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
     else launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
 }
 
@@ -399,6 +602,8 @@ void basin_free(wo_planet* p) {
     if (p->d_basinKey) (void)hipFree(p->d_basinKey);
     for (auto& v : p->d_basinVals) { if (v) (void)hipFree(v); v = nullptr; }
     if (p->d_basinRange) (void)hipFree(p->d_basinRange);
+    if (p->d_basinLong) (void)hipFree(p->d_basinLong);
+    p->d_basinLong = nullptr;
     p->d_basinJ = nullptr; p->d_basinSlot = nullptr; p->d_basinKey = nullptr; p->d_basinRange = nullptr;
 }
 

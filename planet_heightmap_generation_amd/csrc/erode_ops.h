@@ -783,6 +783,14 @@ WO_HD inline float solve_final_cell(const Fields& F, int32_t x) {
 // nothing because its totalExcess is 0 — exactly the effect of the reference's `if (r_isOcean[nb]) continue`.
 WO_HD inline float masked_elev_cell(const Fields& F, int32_t r) { return F.ocean[r] ? INFINITY : F.e[r]; }
 
+// Cheap exact filter for `(x / d) > talus` (x >= 0, d > 0, doubles): when x <= talus * d * (1 - 1e-12) the real quotient is
+// below talus, and since rounding is monotone and talus is a double the rounded quotient cannot exceed it — the division
+// (an f64 division is ~30 VALU operations, and the thermal kernels are bound by them: 110 M VALU instructions per launch
+// at 10 M cells, profiles/r04b_*) is only evaluated where the test can still come out true.  After the first ~80 iterations
+// few slopes exceed the talus angle, so whole waves skip every division of the pass.  Same results bit for bit: the filter
+// only decides whether the exact expression is evaluated.
+WO_HD inline bool talus_may_exceed(double x, double d, double talus) { return x > talus * d * (1.0 - 1e-12); }
+
 // masked(c): F.me[c], or the workgroup's LDS copy of it (kernels_impl.h: TileWindow)
 template <class Masked>
 WO_HD inline void thermal_excess_cell_t(const Fields& F, int32_t r, double talus, Masked masked) {
@@ -801,6 +809,7 @@ WO_HD inline void thermal_excess_cell_t(const Fields& F, int32_t r, double talus
                 const double nh = mh[k];
                 if (k >= deg || nh >= h) continue;
                 const double d = nd_or_eps(dd[k]);
+                if (!talus_may_exceed(h - nh, d, talus)) continue;
                 const double slope = (h - nh) / d;
                 if (slope > talus) total += (slope - talus) * d;
             }
@@ -834,10 +843,20 @@ WO_HD inline float thermal_apply_row(const Fields& F, double h, int32_t myRank, 
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) mh[k] = masked(nbs[k]);
     load_row_dist(F, b, deg, dd);
+    {   // no slope towards or from c can exceed the talus angle (talus_may_exceed; an ocean neighbour's +inf never sends: its
+        // totalExcess is 0): neither c nor a neighbour has an event on c, delta stays 0
+        bool cand = false;
+#pragma unroll
+        for (int k = 0; k < WO_ROW; ++k) {
+            const double nh = mh[k], d = nd_or_eps(dd[k]);
+            cand = cand || (k < deg && nh != (double)INFINITY && talus_may_exceed(fabs(nh - h), d, talus));
+        }
+        if (!cand) return (float)(h + 0.0);
+    }
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) {
         const double nh = mh[k], d = nd_or_eps(dd[k]);
-        snd[k] = k < deg && nh > h && ((nh - h) / d > talus);
+        snd[k] = k < deg && nh > h && talus_may_exceed(nh - h, d, talus) && ((nh - h) / d > talus);
         tx[k] = snd[k] ? F.totalExcess[nbs[k]] : 0.0;
         rk[k] = snd[k] ? F.rank[nbs[k]] : 0;
     }

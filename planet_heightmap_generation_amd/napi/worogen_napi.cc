@@ -525,6 +525,27 @@ napi_value PlanetExchangeNeighbors(napi_env env, napi_callback_info info) {    /
     return nullptr;
 }
 
+napi_value PlanetSetFloodExchange(napi_env env, napi_callback_info info) {    // (planet, trueOcean Uint8Array | null, comm, counts Int32Array(nranks), cellsByRank Int32Array)
+    Args a(env, info); wo_planet* p = planet_at(a, 0);
+    if (!planet_ok(env, p)) return nullptr;
+    napi_valuetype t; napi_typeof(env, a.argv[1], &t);
+    if (t == napi_null || t == napi_undefined) {               // exchange off
+        if (wo_planet_set_flood_exchange(p, nullptr, nullptr, nullptr)) return throw_wo(env, "planetSetFloodExchange");
+        return nullptr;
+    }
+    size_t nOc, nCounts, nCells;
+    uint8_t* oc = (uint8_t*)a.ta(1, napi_uint8_array, &nOc); if (!a.ok) return nullptr;
+    wo_comm* cm = (wo_comm*)a.ext(2);
+    int32_t* counts = (int32_t*)a.ta(3, napi_int32_array, &nCounts); if (!a.ok) return nullptr;
+    int32_t* cells = (int32_t*)a.ta(4, napi_int32_array, &nCells); if (!a.ok) return nullptr;
+    if ((int32_t)nOc != wo_planet_num_regions(p)) { napi_throw_range_error(env, nullptr, "planetSetFloodExchange: r_isOcean length must equal mesh.numRegions"); return nullptr; }
+    if (!cm || (int)nCounts != wo_comm_size(cm)) { napi_throw_range_error(env, nullptr, "planetSetFloodExchange: one count per rank"); return nullptr; }
+    int64_t total = 0; for (size_t j = 0; j < nCounts; ++j) total += counts[j];
+    if (total != (int64_t)nCells) { napi_throw_range_error(env, nullptr, "planetSetFloodExchange: cellsByRank must hold every rank's cells, in rank order"); return nullptr; }
+    if (wo_planet_set_flood_exchange_comm(p, oc, cm, counts, cells)) return throw_wo(env, "planetSetFloodExchange");
+    return nullptr;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct { const char* name; napi_callback fn; } fns[] = {
         {"fibSpherePoints", FibSpherePoints}, {"sphereDelaunay", SphereDelaunay}, {"meshCsr", MeshCsr}, {"neighborDist", NeighborDist},
@@ -543,7 +564,7 @@ napi_value Init(napi_env env, napi_value exports) {
         {"diffuseOceanWarmth", DiffuseOceanWarmth}, {"computeWindConvergence", WindConvergence}, {"advectMoisture", AdvectMoisture},
         {"landComponents", LandComponents},
         {"commUniqueId", CommUniqueId}, {"commCreate", CommCreate}, {"planetSetHalo", PlanetSetHalo},
-        {"planetExchangeAllgather", PlanetExchangeAllgather}, {"planetExchangeNeighbors", PlanetExchangeNeighbors},
+        {"planetExchangeAllgather", PlanetExchangeAllgather}, {"planetExchangeNeighbors", PlanetExchangeNeighbors}, {"planetSetFloodExchange", PlanetSetFloodExchange},
     };
     for (auto& f : fns) {
         napi_value v;
