@@ -10,7 +10,7 @@
 // <= 1 024 — pits re-form between the two floods and cut the forest into small pieces.
 //
 // So, every pass:
-//   1. k_basin_init / k_basin_keys: the root of every land cell's component by pointer jumping on the receiver array
+//   1. k_receivers_flow_init (start state) / k_basin_jump / k_basin_keys: the root of every land cell's component by pointer jumping on the receiver array
 //      (in place, asynchronous: whatever a thread reads is an ancestor), 2-cycles of mutually draining cells cut at the
 //      cell with the smaller Morton slot.  key = root's Morton slot >> shift (a GROUP = the components whose roots fall
 //      in the same 2^shift Morton slots: a union of components is closed under the dependencies just the same, and
@@ -38,25 +38,9 @@ namespace wo {
 namespace {
 
 constexpr int32_t WO_RANGE_NONE = 0x7f7f7f7f;
+constexpr int WO_BASIN_RANGE = 256;                 // slots per workgroup range (a range = the groups that start in one stretch of this many slots)
+constexpr int WO_BASIN_KEY_BITS = 16;               // bits of a group key (two radix passes)
 constexpr int WO_BASIN_CHASE_CAP = 1 << 16;         // pointer-jumping steps of one thread before it gives up (never reached: chains and rings are shorter)
-
-// J[s] = Morton slot of the receiver of the cell at Morton slot s, or s itself for a root: no land receiver, or the
-// lower-slot cell of a pair draining into each other
-__global__ __launch_bounds__(WO_BLOCK) void k_basin_init(Fields F, const int32_t* __restrict__ slotCell, const int32_t* __restrict__ mslot, int32_t* __restrict__ J, int32_t L) {
-    for (int32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < L; s += gridDim.x * blockDim.x) {
-        const int32_t c = slotCell[s];
-        const TargetRank trc = F.tr[c];
-        int32_t j = s;
-        if (trc.target >= 0) {
-            const TargetRank trt = F.tr[trc.target];
-            if (trt.rank >= 0) {                                   // ocean cells carry rank -1
-                const int32_t st = mslot[trc.target];
-                if (!(trt.target == c && st > s)) j = st;
-            }
-        }
-        J[s] = j;
-    }
-}
 
 // Root of the component of the cell at Morton slot s.  Every value ever stored in J[x] is an ancestor of x (or, on a ring
 // of cells draining into each other — possible on flats, where "least ascent" is zero — another cell of the ring), so
@@ -154,110 +138,6 @@ __device__ inline bool block_range(const int32_t* __restrict__ rangeStart, int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Streaming form: ONE WAVE per range, no barrier and no polling.  The store order of a group is its processing order, a
-// topological order of its dependency DAG, so a wave can simply walk its range front to back in chunks of 64 tasks: every
-// predecessor of a chunk's task is either
-//   * further back than the ring (global memory: written by this wave long ago),
-//   * in one of the last WO_RING - 64 slots (the wave's LDS ring of {value, tag} granules), or
-//   * in the chunk itself, a lower lane: the chunk takes as many passes as its longest in-chunk chain (2-3), each pass running
-//     the lanes whose in-chunk predecessors are done (a ballot tells), values through the ring.
-// The windowed form above keeps a 16-wave workgroup on a CU for ~90 k clocks per 1 024 tasks, nearly all of it waiting at
-// barriers or polling (2 workgroups per CU); here a CU carries 32 independent waves that never wait for each other, and the
-// next chunk's records are in flight while the current one computes.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int WO_RING = 256;                       // tasks whose granules a wave keeps in LDS (power of two, >= 256)
-
-__global__ __launch_bounds__(64, 4) void k_solve_stream(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
-                                                         int32_t* patchPending, int32_t* totalPending) {
-    __shared__ unsigned long long s_ring[2 * WO_RING];
-    const int lane = threadIdx.x;
-    const int32_t S = rangeStart[blockIdx.x];
-    if (S == WO_RANGE_NONE) return;                                 // no group starts in this stretch
-    int32_t E = L;
-    for (int32_t j = blockIdx.x + 1; j < nRanges; ++j) { const int32_t v = rangeStart[j]; if (v != WO_RANGE_NONE) { E = v; break; } }
-    const unsigned long long* G = reinterpret_cast<const unsigned long long*>(F.out);      // granule = {value, tag} in one 8-byte word
-    unsigned long long* ring = s_ring;           // one wave: its LDS accesses execute in program order, no volatile (which would drain the loads in flight)
-    const unsigned long long BLOCKED = 0xffffffff00000000ull;       // tag -1
-    auto pack = [](Granule g) { return (unsigned long long)__float_as_uint(g.v) | ((unsigned long long)(uint32_t)g.tag << 32); };
-    // Software pipeline, all loads unconditional (clamped indices) so that they stay in flight across the chunk's work:
-    // records two chunks ahead; the predecessors of the NEXT chunk that lie further back than its ring window (or outside the
-    // range) one chunk ahead — those turns ended at least a whole chunk ago.
-    auto record = [&](int32_t q) { return F.task[q < L ? q : L - 1]; };
-    auto far_index = [&](int32_t g, int32_t cbase) { const int32_t sq = g >> 1; return (g >= 0 && (sq < S || sq < cbase - (WO_RING - 64))) ? g : 0; };
-    SolveTask T1 = record(S + lane), T2 = record(S + 64 + lane);
-    unsigned long long a0 = G[far_index(T1.predSelf, S)], a1 = G[far_index(T1.predT, S)], a2 = G[far_index(T1.predT2, S)];
-    SolveOut oPrev; oPrev.self.v = 0; oPrev.self.tag = 0; oPrev.dep.v = 0; oPrev.dep.tag = 0;
-    bool storePrev = false;
-    for (int32_t base = S; base < E; base += 64) {
-        const bool mine = base + lane < E;
-        // the previous chunk's results go out now, a chunk late: the wait for this chunk's loads at the top of the loop would
-        // otherwise also wait for a store issued a moment ago (whoever reads them from memory is at least two chunks behind)
-        if (storePrev) F.out[base - 64 + lane] = oPrev;
-        const SolveTask T = T1;
-        T1 = T2;
-        T2 = record(base + 128 + lane);
-        const unsigned long long n0 = G[far_index(T1.predSelf, base + 64)], n1 = G[far_index(T1.predT, base + 64)], n2 = G[far_index(T1.predT2, base + 64)];
-        double er = T.e0r, et = T.e0t, et2 = T.e0t2;
-        unsigned long long predMask = 0;                                 // lanes of this chunk I wait for
-        bool blocked = false;
-        int32_t r0 = -1, r1 = -1, r2 = -1;                               // ring words of the predecessors that come through the ring
-        if (mine) {
-            auto classify = [&](int32_t g, unsigned long long far, double& v, int32_t& rw) {
-                if (g < 0) return;
-                const int32_t sq = g >> 1;
-                if (sq >= base) {
-                    if (sq >= base + 64 || sq - base >= lane) { blocked = true; return; }      // not in processing order: the layout is off
-                    predMask |= 1ull << (sq - base);
-                    rw = g & (2 * WO_RING - 1);
-                } else if (sq >= S && sq >= base - (WO_RING - 64)) {
-                    rw = g & (2 * WO_RING - 1);
-                } else {
-                    const int32_t tag = (int32_t)(far >> 32);
-                    const bool own = sq >= S;                                                    // written by this wave, long ago
-                    if (tag <= 0 || (!own && tag >= launchTag)) { blocked = true; return; }
-                    v = __uint_as_float((uint32_t)far);
-                }
-            };
-            classify(T.predSelf, a0, er, r0); classify(T.predT, a1, et, r1); classify(T.predT2, a2, et2, r2);
-        }
-        const SolvePrepared pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
-        bool done = !mine;
-        SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
-        const int32_t myWord = (2 * (base + lane)) & (2 * WO_RING - 1);
-        if (mine && blocked) { ring[myWord] = BLOCKED; ring[myWord + 1] = BLOCKED; done = true; }
-        for (;;) {
-            const unsigned long long dm = __ballot(done);
-            if (dm == ~0ull) break;
-            const bool go = !done && (predMask & ~dm) == 0;
-            if (!__any(go)) {                                            // cannot happen (lower lanes only); give the rest up rather than spin
-                if (!done) { blocked = true; ring[myWord] = BLOCKED; ring[myWord + 1] = BLOCKED; done = true; }
-                continue;
-            }
-            if (go) {
-                bool bad = false;
-                auto rd = [&](int32_t rw, double& v) {
-                    if (rw < 0) return;
-                    const unsigned long long w = ring[rw];
-                    if ((int32_t)(w >> 32) <= 0) { bad = true; return; }
-                    v = __uint_as_float((uint32_t)w);
-                };
-                rd(r0, er); rd(r1, et); rd(r2, et2);
-                if (bad) { blocked = true; ring[myWord] = BLOCKED; ring[myWord + 1] = BLOCKED; }
-                else {
-                    o = solve_apply(T, pre, er, et, et2, launchTag);
-                    ring[myWord] = pack(o.self); ring[myWord + 1] = pack(o.dep);
-                }
-                done = true;
-            }
-        }
-        oPrev = o; storePrev = mine && !blocked;
-        if (mine && blocked) { atomicAdd(&patchPending[(base + lane) / WO_PATCH], 1); atomicAdd(totalPending, 1); }
-        a0 = n0; a1 = n1; a2 = n2;
-    }
-    if (storePrev) F.out[S + ((E - S - 1) / 64) * 64 + lane] = oPrev;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Cooperative streaming form: NW waves per range.  A launch of k_solve_stream lasts as long as its longest range — one wave
 // walking the biggest component alone, 100-330 chunks at ~2.4 us — while the chip is empty.  Here a workgroup of NW waves
 // walks the range in super-chunks of 64 x NW tasks: every lane takes one task and polls the granules of its predecessors
@@ -266,8 +146,8 @@ __global__ __launch_bounds__(64, 4) void k_solve_stream(Fields F, int32_t L, con
 // keeps the waves together (ring entries are reused RING slots later).  Loads are pipelined as in k_solve_stream.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NW>
-__global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
-                                                            int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag, long long* stats) {
+__global__ __launch_bounds__(64 * NW, 6) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
+                                                            int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag) {
     constexpr int SC = 64 * NW;                        // tasks per super-chunk
     constexpr int RING = (2 * SC > 1024) ? 2 * SC : 1024;    // tasks whose granules the workgroup keeps in LDS (power of two, >= 2 super-chunks)
     __shared__ unsigned long long s_ring[2 * RING];
@@ -298,14 +178,10 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
             if (fPrev & 32u) { F.e2[tPrev] = oPrev.dep.v; F.me[tPrev] = oPrev.dep.v; }
         }
     };
-    // WO_BASIN_STATS (diagnostic): block 0's first lane clocks the three phases of a super-chunk
-    const bool clocked = stats && blockIdx.x == 0 && tid == 0;
-    long long cLoad = 0, cPoll = 0, cBar = 0, nPolls = 0, c0 = clocked ? clock64() : 0;
-    const long long cStart = c0;
     for (int32_t base = S; base < E; base += SC) {
         const int32_t q = base + tid;
         const bool mine = q < E;
-        if (storePrev) store_prev(q - SC);                             // a super-chunk late (see k_solve_stream)
+        if (storePrev) store_prev(q - SC);                             // a super-chunk late: the wait for this super-chunk's loads at the top of the loop would otherwise also wait for a store issued a moment ago
         const SolveTask T = T1;
         T1 = T2;
         T2 = record(base + 2 * SC + tid);
@@ -331,9 +207,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
         bool open = mine;
         SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
         if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
-        if (clocked) { const long long c = clock64(); cLoad += c - c0; c0 = c; }
         while (__any(open)) {
-            if (clocked) ++nPolls;
             if (open) {
                 auto poll = [&](int32_t& rw, int32_t expect, double& v) {
                     if (rw < 0) return;
@@ -354,12 +228,9 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 6 : 4)) void k_solve_coop(Field
         oPrev = o; storePrev = mine && !blocked; fPrev = T.flags; rPrev = T.pad_[0]; tPrev = T.pad_[1];
         if (mine && blocked) { atomicAdd(&patchPending[q / WO_PATCH], 1); atomicAdd(totalPending, 1); }
         a0 = n0; a1 = n1; a2 = n2;
-        if (clocked) { const long long c = clock64(); cPoll += c - c0; c0 = c; }
         __syncthreads();
-        if (clocked) { const long long c = clock64(); cBar += c - c0; c0 = c; }
     }
     if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
-    if (clocked) { stats[0] = E - S; stats[1] = cLoad; stats[2] = cPoll; stats[3] = cBar; stats[4] = nPolls; stats[5] = clock64() - cStart; stats[6] = wall_clock64(); }
 }
 
 
@@ -431,7 +302,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (storePrev) store_prev(q - SC);                             // a super-chunk late (see k_solve_stream)
+        if (storePrev) store_prev(q - SC);                             // a super-chunk late: the wait for this super-chunk's loads at the top of the loop would otherwise also wait for a store issued a moment ago
         const SolveTask T = T1;
         T1 = T2;
         T2 = record(base + 2 * SC + tid);
@@ -453,36 +324,46 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
             };
             classify(T.predSelf, a0, er, r0, x0); classify(T.predT, a1, et, r1, x1); classify(T.predT2, a2, et2, r2, x2);
         }
-        const int32_t l0 = r0, l1 = r1, l2 = r2;       // (STATS) the ring words of the predecessors, before the polling clears them
+        // The polling loop as straight-line code: a single wave issues one instruction every few clocks, and the loop the
+        // compiler made of the nested conditions above was ~250 instructions per pass (~2 000 clocks per level of the DAG,
+        // WO_BASIN_STATS, profiles/r04e_*).  Here a pass reads the three ring words (a predecessor already in hand reads the
+        // task's own word), tests the tags with integer compares, and — only when some lane is ready — runs the turn for the
+        // whole wave without a branch (solve_apply_flat: the same operations on the same values, selected at the end).  Tags
+        // do not change once written (the ring slot is reused LAG super-chunks later at the earliest), so nothing is latched.
+        const int32_t w0 = r0 >= 0 ? r0 : myWord, w1 = r1 >= 0 ? r1 : myWord, w2 = r2 >= 0 ? r2 : myWord;
+        const bool n0b = r0 >= 0, n1b = r1 >= 0, n2b = r2 >= 0;
+        const float fr = (float)er, ft = (float)et, ft2 = (float)et2;      // inputs that are already in hand (exact: they came from floats)
         const SolvePrepared pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
         bool open = mine;
         SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
         if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
         while (__any(open)) {
-            // the three reads go out together; a predecessor that is already in hand reads the task's own word (ignored)
-            const unsigned long long w0 = ring_get(r0 >= 0 ? r0 : myWord), w1 = ring_get(r1 >= 0 ? r1 : myWord), w2 = ring_get(r2 >= 0 ? r2 : myWord);
-            if (open) {
-                auto take = [&](int32_t& rw, int32_t expect, unsigned long long w, double& v) {
-                    if (rw < 0) return;
-                    const int32_t tag = (int32_t)(w >> 32);
-                    if (tag == expect) { v = __uint_as_float((uint32_t)w); rw = -1; }
-                    else if (tag == -expect) { blocked = true; }
-                };
-                take(r0, x0, w0, er); take(r1, x1, w1, et); take(r2, x2, w2, et2);
-                if (blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
-                else if (r0 < 0 && r1 < 0 && r2 < 0) {
-                    o = solve_apply(T, pre, er, et, et2, launchTag);
+            const unsigned long long g0 = ring_get(w0), g1 = ring_get(w1), g2 = ring_get(w2);
+            const int32_t t0 = (int32_t)(g0 >> 32), t1 = (int32_t)(g1 >> 32), t2 = (int32_t)(g2 >> 32);
+            const bool ok = (!n0b | (t0 == x0)) & (!n1b | (t1 == x1)) & (!n2b | (t2 == x2));
+            const bool bad = (n0b & (t0 == -x0)) | (n1b & (t1 == -x1)) | (n2b & (t2 == -x2));
+            const bool ready = open & ok;
+            if (__any(ready)) {
+                const double ver = n0b ? (double)__uint_as_float((uint32_t)g0) : (double)fr;
+                const double vet = n1b ? (double)__uint_as_float((uint32_t)g1) : (double)ft;
+                const double vet2 = n2b ? (double)__uint_as_float((uint32_t)g2) : (double)ft2;
+                const SolveOut oo = solve_apply_flat(T, pre, ver, vet, vet2, launchTag);
+                if (ready) {
+                    o = oo;
                     if (STATS) {        // predecessors beyond the ring window count as depth 0 (they finished long ago)
                         int32_t lv = 0;
-                        if (l0 >= 0) lv = max(lv, s_level[l0 >> 1]);
-                        if (l1 >= 0) lv = max(lv, s_level[l1 >> 1]);
-                        if (l2 >= 0) lv = max(lv, s_level[l2 >> 1]);
+                        if (n0b) lv = max(lv, s_level[w0 >> 1]);
+                        if (n1b) lv = max(lv, s_level[w1 >> 1]);
+                        if (n2b) lv = max(lv, s_level[w2 >> 1]);
                         s_level[myWord >> 1] = lv + 1;
                         atomicMax(&s_maxLevel, lv + 1);
                     }
-                    ring_put(myWord, o.self.v, q + 1); ring_put(myWord + 1, o.dep.v, q + 1);
+                    ring_put(myWord, oo.self.v, q + 1); ring_put(myWord + 1, oo.dep.v, q + 1);
                     open = false;
                 }
+            }
+            if (__any(open & bad)) {                                     // a predecessor is blocked (never on real layouts: WO_BASIN_SCRAMBLE)
+                if (open & bad) { blocked = true; ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
             }
         }
         oPrev = o; storePrev = mine && !blocked; fPrev = T.flags; rPrev = T.pad_[0]; tPrev = T.pad_[1];
@@ -504,12 +385,6 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
 
 }  // namespace
 
-// slots per workgroup range (a range = the groups that start in one stretch of this many slots)
-static int basin_range() {
-    static const int r = getenv("WO_BASIN_RANGE") ? std::max(64, (atoi(getenv("WO_BASIN_RANGE")) / 64) * 64) : 256;
-    return r;
-}
-
 // Group-major store order for this pass (d_basinSlot) and the sorted group keys (d_keys[1]).  Call after the receivers
 // pass (F.tr) and before k_solve_setup; everything is enqueued on the planet's stream, no host sync.
 void basin_alloc(wo_planet* p) {
@@ -526,27 +401,24 @@ void basin_alloc(wo_planet* p) {
     }
 }
 
-// jFromReceivers: J already holds the start state (k_receivers_flow_init, Fields::basinJ; pairs of cells draining into each other
-// are rings of two there, which the search cuts like any ring: at the smaller slot, as k_basin_init does).  slotIdentity: a land
+// J already holds the start state (k_receivers_flow_init, Fields::basinJ; pairs of cells draining into each other are rings of
+// two there, which the search cuts like any ring: at the smaller slot).  slotIdentity: a land
 // cell's Morton slot is its id (land-first mirror).
-void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
+void basin_layout(wo_planet* p, bool slotIdentity) {
     const int32_t L = p->L;
     hipStream_t s = cur_stream(p);
     basin_alloc(p);
-    const Fields F = p->fields();
     int bitsL = 1;
     while (((int64_t)1 << bitsL) < (int64_t)L) ++bitsL;
-    static const int keyBits = getenv("WO_BASIN_KEY_BITS") ? std::max(8, std::min(30, atoi(getenv("WO_BASIN_KEY_BITS")))) : 16;
-    const int shift = bitsL > keyBits ? bitsL - keyBits : 0;
+    const int shift = bitsL > WO_BASIN_KEY_BITS ? bitsL - WO_BASIN_KEY_BITS : 0;
     const int grid = blocks_for(L, 1 << 16);
-    if (!jFromReceivers) launch(p, FAM_BASIN, k_basin_init, grid, WO_BLOCK, F, (const int32_t*)p->d_patchOrder, (const int32_t*)p->d_slotOf, p->d_basinJ, L);
     launch(p, FAM_BASIN, k_basin_jump, grid, WO_BLOCK, slotIdentity ? (const int32_t*)nullptr : (const int32_t*)p->d_patchOrder, p->d_basinJ, L, (int32_t)shift, p->d_basinKey);
-    const int rangeT = basin_range();
+    const int rangeT = WO_BASIN_RANGE;
     const int nRanges = (int)(((int64_t)L + rangeT - 1) / rangeT);
     launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
-           (int32_t)((getenv("WO_BASIN_SCRAMBLE") && atoi(getenv("WO_BASIN_SCRAMBLE")) != 0) ? 1 : 0), p->d_basinRange, (int32_t)(nRanges + 1));
+           (int32_t)(p->opt.basinScramble ? 1 : 0), p->d_basinRange, (int32_t)(nRanges + 1));
     // the in-tree sort (radix.hip; its last pass also writes slotOf[cell] = position); WO_SORT=hipcub: the library sort
-    const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";     // read per sort (tests switch it)
+    const bool library = p->opt.sortLibrary;
     int sorted = 1;                                  // which of d_keys / d_basinVals holds the result
     if (!library) {
         uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
@@ -566,34 +438,29 @@ void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity) {
 
 // the one launch of the pass; F.slotOf must be d_basinSlot, patchPending zeroed
 void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending) {
-    const int rangeT = basin_range();
-    const int nRanges = (int)(((int64_t)p->L + rangeT - 1) / rangeT);
-    // WO_BASIN_WAVES: waves per range — 4 (default) / 2: k_solve_coop; 1: k_solve_stream
-    static const int coopWaves = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
+    const int nRanges = (int)(((int64_t)p->L + WO_BASIN_RANGE - 1) / WO_BASIN_RANGE);
     ++p->basinLaunches;
-    static const bool longFirst = !(getenv("WO_BASIN_LONG_FIRST") && atoi(getenv("WO_BASIN_LONG_FIRST")) == 0);
-    const int32_t* big = longFirst ? (const int32_t*)(p->d_basinRange + nRanges + 1) : (const int32_t*)nullptr;
-    const uint8_t* flag = longFirst ? (const uint8_t*)p->d_basinLong : (const uint8_t*)nullptr;
-    static const bool flowing = !(getenv("WO_BASIN_KERNEL") && std::string(getenv("WO_BASIN_KERNEL")) == "barrier");      // barrier: k_solve_coop (one barrier per super-chunk)
-    static const bool statsOn = getenv("WO_BASIN_STATS") && atoi(getenv("WO_BASIN_STATS")) != 0;
-    static long long* dstatsBuf = nullptr;
-    if (statsOn && !dstatsBuf) { WO_HIP(hipMalloc((void**)&dstatsBuf, 8 * sizeof(long long))); WO_HIP(hipMemset(dstatsBuf, 0, 8 * sizeof(long long))); }
-    long long* dstats = statsOn ? dstatsBuf : nullptr;
-    struct StatsPrint { wo_planet* p; long long* d; bool flowingKernel; ~StatsPrint() {
-        if (!d) return;
-        long long h[8]; (void)hipStreamSynchronize(cur_stream(p)); (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-        if (flowingKernel) fprintf(stderr, "[basin stats] slowest range: %lld slots, %lld clocks, DAG depth (ring window) %lld -> %.0f clocks per level\n", h[1], (long long)((unsigned long long)h[0] >> 24), h[0] & 0xffffff, (double)((unsigned long long)h[0] >> 24) / (double)std::max<long long>(1, h[0] & 0xffffff));
-        else fprintf(stderr, "[basin stats] block 0: range %lld slots, clocks: loads %lld, polling %lld (%lld loop passes), barrier %lld, total %lld\n", h[0], h[1], h[2], h[4], h[3], h[5]);
-    } } statsPrint{p, dstats, flowing && coopWaves >= 4 && coopWaves < 8};
-    if (coopWaves >= 16) launch(p, FAM_SOLVE_BASIN, k_solve_coop<16>, nRanges + (longFirst ? WO_LONG_MAX : 0), 1024, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    else if (coopWaves >= 8) launch(p, FAM_SOLVE_BASIN, k_solve_coop<8>, nRanges + (longFirst ? WO_LONG_MAX : 0), 512, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    else if (coopWaves >= 4 && flowing) {
-        if (dstats) { WO_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(long long), cur_stream(p))); launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, true>, nRanges + (longFirst ? WO_LONG_MAX : 0), 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)dstats); }
-        else launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, false>, nRanges + (longFirst ? WO_LONG_MAX : 0), 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
+    const int32_t* big = (const int32_t*)(p->d_basinRange + nRanges + 1);
+    const uint8_t* flag = (const uint8_t*)p->d_basinLong;
+    const int grid = nRanges + WO_LONG_MAX;
+    if (p->opt.basinBarrierKernel) {           // WO_BASIN_KERNEL=barrier: the walk with one barrier per super-chunk (cross-check route)
+        launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, grid, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag);
+        return;
     }
-    else if (coopWaves >= 4) launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, nRanges + (longFirst ? WO_LONG_MAX : 0), 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    else if (coopWaves >= 2) launch(p, FAM_SOLVE_BASIN, k_solve_coop<2>, nRanges + (longFirst ? WO_LONG_MAX : 0), 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    else launch(p, FAM_SOLVE_BASIN, k_solve_stream, nRanges, 64, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending);
+    if (!p->opt.basinStats) {
+        launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, false>, grid, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
+        return;
+    }
+    // WO_BASIN_STATS=1 (diagnostic): the slowest range of the launch, its clocks and the depth of its dependency DAG -> stderr
+    static unsigned long long* dstats = nullptr;
+    if (!dstats) WO_HIP(hipMalloc((void**)&dstats, 2 * sizeof(unsigned long long)));
+    WO_HIP(hipMemsetAsync(dstats, 0, 2 * sizeof(unsigned long long), cur_stream(p)));
+    launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, true>, grid, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    unsigned long long h[2];
+    WO_HIP(hipStreamSynchronize(cur_stream(p)));
+    WO_HIP(hipMemcpy(h, dstats, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[basin stats] slowest range: %llu slots, %llu clocks, DAG depth (ring window) %llu -> %.0f clocks per level\n", h[1], h[0] >> 24, h[0] & 0xffffffull,
+            (double)(h[0] >> 24) / (double)std::max<unsigned long long>(1, h[0] & 0xffffffull));
 }
 
 void basin_free(wo_planet* p) {

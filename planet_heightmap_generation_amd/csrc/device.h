@@ -82,8 +82,35 @@ struct wo_flood_gpu {
     int32_t *h_par = nullptr, *h_root = nullptr; float* h_surf = nullptr;   // pinned
 };
 
+namespace wo {
+// Environment switches, read once per API call (check_planet -> Options::from_env), never inside an iteration.  What is left are
+// the cross-check routes the tests drive (every one must give the default route's bits), test hooks and diagnostics.
+struct Options {
+    bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror
+    bool sortLibrary = false;          // WO_SORT=hipcub           the library's radix sort instead of radix.hip
+    bool basinBarrierKernel = false;   // WO_BASIN_KERNEL=barrier  k_solve_coop (one barrier per super-chunk) instead of k_solve_flowing
+    bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr
+    bool basinScramble = false;        // WO_BASIN_SCRAMBLE=1      test hook: a deliberately wrong layout (leftovers for the patch finisher)
+    bool tileLds = false;              // WO_TILE_LDS=1            neighbour window of a workgroup's tile staged in LDS
+    bool noSolvePatch = false;         // WO_NO_SOLVE_PATCH        level-synchronous solve rounds
+    bool noEventLists = false;         // WO_NO_EVENT_LISTS        solve setup by row scans
+    int  flowClimbCap = 0x7fffffff;    // WO_FLOW_CLIMB=n          cap of a thread's climb (0: rake rounds + pointer doubling)
+    bool flowEventsStream = false;     // WO_FLOW_EVENTS_STREAM=1  the solve's event lists on a third stream
+    bool iceRounds = false;            // WO_ICE_ROUNDS=1          synchronous ice accumulation rounds
+    int  carveFlow = 2;                // WO_CARVE_FLOW            2 granules, 1 done words, 0 rounds
+    long long carveFlowBudgetMs = 200; // WO_CARVE_FLOW_BUDGET_MS  spin budget of the one-launch carve
+    int  carveFlowBlocks = 0;          // WO_CARVE_FLOW_BLOCKS     test hook: at most this many workgroups
+    bool floodDevice = false;          // WO_FLOOD=device          pass 1 of the flood as the device label-correcting fixed point
+    bool floodTiesById = false;        // WO_FLOOD_TIES=id         accept the cell-id order between equal labels (device flood)
+    bool floodTiming = false;          // WO_FLOOD_TIMING          stage laps -> stderr
+    bool stageTimingAll = false;       // WO_STAGE_TIMING=all      bracket every iteration
+    static Options from_env();
+};
+}  // namespace wo
+
 struct wo_planet {
     wo_ctx* ctx = nullptr;
+    wo::Options opt;
     int32_t N = 0, E = 0, maxDeg = 0;
     // host copies kept for the host-resident flood stage
     wo::hvec<int32_t> h_off, h_adj;          // host mirrors walked in data-dependent order: huge-page advised (host_util.h)
@@ -116,7 +143,7 @@ struct wo_planet {
     float *d_cellDist = nullptr, *d_flow = nullptr;
     wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; int32_t *d_haloSend = nullptr, *d_haloRecv = nullptr; float *d_haloBuf = nullptr, *h_haloBuf = nullptr; int32_t nHaloSend = 0, nHaloRecv = 0;   // banded Jacobi passes
     int32_t* d_flowCnt = nullptr; wo::TargetRank* d_tr = nullptr; wo::EventList* d_ev = nullptr; float* d_me = nullptr;
-    int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; int2* d_carvePairs[2] = {nullptr, nullptr}; uint32_t* d_rs[2] = {nullptr, nullptr}; int rsFlip[2] = {0, 0};   /* radix.hip scratch: elevation sort, basin sort */ wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
+    int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; uint32_t* d_rs[2] = {nullptr, nullptr}; int rsFlip[2] = {0, 0};   /* radix.hip scratch: elevation sort, basin sort */ wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
     uint32_t *d_acc = nullptr, *d_snap = nullptr; unsigned long long* d_accCnt = nullptr;
     int32_t *d_jump = nullptr, *d_nj = nullptr;
     int32_t* d_doneAt = nullptr;
@@ -213,7 +240,7 @@ uint32_t* radix_scratch(wo_planet* p, int which);      // 0: elevation sort, 1: 
 void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount);   // carve tasks in landCells order
 // basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it
 void basin_alloc(wo_planet* p);
-void basin_layout(wo_planet* p, bool jFromReceivers, bool slotIdentity);
+void basin_layout(wo_planet* p, bool slotIdentity);
 void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_t* totalPending);
 void basin_free(wo_planet* p);
 

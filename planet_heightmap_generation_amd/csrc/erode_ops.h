@@ -719,6 +719,29 @@ WO_HD inline SolveOut solve_apply(const SolveTask& T, const SolvePrepared& S, do
     o.self.v = (float)hn; o.dep.v = tval;
     return o;
 }
+// The same turn without a branch, for a wave that runs it for whichever lanes are ready (basin.hip: k_solve_flowing): every
+// expression of solve_apply is evaluated, on the same operands, and the conditions select among the results — an unused
+// quotient may be inf / NaN (a missing t2 has cellDistT 0), it is never selected.
+WO_HD inline SolveOut solve_apply_flat(const SolveTask& T, const SolvePrepared& S, double er, double et, double et2, int32_t tag) {
+    const bool hasT = (T.flags & 4u) != 0, tOcean = (T.flags & 1u) != 0, hasT2 = (T.flags & 8u) != 0;
+    const double hr = et > 0 ? et : 0;
+    double hn = div_by_prepared(er + S.factor * hr, S.onePlusFactor);
+    hn = hn < hr ? hr : hn;
+    hn = hn < 0 ? 0 : hn;
+    const double eroded = er - hn;
+    const double sl = div_by_prepared(fabs(et - et2), S.cellDistT);
+    const double slope = hasT2 ? sl : 0.0;
+    const double depositFrac = 0.5 / (1 + slope * 50);
+    const double deposit = eroded * depositFrac;
+    float tv = (float)(et + deposit);
+    tv = ((double)tv > hn) ? (float)hn : tv;
+    const bool deposits = eroded > 0 && !tOcean;
+    SolveOut o;
+    o.self.tag = tag; o.dep.tag = tag;
+    o.self.v = hasT ? (float)hn : (float)er;
+    o.dep.v = hasT ? (deposits ? tv : (float)et) : 0.0f;
+    return o;
+}
 WO_HD inline SolveOut solve_compute(const SolveTask& T, double er, double et, double et2, int32_t tag, double K, double m, double dt) {
     return solve_apply(T, solve_prepare(T, K, m, dt), er, et, et2, tag);
 }

@@ -126,7 +126,7 @@ inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
     int nt = host_threads();
     if (n < min_chunk * 2 || nt == 1) { fn((int64_t)0, n, 0); return; }
     int64_t chunks = std::min<int64_t>(nt, (n + min_chunk - 1) / min_chunk);
-    static const bool pooled = !(std::getenv("WO_HOST_POOL") && std::atoi(std::getenv("WO_HOST_POOL")) == 0);
+    constexpr bool pooled = true;
     if (pooled) {
         const std::function<void(int64_t)> job = [&](int64_t c) { fn(n * c / chunks, n * (c + 1) / chunks, (int)c); };
         if (HostPool::get().run(chunks, job)) return;

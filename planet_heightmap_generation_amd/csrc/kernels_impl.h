@@ -174,7 +174,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_plate_project(CoarsePlates C, cons
 __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N) { WO_GRID_STRIDE(r, N) rank[r] = -1; }
 
 // ---------------------------------------------------------------- hydraulic ---------------------
-__global__ __launch_bounds__(WO_BLOCK) void k_receivers(Fields F) { WO_XCD_CELLS(r, F.N) receiver_cell(F, r); }
 // receivers + the start state of the flow accumulation (k_flow_init) in one pass over the cells
 // per-ocean-cell constants of the hydraulic and thermal passes (the ocean mask is fixed during an erodeComposite)
 __global__ __launch_bounds__(WO_BLOCK) void k_erode_ocean_init(Fields F) {
@@ -334,13 +333,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_init(Fields F) {
-    WO_XCD_CELLS(r, F.N) {
-        int32_t j = -1; uint32_t a = 0;
-        if (!F.ocean[r]) { a = 1; j = flow_forward_target(F, r); }
-        F.accA[r] = a; F.jumpA[r] = j;
-    }
-}
 // pointer-doubling round, part 1: snapshot the value each active cell will send and its next ancestor
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_snap(Fields F, const int32_t* list, const int32_t* count, uint32_t* snap, int32_t* nj) {
     const int32_t n = *count;
@@ -944,23 +936,8 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_records(Fields F, const int3
     const int32_t n = *count;
     WO_GRID_STRIDE(i, n) { carve_record_cell(F, list[i], i, recs, gCarve, gConv, gStrength, withDeps); if (resetDone) slotDone[i] = WO_NOT_DONE; }
 }
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
-                                                           int32_t* outCount, int32_t* zeroCount, int32_t round, double gCarve,
-                                                           double gConv, double gStrength) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    const int32_t n = *inCount;
-    WO_BLOCK_STRIDE(i, valid, n) {
-        bool pending = false; int32_t r = -1;
-        if (valid) { r = in[i]; pending = !carve_task(F, r, round, gCarve, gConv, gStrength); }
-        block_append(pending, r, out, outCount);
-    }
-}
 // Carve rounds on {task, blocker} entries: a round is as long as its longest chain of dependent loads, and a parked task
 // only needs list entry -> doneAt[blocker]; the task's own records are touched when that blocker has finished.
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_pairs_init(const int32_t* list, const int32_t* count, int2* out) {
-    const int32_t n = *count;
-    WO_GRID_STRIDE(i, n) out[i] = make_int2(list[i], -1);
-}
 __device__ inline void block_append2(bool flag, int2 v, int2* out, int32_t* outCount) {
     __shared__ int32_t s_base2, s_wave2[WO_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -975,20 +952,6 @@ __device__ inline void block_append2(bool flag, int2 v, int2* out, int32_t* outC
     __syncthreads();
     if (flag) out[s_base2 + s_wave2[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
     __syncthreads();
-}
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_round_pairs(Fields F, const int2* in, const int32_t* inCount, int2* out, int32_t* outCount,
-                                                                 int32_t* zeroCount, int32_t round, double gCarve, double gConv, double gStrength) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    const int32_t n = *inCount;
-    WO_BLOCK_STRIDE(i, valid, n) {
-        bool pending = false; int2 ent = make_int2(-1, -1);
-        if (valid) {
-            ent = in[i];
-            if (ent.y >= 0 && !(F.doneAt[ent.y] < round)) pending = true;             // still parked on the same blocker
-            else if (!carve_task(F, ent.x, round, gCarve, gConv, gStrength)) { pending = true; ent.y = carve_current_blocker(F, ent.x); }
-        }
-        block_append2(pending, ent, out, outCount);
-    }
 }
 // Carve rounds over the STATIC activation list: one thread per active task in every round, no pending lists, no counters on the
 // chain.  A finished task leaves after one load; an open one issues all its loads at once (carve_task_eager) and runs when its

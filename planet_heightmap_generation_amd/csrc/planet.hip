@@ -78,9 +78,8 @@ static void ensure_scratch(wo_planet* p) {
 
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
-    static const int tileLds = (getenv("WO_TILE_LDS") && atoi(getenv("WO_TILE_LDS")) != 0) ? 1 : 0;
-    F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = tileLds; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = (getenv("WO_NO_EVENT_LISTS") == nullptr) ? d_ev : nullptr; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
+    F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = opt.tileLds ? 1 : 0; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = opt.noEventLists ? nullptr : d_ev; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -108,9 +107,9 @@ static void refresh_host_ocean(wo_planet* p) {
 
 // One device integer for the host, through a host-mapped word the host polls: ~10 us from the producing kernel's end to the next
 // launch instead of ~30 (copy kernel, stream synchronisation, wake-up).  Falls back to the copy when the word is not there or the
-// poll outlasts 2 s (a faulted stream must surface as an error, not as a hang).  WO_POLL_COUNTS=0: always the copy.
+// poll outlasts 2 s (a faulted stream must surface as an error, not as a hang).
 static int32_t publish_and_wait(wo_planet* p, const int32_t* d_ptr) {
-    static const bool poll = !(getenv("WO_POLL_COUNTS") && atoi(getenv("WO_POLL_COUNTS")) == 0);
+    const bool poll = true;
     hipStream_t s = p->ctx->stream;
     if (poll && !p->h_word) {
         if (hipHostMalloc((void**)&p->h_word, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void**)&p->d_word, p->h_word, 0) != hipSuccess) { p->h_word = nullptr; p->d_word = nullptr; (void)hipGetLastError(); }
@@ -210,7 +209,7 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
     int32_t leftKnown = 0;
     const int32_t* in = p->d_listB;
     int32_t* out = p->d_listA;
-    const bool tailEnabled = std::getenv("WO_NO_SOLVE_TAIL") == nullptr;
+    const bool tailEnabled = true;
     for (;;) {
         for (int b = 0; b < batch; ++b, ++k) {
             // tasks enter WO_LOOKAHEAD rounds ahead of their predicted level: a few cheap re-examinations buy
@@ -285,16 +284,9 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
     int32_t* tot = p->d_patchTotals;
     if (!countersCleared) WO_HIP(hipMemsetAsync(tot, 0, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), s));
     int64_t launches = 0;
-    // WO_SOLVE_SPINS: polling passes per visit (kernels_impl.h).  WO_SOLVE_STATS=<n>: per-launch counters of the n-th solve
-    // pass of the planet -> stderr (diagnostic).
-    static const int spinCap = getenv("WO_SOLVE_SPINS") ? std::max(1, atoi(getenv("WO_SOLVE_SPINS"))) : WO_PATCH_SPIN_CAP;
-    // launches from lateFrom on (few patches still open: no queue of visits behind a long one) may poll longer
-    static const int lateFrom = getenv("WO_SOLVE_LATE_FROM") ? atoi(getenv("WO_SOLVE_LATE_FROM")) : WO_PATCH_LATE_FROM;
-    static const int lateCap = getenv("WO_SOLVE_LATE_SPINS") ? std::max(1, atoi(getenv("WO_SOLVE_LATE_SPINS"))) : WO_PATCH_LATE_SPIN_CAP;
-    static const int statsIter = getenv("WO_SOLVE_STATS") ? atoi(getenv("WO_SOLVE_STATS")) : -1;
-    constexpr int DBG_W = 8, DBG_N = 512;
-    int32_t* dbg = nullptr;
-    if (statsIter >= 0 && p->solveCalls++ == statsIter) { WO_HIP(hipMalloc(&dbg, DBG_N * DBG_W * sizeof(int32_t))); WO_HIP(hipMemsetAsync(dbg, 0, DBG_N * DBG_W * sizeof(int32_t), s)); }
+    // polling passes per visit (kernels_impl.h); launches from lateFrom on (few patches still open: no queue of visits behind a
+    // long one) may poll longer
+    constexpr int spinCap = WO_PATCH_SPIN_CAP, lateFrom = WO_PATCH_LATE_FROM, lateCap = WO_PATCH_LATE_SPIN_CAP;
     int64_t need = 0;
     for (int32_t tag = 1;; ) {
         // The pending totals are read back (one stream sync) after every burst.  The number of launches a pass needs barely
@@ -315,7 +307,7 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
             // launch left pending get one; normally there is no such launch at all)
             if (basin && tag == 2 && F.solveLean) launch(p, FAM_MISC, k_solve_blk_init, blocks_for(p->L, 4096), WO_BLOCK, F, p->L);
             launch(p, FAM_SOLVE_PATCH, k_solve_patch, np, WO_PATCH_THREADS, F, p->L, tag, p->d_patchPending, tot + (tag % WO_PATCH_TOTAL_SLOTS), K, m, dt,
-                   dbg ? dbg + DBG_W * std::min<int32_t>(tag, DBG_N - 1) : nullptr, (int32_t)(tag >= lateFrom ? lateCap : spinCap));
+                   (int32_t*)nullptr, (int32_t)(tag >= lateFrom ? lateCap : spinCap));
             }
             ++launches;
         }
@@ -329,13 +321,6 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
         }
         if (need) break;
         if (launches > 4 * (int64_t)p->N + 1024) throw HipError{"patch solve does not converge"};
-    }
-    if (dbg) {
-        std::vector<int32_t> h(DBG_N * DBG_W);
-        WO_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        WO_HIP(hipFree(dbg));
-        fprintf(stderr, "solve stats: %d patches of %d, %d tasks, %lld launches, spin cap %d\nlaunch idle_visits running_visits runnable completed max_passes\n", np, WO_PATCH, p->L, (long long)launches, spinCap);
-        for (int t = 1; t <= std::min<int64_t>(launches, DBG_N - 1); ++t) { const int32_t* q = &h[DBG_W * t]; fprintf(stderr, "%d %d %d %d %d %d\n", t, q[0], q[1], q[2], q[3], q[4]); }
     }
     p->lastPatchLaunches = basin ? need : need + 1;      // basin: the first burst is exactly what the last pass needed (one launch)
     return need;
@@ -450,7 +435,7 @@ static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
     launch(p, FAM_FLOOD_MISC, k_fl_init, blocks_for(L, 4096), WO_BLOCK, D, G.e, (const float*)p->d_e, C);
     launch(p, FAM_FLOOD_MISC, k_fl_seed_dirty, blocks_for(G.nSeeds, 1024), WO_BLOCK, D, (const int32_t*)G.seeds, G.nSeeds, Ls, C);
     const int grid = blocks_for(L / 4 + 1, 1024);
-    static const int64_t maxRounds = [] { const char* e = std::getenv("WO_FLOOD_MAX_ROUNDS"); const long long v = e ? std::atoll(e) : 0; return v > 0 ? (int64_t)v : (int64_t)200000; }();
+    constexpr int64_t maxRounds = 200000;
     bool done = false, over = false;
     int batch = 32;
     for (int64_t launched = 0; launched < maxRounds && !done;) {
@@ -484,8 +469,7 @@ static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
     if (ok && hC->notFixed != 0) ok = false;                // cannot happen at termination; refuse the result if it does
     if (ok) {
         R.ties += hC->ties;
-        const char* te = std::getenv("WO_FLOOD_TIES");
-        const bool acceptIdOrder = te && std::string(te) == "id";
+        const bool acceptIdOrder = p->opt.floodTiesById;
         if (hC->ties > 0 && !acceptIdOrder) ok = false;
     }
     if (!ok) R.fellBack = true;
@@ -495,7 +479,7 @@ static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
 static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     hipStream_t s = p->ctx->stream;
     const size_t bytes = (size_t)p->N * sizeof(float);
-    const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    const bool timing = p->opt.floodTiming;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing) return;
@@ -511,8 +495,7 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
         flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S);
     lap("static");
     if (S.L == 0 && !p->floodX.on) return;       // (a share without land still takes part in the exchange)
-    const char* fe = std::getenv("WO_FLOOD");
-    const bool hostOnly = p->floodX.on || !(fe && std::string(fe) == "device");
+    const bool hostOnly = p->floodX.on || !p->opt.floodDevice;
     WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     const bool useDevice = !hostOnly && flood_device_pass1(p, R);       // synchronises the stream
     if (hostOnly) WO_HIP(hipStreamSynchronize(s));
@@ -550,8 +533,7 @@ static void coast_flags(wo_planet* p) {
 // 1.10 -> 0.85 s.  WO_LAYOUT=index switches the mirror off.
 // ---------------------------------------------------------------------------------------------------
 static bool mirror_wanted(const wo_planet* p) {
-    const char* e = std::getenv("WO_LAYOUT");
-    return !(e && std::string(e) == "index") && !p->h_xyz.empty() && p->N > 1;
+    return !p->opt.layoutIndex && !p->h_xyz.empty() && p->N > 1;
 }
 // mask (may be null): the ocean mask of the call the mirror is entered for.  With a mask the renaming is LAND FIRST: the land
 // cells in Morton order take the ids 0 .. L-1, the ocean cells follow in Morton order.  Every per-cell array of the erosion
@@ -563,8 +545,6 @@ static bool mirror_wanted(const wo_planet* p) {
 static void mirror_build(wo_planet* p, const uint8_t* mask = nullptr) {
     auto& M = p->mirror;
     const int32_t N = p->N; const size_t E = (size_t)p->E;
-    static const bool landFirst = !(std::getenv("WO_MIRROR_LAND_FIRST") && std::atoi(std::getenv("WO_MIRROR_LAND_FIRST")) == 0);
-    if (!landFirst) mask = nullptr;
     if (M.built && (!mask || (M.h_mask.size() == (size_t)N && std::memcmp(M.h_mask.data(), mask, (size_t)N) == 0))) return;
     hipStream_t s = p->ctx->stream;
     if (M.h_morton.empty()) morton_order_cells(N, p->h_xyz.data(), M.h_morton);
@@ -675,8 +655,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     refresh_host_ocean(p);          // the planet's own mask, before the pointers move
     MirrorScope mir(p);
     mir.enter(p->h_ocean.data());          // land first (mirror_build)
-    static const bool identityOk = !(getenv("WO_LAND_IDENTITY") && atoi(getenv("WO_LAND_IDENTITY")) == 0);
-    p->landIdentity = identityOk && mir.on && p->mirror.h_mask.size() == (size_t)N;      // land cells are the ids 0 .. L-1: the index-order passes skip the land list
+    p->landIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;      // land cells are the ids 0 .. L-1: the index-order passes skip the land list
     coast_flags(p);
     // landCells in ascending r (js/terrain-post.js:384-390): host-side compaction of the ocean mask
     {
@@ -731,7 +710,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         rank_from_land(p);      // thermal-only runs never sort: landCells stays in ascending-r order
         launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_level, 1, N);   // no level history yet: everything in round 1
         // spatial patches for the patch-local solve: land cells in Morton order (shared with the host flood's layout)
-        if (hIters > 0 && !p->h_xyz.empty() && std::getenv("WO_NO_SOLVE_PATCH") == nullptr) {
+        if (hIters > 0 && !p->h_xyz.empty() && !p->opt.noSolvePatch) {
             if (!p->flood.staticValid || p->flood.staticN != N)
                 flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood);
             if (p->patchVersion != p->flood.staticVersion || p->patchMirror != mir.on) {
@@ -783,12 +762,11 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t midIter = (int32_t)std::floor(total * 0.75 + 0.5);
     bool midDone = false;
     // (round 2's river-aligned patch lists, WO_RIVER_PATCHES, were measured and dropped: profiles/r02c_river_patch_experiment.txt)
-    // WO_BASIN=0: the Morton patches of round 2 (k_solve_patch from the first launch on) instead of the basin-local solve
-    static const bool basinSolve = !(getenv("WO_BASIN") && atoi(getenv("WO_BASIN")) == 0);
+    const bool basinSolve = true;          // (k_solve_patch launches remain as the finisher of tasks a basin launch leaves pending)
     int64_t basinPasses = 0, basinLeftoverPasses = 0, carveActive = 0;
     int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
-    static const bool stageAll = getenv("WO_STAGE_TIMING") && std::string(getenv("WO_STAGE_TIMING")) == "all";
+    const bool stageAll = p->opt.stageTimingAll;
     for (int32_t iter = 0; iter < total; ++iter) {
         clk.on = true;
         if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
@@ -802,14 +780,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             launch(p, FAM_ICE_RECV, k_ice_receivers, gridN, WO_BLOCK, F);
             // ice accumulation: one launch in which the last donor to arrive runs its receiver's task (k_ice_climb);
             // WO_ICE_ROUNDS=1: the synchronous rounds of earlier builds (cross-check)
-            const bool iceRoundsEnv = getenv("WO_ICE_ROUNDS") && atoi(getenv("WO_ICE_ROUNDS")) != 0;     // read per glacial step (tests switch it)
+            const bool iceRoundsEnv = p->opt.iceRounds;
             if (!iceRoundsEnv) { launch(p, FAM_ICE_ROUND, k_ice_climb, gridL, WO_BLOCK, F, F.blocker); ++iceRounds; }
             else iceRounds += run_rounds(p, p->d_landIdx, L, false, 8,
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
                 });
             // WO_CARVE_FLOW=0: no one-launch carve (k_carve_flow), activation list in arrival order as in earlier builds
-            const int carveFlowMode = getenv("WO_CARVE_FLOW") ? atoi(getenv("WO_CARVE_FLOW")) : 2;      // 2: heights as granules (k_carve_granules), 1: done words (k_carve_flow), 0: rounds
+            const int carveFlowMode = p->opt.carveFlow;      // 2: heights as granules (k_carve_granules), 1: done words (k_carve_flow), 0: rounds
             const bool carveFlow = carveFlowMode != 0;
             if (carveFlow) {
                 launch(p, FAM_CARVE_SETUP, k_carve_setup_cells, gridN, WO_BLOCK, F);
@@ -818,16 +796,17 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 WO_HIP(hipMemsetAsync(p->d_counters + 3, 0, sizeof(int32_t), s));
                 launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
             }
+            int32_t activeTasks = 0;
             {   // dependency lists of the active tasks (once per glacial step)
                 const int32_t active = read_count(p, p->d_counters + 3);
+                activeTasks = active;
                 carveActive += active;
                 if ((int64_t)active > p->carveCap) {
-                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveExpect);
+                    dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveExpect);
                     p->carveCap = (int64_t)active + active / 4 + 1024;
                     p->d_carveDeps = dalloc<int32_t>((size_t)p->carveCap * WO_CARVE_DEPS);
                     p->d_carveDepCnt = dalloc<int32_t>((size_t)p->carveCap); p->d_carveDepPos = dalloc<int32_t>((size_t)p->carveCap);
                     p->d_carveRecs = dalloc<CarveRec>((size_t)p->carveCap); p->d_carveSlotDone = dalloc<int32_t>((size_t)p->carveCap); p->d_carveExpect = dalloc<CarveExpect>((size_t)p->carveCap);
-                    p->d_carvePairs[0] = dalloc<int2>((size_t)p->carveCap); p->d_carvePairs[1] = dalloc<int2>((size_t)p->carveCap);
                 }
                 F.carveDeps = p->d_carveDeps; F.carveDepCnt = p->d_carveDepCnt; F.carveDepPos = p->d_carveDepPos;
                 // the dependency lists (a two-hop walk per task) are for the done-word launch and the rounds; the granule launch waits on the
@@ -838,30 +817,22 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     launch(p, FAM_CARVE_SETUP, k_carve_records, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength,
                            (int32_t)(carveFlowMode == 2 ? 0 : carveFlowMode == 1 ? 2 : 1), (int32_t)1);
             }
-            // rounds over {task, blocker} entries (k_carve_round_pairs); counters as in run_rounds: c[k%3] in, c[(k+1)%3] out
             {
                 int32_t* c = p->d_counters;
-                WO_HIP(hipMemcpyAsync(c + 1, c + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-                WO_HIP(hipMemsetAsync(c, 0, sizeof(int32_t), s));
-                WO_HIP(hipMemsetAsync(c + 2, 0, sizeof(int32_t), s));
-                int32_t count = read_count(p, c + 1);
-                if (count > 0) launch(p, FAM_CARVE_SETUP, k_carve_pairs_init, blocks_for(count), WO_BLOCK, (const int32_t*)p->d_listB, (const int32_t*)(c + 1), p->d_carvePairs[0]);
+                const int32_t count = activeTasks;
                 int64_t k = 1;
-                int cur = 0;
-                // (round 2 also tried all rounds in ONE cooperative launch with a grid barrier: slower, profiles/r02f_persistent_rounds_grid.txt)
-                // default: rounds over the static activation list (k_carve_round_static): every launch covers all active tasks, a
-                // finished one leaves after one load, an open one issues its loads at once; the number of finished tasks is read
-                // back after a burst (first burst: what the previous glacial iteration needed).  WO_CARVE_ROUNDS=lists: the pending
-                // lists of round 2 (k_carve_round_pairs) below.
-                static const bool staticRounds = !(getenv("WO_CARVE_ROUNDS") && std::string(getenv("WO_CARVE_ROUNDS")) == "lists");
-                if (count > 0 && staticRounds && F.carveDeps) {
+                // The one launch (k_carve_granules / k_carve_flow), then — for whatever it leaves, and as the WO_CARVE_FLOW=0 route — rounds
+                // over the static activation list (k_carve_round_static): every launch covers all active tasks, a finished one leaves
+                // after one load, an open one issues its loads at once; the number of finished tasks is read back after a burst.
+                // (Round 2 also tried all rounds in ONE cooperative launch with a grid barrier: slower, profiles/r02f_persistent_rounds_grid.txt.)
+                if (count > 0) {
                     const int32_t active = count;
                     int32_t* done = c + 4;
                     WO_HIP(hipMemsetAsync(done, 0, sizeof(int32_t), s));
                     const int grid = blocks_for(active);
                     // the depth of the carve DAG falls from one glacial iteration to the next (the ice smooths its bed), so the count of
                     // finished tasks is read back every 32 rounds (a read-back costs about as much as three empty rounds)
-                    static const int burst = getenv("WO_CARVE_BURST") ? std::max(1, atoi(getenv("WO_CARVE_BURST"))) : 32;
+                    constexpr int burst = 32;
                     bool allDone = false;
                     if (carveFlow) {
                         // every task in one launch (k_carve_flow); the grid is what is certainly resident at once: the occupancy
@@ -877,10 +848,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                             flowBlocks = std::max(1, std::min(perCu, 8) - 1) * prop.multiProcessorCount;
                         }
                         // WO_CARVE_FLOW_BLOCKS=<n> (test hook, read per step): at most n workgroups, so that every thread takes many tasks in turn
-                        const int blocksNow = getenv("WO_CARVE_FLOW_BLOCKS") ? std::max(1, std::min(flowBlocks, atoi(getenv("WO_CARVE_FLOW_BLOCKS")))) : flowBlocks;
-                        static const int32_t flowWatch = getenv("WO_CARVE_FLOW_WATCH") ? atoi(getenv("WO_CARVE_FLOW_WATCH")) : 1;
-                        static const int32_t flowSleep = getenv("WO_CARVE_FLOW_SLEEP") ? atoi(getenv("WO_CARVE_FLOW_SLEEP")) : 0;
-                        const long long flowBudget = (getenv("WO_CARVE_FLOW_BUDGET_MS") ? atoll(getenv("WO_CARVE_FLOW_BUDGET_MS")) : 200) * 100000ll;   // 100 MHz ticks
+                        const int blocksNow = p->opt.carveFlowBlocks > 0 ? std::max(1, std::min(flowBlocks, p->opt.carveFlowBlocks)) : flowBlocks;
+                        constexpr int32_t flowWatch = 1, flowSleep = 0;
+                        const long long flowBudget = p->opt.carveFlowBudgetMs * 100000ll;   // 100 MHz ticks
                         if (carveFlowMode == 2) {
                             if (!p->d_carveG) p->d_carveG = dalloc<unsigned long long>((size_t)N);
                             launch(p, FAM_CARVE_SETUP, k_carve_expect, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const int32_t*)(c + 3), p->d_carveExpect);
@@ -907,17 +877,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                         if (read_count(p, done) >= active) break;
                         if (k > 4 * (int64_t)p->N + 1024) throw HipError{"carve rounds do not converge"};
                     }
-                    count = 0;
-                }
-                while (count > 0) {
-                    const int grid = blocks_for(count, 2048);
-                    for (int b = 0; b < 16; ++b, ++k) {
-                        launch(p, FAM_CARVE_ROUND, k_carve_round_pairs, grid, WO_BLOCK, F, (const int2*)p->d_carvePairs[cur], (const int32_t*)(c + (k % 3)),
-                               p->d_carvePairs[cur ^ 1], c + ((k + 1) % 3), c + ((k + 2) % 3), (int32_t)k, gCarve, gConv, gStrength);
-                        cur ^= 1;
-                    }
-                    count = read_count(p, c + (k % 3));
-                    if (k > 4 * (int64_t)p->N + 1024) throw HipError{"carve rounds do not converge"};
                 }
                 carveRounds += k - 1;
             }
@@ -930,14 +889,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             Fields F = p->fields();
             F.solveK = K; F.solveM = m; F.solveDt = dt;
             const bool basin = basinSolve && p->patchVersion >= 0;
-            // the receivers pass also leaves the start state of the layout's component search (WO_BASIN_INIT=kernel: k_basin_init does)
-            static const bool basinInitKernel = getenv("WO_BASIN_INIT") && std::string(getenv("WO_BASIN_INIT")) == "kernel";
-            const bool basinJFromReceivers = basin && !basinInitKernel;
+            // the receivers pass also leaves the start state of the layout's component search
+            const bool basinJFromReceivers = basin;
             const bool slotIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;          // land-first mirror: a land cell's Morton slot is its id
             if (basinJFromReceivers) { basin_alloc(p); F.basinJ = p->d_basinJ; F.basinMslot = slotIdentity ? nullptr : p->d_slotOf; }
-            static const bool basinOverlap = !(getenv("WO_BASIN_OVERLAP") && atoi(getenv("WO_BASIN_OVERLAP")) == 0);
-            const char* climbEnv = getenv("WO_FLOW_CLIMB");
-            const int climbCap = climbEnv ? std::max(0, atoi(climbEnv)) : 0x7fffffff;
+            const bool basinOverlap = true;
+            const int climbCap = p->opt.flowClimbCap;
             const bool climbAll = climbCap == 0x7fffffff;
             // three streams: the event lists of the solve (they need the receivers only) are built on a stream of their own beside the flow
             // accumulation (main) and the basin layout (side); the totals pass after the accumulation is a coalesced sweep, because the
@@ -945,7 +902,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             // three kernels at once the climb takes 274 us instead of 200, the events 261 instead of ~90, the layout's scatter 75 instead of
             // 27, and the setup starts at the same moment (profiles/r03bc_*): these "latency-bound" launches do fill the memory pipelines
             // when two of them already run side by side.  Default: k_flow_final after the accumulation.
-            const bool eventsStreamEnv = getenv("WO_FLOW_EVENTS_STREAM") && atoi(getenv("WO_FLOW_EVENTS_STREAM")) != 0;      // read per pass (tests switch it)
+            const bool eventsStreamEnv = p->opt.flowEventsStream;
             const bool eventsStream = eventsStreamEnv && basin && basinOverlap && climbAll && F.ev;
             if (eventsStream) {
                 if (!p->d_lateDonor) { p->d_lateDonor = dalloc<uint8_t>((size_t)N); WO_HIP(hipMemsetAsync(p->d_lateDonor, 0, (size_t)N, s)); }
@@ -965,14 +922,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     // the flow kernels' (a 22 us scatter pass took 108 us beside k_flow_final), so the side stream gets the highest priority
                     int prLeast = 0, prGreatest = 0;
                     WO_HIP(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
-                    static const bool sidePriority = !(getenv("WO_SIDE_PRIORITY") && atoi(getenv("WO_SIDE_PRIORITY")) == 0);
-                    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, sidePriority ? prGreatest : prLeast));
+                    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prGreatest));
                     WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
                 }
                 WO_HIP(hipEventRecord(p->evFork, s));
                 WO_HIP(hipStreamWaitEvent(p->side, p->evFork, 0));
                 p->onSide = true;
-                try { basin_layout(p, basinJFromReceivers, slotIdentity); } catch (...) { p->onSide = false; throw; }
+                try { basin_layout(p, slotIdentity); } catch (...) { p->onSide = false; throw; }
                 p->onSide = false;
                 WO_HIP(hipEventRecord(p->evJoin, p->side));
                 if (eventsStream) {
@@ -999,7 +955,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     int32_t* c = p->d_counters;
                     hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
                     const int32_t* in = p->d_landIdx;
-                    static const int rakeRounds = getenv("WO_FLOW_RAKE") ? std::max(1, atoi(getenv("WO_FLOW_RAKE"))) : WO_FLOW_RAKE_ROUNDS;
+                    constexpr int rakeRounds = WO_FLOW_RAKE_ROUNDS;
                     for (int k = 1; k <= rakeRounds && climbCap == 0; ++k) {
                         int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
                         launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
@@ -1011,13 +967,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 }
                 // pointer doubling on what is left (the cells queued for the next rake round included); 8 rounds per read-back: a
                 // stream synchronisation costs as much as several empty rounds
-                static const int flowBatch = getenv("WO_FLOW_BATCH") ? std::max(1, atoi(getenv("WO_FLOW_BATCH"))) : 8;
+                constexpr int flowBatch = 8;
                 flowRounds += run_rounds(p, p->d_listB, 0, true, flowBatch,
                     [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                         launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
                         launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
                                (const int32_t*)p->d_nj, out, outC, zeroC);
-                    }, getenv("WO_FLOW_NO_HINT") ? nullptr : &flowCountHint);
+                    }, &flowCountHint);
             }
             {
                 Fields Ff = F;
@@ -1029,20 +985,16 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.begin("solve");
             if (basin) {
                 if (basinOverlap && eventsStream) WO_HIP(hipStreamWaitEvent(s, p->evJoin2, 0));
-                if (basinOverlap) WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0)); else basin_layout(p, basinJFromReceivers, slotIdentity);
+                WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0));
                 F.slotOf = p->d_basinSlot;
                 F.solveLean = 1;
                 // (the outputs' tags were cleared by k_flow_final: one coalesced sweep instead of one scattered 16-byte write per task)
             }
-            // WO_SETUP_BATCHED=0: the setup that decides load by load (solve_setup_cell) instead of k_solve_setup_batched
-            static const bool setupBatched = !(getenv("WO_SETUP_BATCHED") && atoi(getenv("WO_SETUP_BATCHED")) == 0);
             bool countersCleared = false, solveFinals = false;
-            if (setupBatched && F.ev) {
+            if (F.ev) {
                 // the solve launch writes the final heights itself (SolveTask finality flags) when its result is not looked at pass by pass and
-                // it is the cooperative kernel: no k_solve_final then.  WO_SOLVE_FINALS=0: the final pass as before.
-                static const bool finalsEnv = !(getenv("WO_SOLVE_FINALS") && atoi(getenv("WO_SOLVE_FINALS")) == 0);
-                static const int coopWavesEnv = getenv("WO_BASIN_WAVES") ? atoi(getenv("WO_BASIN_WAVES")) : 4;
-                solveFinals = finalsEnv && basin && !checkEveryPass && coopWavesEnv >= 2;
+                // no k_solve_final then
+                solveFinals = basin && !checkEveryPass;
                 F.solveFinals = solveFinals ? 1 : 0;
                 // (with the basin solve the setup launch also clears the counters of the solve launch: run_solve_patches' countersCleared)
                 int32_t* zA = basin ? p->d_patchPending : nullptr; const int32_t nA = basin ? p->numPatches : 0;
@@ -1056,7 +1008,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared, !checkEveryPass);
                 if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
-                if (getenv("WO_SOLVE_TRACE")) fprintf(stderr, "iter %d: %lld patch launches\n", iter, (long long)r);
             } else {
                 const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
                 solveRounds += r; maxSolve = std::max(maxSolve, r);
@@ -1185,8 +1136,35 @@ using namespace wo;
     } catch (const HipError& e) { set_error(std::string(fn) + ": " + e.msg); return 2; } \
       catch (const std::exception& e) { set_error(std::string(fn) + ": " + e.what()); return 3; }
 
+Options Options::from_env() {
+    auto str = [](const char* n) { const char* v = std::getenv(n); return std::string(v ? v : ""); };
+    auto on = [](const char* n) { const char* v = std::getenv(n); return v && std::atoi(v) != 0; };
+    auto set = [](const char* n) { return std::getenv(n) != nullptr; };
+    Options o;
+    o.layoutIndex = str("WO_LAYOUT") == "index";
+    o.sortLibrary = str("WO_SORT") == "hipcub";
+    o.basinBarrierKernel = str("WO_BASIN_KERNEL") == "barrier";
+    o.basinStats = on("WO_BASIN_STATS");
+    o.basinScramble = on("WO_BASIN_SCRAMBLE");
+    o.tileLds = on("WO_TILE_LDS");
+    o.noSolvePatch = set("WO_NO_SOLVE_PATCH");
+    o.noEventLists = set("WO_NO_EVENT_LISTS");
+    if (set("WO_FLOW_CLIMB")) o.flowClimbCap = std::max(0, std::atoi(std::getenv("WO_FLOW_CLIMB")));
+    o.flowEventsStream = on("WO_FLOW_EVENTS_STREAM");
+    o.iceRounds = on("WO_ICE_ROUNDS");
+    if (set("WO_CARVE_FLOW")) o.carveFlow = std::atoi(std::getenv("WO_CARVE_FLOW"));
+    if (set("WO_CARVE_FLOW_BUDGET_MS")) o.carveFlowBudgetMs = std::atoll(std::getenv("WO_CARVE_FLOW_BUDGET_MS"));
+    if (set("WO_CARVE_FLOW_BLOCKS")) o.carveFlowBlocks = std::max(1, std::atoi(std::getenv("WO_CARVE_FLOW_BLOCKS")));
+    o.floodDevice = str("WO_FLOOD") == "device";
+    o.floodTiesById = str("WO_FLOOD_TIES") == "id";
+    o.floodTiming = set("WO_FLOOD_TIMING");
+    o.stageTimingAll = str("WO_STAGE_TIMING") == "all";
+    return o;
+}
+
 static bool check_planet(wo_planet* p, const char* fn) {
     if (!p) { set_error(std::string(fn) + ": null planet handle"); return false; }
+    p->opt = Options::from_env();
     hipError_t e = hipSetDevice(p->ctx->device);
     if (e != hipSuccess) { set_error(std::string(fn) + ": hipSetDevice failed: " + hipGetErrorString(e)); return false; }
     return true;
@@ -1199,8 +1177,7 @@ static bool check_planet(wo_planet* p, const char* fn) {
 // that finishes pending tasks with k_solve_patch launches.  WO_SOLVE_CHECK=pass: always that form.
 static void erode_composite_checked(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talus,
                                     double kThermal, int32_t gIters, double gStrength) {
-    static const bool everyPass = getenv("WO_SOLVE_CHECK") && std::string(getenv("WO_SOLVE_CHECK")) == "pass";
-    if (everyPass || hIters <= 0) { erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true); return; }
+    if (hIters <= 0) { erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true); return; }
     hipStream_t s = p->ctx->stream;
     if (!p->d_redoE) p->d_redoE = dalloc<float>((size_t)p->N);
     if (!p->d_pendingEver) p->d_pendingEver = dalloc<int32_t>(16);
@@ -1330,7 +1307,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_carvePairs[0]); dfree(p->d_carvePairs[1]); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

@@ -66,18 +66,67 @@ void sort_by_level(wo_planet* p) {
     WO_HIP(hipStreamSynchronize(s));
 }
 
-// the active carve tasks in landCells order: the cells of the current order whose arank is set, order kept (stable selection)
-struct CarveActive {
-    const int32_t* arank;
-    __device__ bool operator()(const int32_t& r) const { return arank[r] != WO_NOT_DONE; }
-};
+// The active carve tasks in landCells order: the cells of the current order whose arank is set, order kept (stable selection).
+// In-tree compaction, three launches: flagged entries per tile of 2 048, one workgroup scans the tile counts, every tile writes
+// its flagged entries behind the tiles before it (a thread takes 8 consecutive entries, so the order inside a tile is kept too).
+constexpr int WO_SEL_PER_THREAD = 8, WO_SEL_TILE = WO_BLOCK * WO_SEL_PER_THREAD;
+__device__ inline int32_t block_exclusive_scan(int32_t v, int32_t* s_wave, int32_t& total) {      // WO_BLOCK threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < WO_BLOCK / 64; ++w) { const int32_t c = s_wave[w]; if (w < wave) before += c; tot += c; }
+    total = tot;
+    __syncthreads();
+    return before + incl - v;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_sel_count(const int32_t* __restrict__ land, const int32_t* __restrict__ arank, int32_t L, int32_t* __restrict__ tileCnt) {
+    __shared__ int32_t s_wave[WO_BLOCK / 64];
+    const int32_t base = blockIdx.x * WO_SEL_TILE + threadIdx.x * WO_SEL_PER_THREAD;
+    int32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < WO_SEL_PER_THREAD; ++q) { const int32_t i = base + q; if (i < L && arank[land[i]] != WO_NOT_DONE) ++c; }
+    int32_t total;
+    (void)block_exclusive_scan(c, s_wave, total);
+    if (threadIdx.x == 0) tileCnt[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_sel_scan(int32_t* tileCnt, int32_t nTiles, int32_t* outCount) {      // one workgroup
+    __shared__ int32_t s_wave[WO_BLOCK / 64];
+    int32_t run = 0;
+    for (int32_t b0 = 0; b0 < nTiles; b0 += WO_BLOCK) {
+        const int32_t i = b0 + threadIdx.x;
+        const int32_t v = i < nTiles ? tileCnt[i] : 0;
+        int32_t total;
+        const int32_t ex = block_exclusive_scan(v, s_wave, total);
+        if (i < nTiles) tileCnt[i] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) *outCount = run;
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_sel_scatter(const int32_t* __restrict__ land, const int32_t* __restrict__ arank, int32_t L, const int32_t* __restrict__ tileStart, int32_t* __restrict__ out) {
+    __shared__ int32_t s_wave[WO_BLOCK / 64];
+    const int32_t base = blockIdx.x * WO_SEL_TILE + threadIdx.x * WO_SEL_PER_THREAD;
+    int32_t cell[WO_SEL_PER_THREAD]; bool on[WO_SEL_PER_THREAD];
+    int32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < WO_SEL_PER_THREAD; ++q) { const int32_t i = base + q; cell[q] = i < L ? land[i] : 0; on[q] = i < L && arank[cell[q]] != WO_NOT_DONE; c += on[q] ? 1 : 0; }
+    int32_t total;
+    int32_t at = tileStart[blockIdx.x] + block_exclusive_scan(c, s_wave, total);
+#pragma unroll
+    for (int q = 0; q < WO_SEL_PER_THREAD; ++q) if (on[q]) out[at++] = cell[q];
+}
 void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount) {
-    size_t bytes = p->sortTempBytes;
-    hipStream_t s = p->ctx->stream;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
-    WO_HIP(hipcub::DeviceSelect::If(p->d_sortTemp, bytes, (const int32_t*)p->d_land[p->landCur], out, outCount, p->L, CarveActive{arank}, s));
-    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_CARVE_SETUP, a, b}); }
+    const int32_t L = p->L;
+    const int nTiles = (int)(((int64_t)L + WO_SEL_TILE - 1) / WO_SEL_TILE);
+    int32_t* tileCnt = reinterpret_cast<int32_t*>(p->d_sortTemp);
+    const int32_t* land = p->d_land[p->landCur];
+    launch(p, FAM_CARVE_SETUP, k_sel_count, nTiles, WO_BLOCK, land, arank, L, tileCnt);
+    launch(p, FAM_CARVE_SETUP, k_sel_scan, 1, WO_BLOCK, tileCnt, (int32_t)nTiles, outCount);
+    launch(p, FAM_CARVE_SETUP, k_sel_scatter, nTiles, WO_BLOCK, land, arank, L, (const int32_t*)tileCnt, out);
 }
 
 size_t sort_temp_bytes(int32_t n) {
@@ -88,19 +137,8 @@ size_t sort_temp_bytes(int32_t n) {
     size_t bytes2 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes2, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr,
                                              (int32_t*)nullptr, n, 0, WO_LEVEL_BITS, nullptr);
-    size_t bytes3 = 0;
-    (void)hipcub::DeviceSelect::If(nullptr, bytes3, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, n, CarveActive{nullptr}, nullptr);
+    const size_t bytes3 = ((size_t)n / WO_SEL_TILE + 2) * sizeof(int32_t);      // select_active_by_rank: tile counts
     return std::max(bytes, std::max(bytes2, bytes3));
-}
-
-// diagnostic (WO_SORT_STATS=1): how far does a cell move in the order from one sort to the next?  rank[] still holds the previous
-// positions when this runs.  hist[b]: cells whose displacement d has floor(log2(d + 1)) == b; hist[32]: the maximum.
-__global__ __launch_bounds__(WO_BLOCK) void k_sort_displacement(const int32_t* __restrict__ land, const int32_t* __restrict__ rankOld, int32_t L, unsigned long long* hist) {
-    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < L; i += gridDim.x * blockDim.x) {
-        const int32_t d = abs(i - rankOld[land[i]]);
-        atomicAdd(&hist[31 - __clz((uint32_t)d + 1u)], 1ull);
-        atomicMax(&hist[32], (unsigned long long)d);
-    }
 }
 
 void sort_land_by_elevation(wo_planet* p) {
@@ -111,15 +149,14 @@ void sort_land_by_elevation(wo_planet* p) {
     hipStream_t s = p->ctx->stream;
     // WO_SORT=hipcub: the library sort + the rank scatter of earlier builds; default: the in-tree sort (radix.hip), whose last pass
     // also writes rank[cell] = position
-    const bool library = getenv("WO_SORT") && std::string(getenv("WO_SORT")) == "hipcub";     // read per sort (tests switch it)
-    static const bool stats0 = getenv("WO_SORT_STATS") != nullptr;
+    const bool library = p->opt.sortLibrary;
     bool rankWritten = false;
     if (!library) {
         uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
         int32_t* const vb[2] = {p->d_land[cur], p->d_land[cur ^ 1]};
-        const int r = radix_sort_pairs(p, FAM_SORT_RADIX, kb, vb, L, 0, 32, stats0 ? (int32_t*)nullptr : p->d_rank, radix_scratch(p, 0), p->N, p->rsFlip[0]);
+        const int r = radix_sort_pairs(p, FAM_SORT_RADIX, kb, vb, L, 0, 32, p->d_rank, radix_scratch(p, 0), p->N, p->rsFlip[0]);
         p->landCur = r == 0 ? cur : (cur ^ 1);
-        rankWritten = !stats0;
+        rankWritten = true;
     } else {
         hipcub::DoubleBuffer<uint32_t> k(p->d_keys[0], p->d_keys[1]);
         hipcub::DoubleBuffer<int32_t> v(p->d_land[cur], p->d_land[cur ^ 1]);
@@ -131,17 +168,6 @@ void sort_land_by_elevation(wo_planet* p) {
         WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, k, v, L, 0, 32, s));
         if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_SORT_RADIX, a, b}); }
         p->landCur = (v.Current() == p->d_land[cur]) ? cur : (cur ^ 1);
-    }
-    static const bool stats = getenv("WO_SORT_STATS") != nullptr;
-    if (stats) {
-        unsigned long long* d_h = nullptr; unsigned long long h[33];
-        WO_HIP(hipMalloc((void**)&d_h, sizeof(h))); WO_HIP(hipMemsetAsync(d_h, 0, sizeof(h), s));
-        hipLaunchKernelGGL(k_sort_displacement, dim3(blocks_for(L, 4096)), dim3(WO_BLOCK), 0, s, (const int32_t*)p->d_land[p->landCur], (const int32_t*)p->d_rank, L, d_h);
-        WO_HIP(hipMemcpyAsync(h, d_h, sizeof(h), hipMemcpyDeviceToHost, s)); WO_HIP(hipStreamSynchronize(s)); WO_HIP(hipFree(d_h));
-        unsigned long long moved = 0; for (int b = 1; b < 32; ++b) moved += h[b];
-        fprintf(stderr, "[sort] displacement vs the previous order: %llu of %d cells moved, max %llu; cells by floor(log2(d+1)):", moved, L, h[32]);
-        for (int b = 0; b < 24; ++b) fprintf(stderr, " %llu", h[b]);
-        fprintf(stderr, "\n");
     }
     if (!rankWritten) launch(p, FAM_RANK, k_rank_scatter, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_land[p->landCur], p->d_rank, L);
 }

@@ -602,9 +602,9 @@ def test_decomposed_shares_with_flood_exchange_small(TP, oracle):
     assert stats[0]["flood_exchange_calls"] == 2
 
 
-@pytest.mark.parametrize("seed", [2, 3])
+@pytest.mark.parametrize("seed", [2, 3, 4, 5, 6, 7, 8, 9])
 def test_config5_seeds_checksum(TP, seed):
-    """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 and 3, 20 composite iterations (1 glacial),
+    """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 .. 9, 20 composite iterations (1 glacial),
     CRC == the oracle's (seed 1 at the full 200 iterations: test_config3_checksum_of_the_benched_field)."""
     stats = _checksum_case(TP, f"10000000_seed{seed}_iters20", 10_000_000, seed, 20, 1)
     assert stats["flood_host_serial_pass1"] == 0
@@ -775,4 +775,33 @@ def test_sort_routes_agree_under_ties(TP, oracle, monkeypatch):
     monkeypatch.setenv("WO_SORT", "hipcub")
     got = eq.copy(); pl.erode_composite(got, oc, *args)
     assert np.array_equal(got, ref), int((got != ref).sum())
+    pl.close()
+
+
+def test_solve_kernel_and_tile_staging_routes_agree(TP, oracle, monkeypatch):
+    """Two routes kept beside the default: WO_BASIN_KERNEL=barrier (k_solve_coop: the basin walk with one barrier per super-chunk;
+    default k_solve_flowing lets a wave run ahead) and WO_TILE_LDS=1 (north_star's "neighbour cells staged into LDS": the
+    neighbour window of a workgroup's tile copied into LDS for the receivers and thermal passes; measured no faster, off by
+    default).  Same dataflow, same operations: every route must give the oracle's field bit for bit, ties included."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(300000, 0.75, 11)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(11)
+    e0 = pl.download()
+    eq = (np.round(e0 * 64) / 64).astype(np.float32)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    args = (10, 3e-4, 0.5, 1.0, 10, 1.16, 0.015, 2, 0.5)
+    for field in (e0, eq):
+        oc = (field <= 0).astype(np.uint8)
+        ref = oracle.erode_composite(om, field, xyz, oc, *args, nd)
+        for env in ({}, {"WO_BASIN_KERNEL": "barrier"}, {"WO_TILE_LDS": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = field.copy()
+            pl.erode_composite(got, oc, *args)
+            st = pl.last_erode_stats()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert np.array_equal(got, ref), (env, int((got != ref).sum()))
+            assert st["solve_basin_passes"] == 10 and st["solve_basin_passes_with_leftovers"] == 0, (env, st)
     pl.close()
