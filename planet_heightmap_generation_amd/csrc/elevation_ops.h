@@ -164,137 +164,137 @@ WO_HD inline bool back_arc_effect(const ElevFields& F, const ElevParams& Q, int3
 WO_HD inline float elevation_main_cell(const ElevFields& F, const ElevParams& Q, const PlateTable& T, int32_t r,
                                        NoiseTab noise, NoiseTab riftNoise, NoiseTab foldNoise) {
     const bool dl = F.dl != nullptr;
-    const bool isOceanPlate = F.isOcean[r] != 0;
+    const bool ocean_plate = F.isOcean[r] != 0;
     const double eps = 1e-3, warpScale = 0.4, S = Q.scaleFactor, noiseMag = Q.noiseMag;
-    const double sfAsym = F.subduct[r];
-    const double asymmetry = 1.0 + (sfAsym - 0.5) * 0.8;
-    const double a = (double)F.distMountain[r] * asymmetry + eps;
+    const double sub_f0 = F.subduct[r];
+    const double slab_skew = 1.0 + (sub_f0 - 0.5) * 0.8;
+    const double a = (double)F.distMountain[r] * slab_skew + eps;
     const double b = (double)F.distOcean[r] + eps;
     const double c = (double)F.distCoastline[r] + eps;
-    const double BASE_SCALE = 0.6;
+    const double kBaseScale = 0.6;
     float e;
-    if (a == INFINITY && b == INFINITY) e = (float)(0.1 * BASE_SCALE);
-    else e = (float)((1 / a - 1 / b) / (1 / a + 1 / b + 1 / c) * BASE_SCALE);
+    if (a == INFINITY && b == INFINITY) e = (float)(0.1 * kBaseScale);
+    else e = (float)((1 / a - 1 / b) / (1 / a + 1 / b + 1 / c) * kBaseScale);
     if (dl) EL_DL(DL_BASE) = e;
 
-    const double stressNorm = js_min(1, (double)F.stress[r] / Q.maxStress);
+    const double stress_rel = js_min(1, (double)F.stress[r] / Q.maxStress);
     const int32_t btype = F.btype[r];
     const double x = F.xyz[3 * r], y = F.xyz[3 * r + 1], z = F.xyz[3 * r + 2];
     const double wx = x + warpScale * fbm(noise.P, noise.M, x + 5.3, y + 1.7, z + 3.1, Q.warpOctaves);
     const double wy = y + warpScale * fbm(noise.P, noise.M, x + 8.1, y + 2.9, z + 7.3, Q.warpOctaves);
     const double wz = z + warpScale * fbm(noise.P, noise.M, x + 1.4, y + 6.2, z + 4.8, Q.warpOctaves);
 
-    const double rawOro = noise3d(noise.P, noise.M, x * 1.5 + 33.7, y * 1.5 + 11.2, z * 1.5 + 22.9);
-    const double shaped = rawOro >= 0 ? sqrt(rawOro) : -sqrt(-rawOro);
-    const double orogenicPower = js_max(0, js_min(1, 0.5 + 0.5 * shaped));
-    if (dl) EL_DL(DL_ORO) = (float)(orogenicPower - 0.5);
+    const double oro_raw = noise3d(noise.P, noise.M, x * 1.5 + 33.7, y * 1.5 + 11.2, z * 1.5 + 22.9);
+    const double oro_shaped = oro_raw >= 0 ? sqrt(oro_raw) : -sqrt(-oro_raw);
+    const double oro_gain = js_max(0, js_min(1, 0.5 + 0.5 * oro_shaped));
+    if (dl) EL_DL(DL_ORO) = (float)(oro_gain - 0.5);
 
-    if (!isOceanPlate) {
+    if (!ocean_plate) {
         const double sf = F.subduct[r];
-        const float elevBefore = e;
+        const float e_prev = e;
         if (sf > 0.5 && e > 0) {
-            const double suppression = (sf - 0.5) * 2;
-            e = (float)((double)e * (1 - suppression * 0.42));
+            const double slab_damp = (sf - 0.5) * 2;
+            e = (float)((double)e * (1 - slab_damp * 0.42));
         }
-        if (stressNorm > 0.01) {
-            const double stressMag = stressNorm * stressNorm * 0.55 * orogenicPower;
-            const double uplift = stressMag * (1 - sf);
-            const double depress = stressMag * 0.4 * sf;
-            const double heightVar = 0.60 + 0.8 * fbm(noise.P, noise.M, x * 8 + 13.7, y * 8 + 9.2, z * 8 + 4.5, 3);
-            EL_ADD(e, (uplift - depress) * heightVar);
+        if (stress_rel > 0.01) {
+            const double stress_amp = stress_rel * stress_rel * 0.55 * oro_gain;
+            const double uplift = stress_amp * (1 - sf);
+            const double sag = stress_amp * 0.4 * sf;
+            const double relief_var = 0.60 + 0.8 * fbm(noise.P, noise.M, x * 8 + 13.7, y * 8 + 9.2, z * 8 + 4.5, 3);
+            EL_ADD(e, (uplift - sag) * relief_var);
         }
-        if (stressNorm > 0 && stressNorm < 0.10) {
-            const double forelandT = stressNorm / 0.10;
-            e = (float)((double)e - 0.06 * (1 - forelandT));
+        if (stress_rel > 0 && stress_rel < 0.10) {
+            const double foreland_u = stress_rel / 0.10;
+            e = (float)((double)e - 0.06 * (1 - foreland_u));
         }
         {   // rift graben (:698-727)
             const double rd = F.riftDist[r];
             if (rd != INFINITY) {
-                const double floorEnd = js_max(1, js_round(1.5 * S));
-                const double shoulderEnd = js_max(2, js_round(2.5 * S));
-                double riftEffect = 0;
+                const double floor_edge = js_max(1, js_round(1.5 * S));
+                const double shoulder_edge = js_max(2, js_round(2.5 * S));
+                double rift_drop = 0;
                 if (rd <= 0.5) {
-                    riftEffect = -0.15;
-                    riftEffect += ridged_fbm(riftNoise.P, riftNoise.M, x * 8, y * 8, z * 8, 3) * 0.04;
-                } else if (rd <= floorEnd) {
-                    const double t = rd / floorEnd;
-                    riftEffect = -0.12 * (1 - t * 0.3);
-                    riftEffect += ridged_fbm(riftNoise.P, riftNoise.M, x * 8, y * 8, z * 8, 3) * 0.03 * (1 - t);
-                } else if (rd <= shoulderEnd) {
-                    const double t = (rd - floorEnd) / (shoulderEnd - floorEnd);
-                    riftEffect = 0.03 * (1 - t);
-                } else if (Q.riftHalfWidth > shoulderEnd) {
-                    const double t = (rd - shoulderEnd) / (Q.riftHalfWidth - shoulderEnd);
+                    rift_drop = -0.15;
+                    rift_drop += ridged_fbm(riftNoise.P, riftNoise.M, x * 8, y * 8, z * 8, 3) * 0.04;
+                } else if (rd <= floor_edge) {
+                    const double t = rd / floor_edge;
+                    rift_drop = -0.12 * (1 - t * 0.3);
+                    rift_drop += ridged_fbm(riftNoise.P, riftNoise.M, x * 8, y * 8, z * 8, 3) * 0.03 * (1 - t);
+                } else if (rd <= shoulder_edge) {
+                    const double t = (rd - floor_edge) / (shoulder_edge - floor_edge);
+                    rift_drop = 0.03 * (1 - t);
+                } else if (Q.riftHalfWidth > shoulder_edge) {
+                    const double t = (rd - shoulder_edge) / (Q.riftHalfWidth - shoulder_edge);
                     const double fadeT = js_min(1, t);
                     const double fade = fadeT * fadeT * (3 - 2 * fadeT);
-                    riftEffect = 0.03 * (1 - fade) * 0.2;
+                    rift_drop = 0.03 * (1 - fade) * 0.2;
                 }
-                EL_ADD(e, riftEffect);
+                EL_ADD(e, rift_drop);
             }
         }
         {   // back-arc
-            double baEffect;
-            if (back_arc_effect(F, Q, r, baEffect)) { EL_ADD(e, baEffect); if (dl) EL_DL(DL_BACKARC) = (float)baEffect; }
+            double backarc_add;
+            if (back_arc_effect(F, Q, r, backarc_add)) { EL_ADD(e, backarc_add); if (dl) EL_DL(DL_BACKARC) = (float)backarc_add; }
         }
-        if (dl) EL_DL(DL_TECTONIC) = (float)((double)e - (double)elevBefore);
+        if (dl) EL_DL(DL_TECTONIC) = (float)((double)e - (double)e_prev);
 
         const double dMtn = F.distMountain[r];
-        const double rawProximity = (dMtn == INFINITY || dMtn >= Q.tectonicReach) ? 0 : (1 - dMtn / Q.tectonicReach);
-        const double tectonicActivity = js_max(stressNorm, rawProximity * rawProximity);
-        if (dl) EL_DL(DL_TECACT) = (float)tectonicActivity;
+        const double near_raw = (dMtn == INFINITY || dMtn >= Q.tectonicReach) ? 0 : (1 - dMtn / Q.tectonicReach);
+        const double tect_level = js_max(stress_rel, near_raw * near_raw);
+        if (dl) EL_DL(DL_TECACT) = (float)tect_level;
 
         {   // fold ridges (:770-799)
             const int32_t pid = F.plate[r];
-            const double foldActivity = tectonicActivity * tectonicActivity;
-            if (pid >= 0 && pid < T.numIds && T.hasVec[pid] && foldActivity > 0.01) {
+            const double fold_level = tect_level * tect_level;
+            if (pid >= 0 && pid < T.numIds && T.hasVec[pid] && fold_level > 0.01) {
                 const double ppx = T.pole[3 * pid], ppy = T.pole[3 * pid + 1], ppz = T.pole[3 * pid + 2];
                 const double u = x * ppx + y * ppy + z * ppz;
-                const double phaseWarp = fbm(foldNoise.P, foldNoise.M, x * 3 + 55.3, y * 3 + 33.7, z * 3 + 17.2, 2) * 0.08;
-                const double phase = (u + phaseWarp) * 30 * EL_PI;
+                const double phase_bend = fbm(foldNoise.P, foldNoise.M, x * 3 + 55.3, y * 3 + 33.7, z * 3 + 17.2, 2) * 0.08;
+                const double phase = (u + phase_bend) * 30 * EL_PI;
                 const double ridge = 1 - fabs(sin(phase));
-                const double foldCentered = ridge - 0.36;
-                const double ampMod = 0.6 + 0.4 * fbm(foldNoise.P, foldNoise.M, x * 4 + 88.1, y * 4 + 62.3, z * 4 + 41.7, 2);
-                const double elevBoost = 1 + 4 * js_max(0, (double)e);
-                const double foldAmp = foldActivity * js_max(0, 1 - sf * 1.5) * noiseMag * 0.8 * elevBoost;
-                const double foldContrib = foldCentered * foldAmp * ampMod;
-                EL_ADD(e, foldContrib);
-                if (dl) EL_DL(DL_FOLD) = (float)foldContrib;
+                const double fold_mid = ridge - 0.36;
+                const double amp_scale = 0.6 + 0.4 * fbm(foldNoise.P, foldNoise.M, x * 4 + 88.1, y * 4 + 62.3, z * 4 + 41.7, 2);
+                const double e_gain = 1 + 4 * js_max(0, (double)e);
+                const double fold_gain = fold_level * js_max(0, 1 - sf * 1.5) * noiseMag * 0.8 * e_gain;
+                const double fold_add = fold_mid * fold_gain * amp_scale;
+                EL_ADD(e, fold_add);
+                if (dl) EL_DL(DL_FOLD) = (float)fold_add;
             }
         }
-        const bool isPlateauZone = sf < 0.45 && dMtn != INFINITY && dMtn > Q.plateauStart;
-        const double blend = js_min(1, stressNorm * 3);
-        const double smoothNoise = fbm(noise.P, noise.M, wx, wy, wz) * noiseMag;
-        const double ridgedNoise = ridged_fbm(noise.P, noise.M, wx, wy, wz) * noiseMag * 1.5;
-        const double noiseVal = smoothNoise * (1 - blend) + ridgedNoise * blend;
-        const double detailNoise = fbm(noise.P, noise.M, wx * 4 + 22.1, wy * 4 + 6.8, wz * 4 + 15.4, 4, 0.5) * noiseMag * 0.5;
-        const double noiseActivity = js_min(1, stressNorm * 4);
-        const double plateauSuppress = isPlateauZone ? js_max(0.30, 1 - tectonicActivity * 0.60) : 1.0;
-        const double noiseScale = (0.25 + 0.75 * noiseActivity) * plateauSuppress;
-        const double fineNoise = fbm(noise.P, noise.M, wx * 8 + 41.7, wy * 8 + 13.2, wz * 8 + 27.9, 3, 0.5) * noiseMag * 0.25;
-        const double fineScale = sqrt(noiseScale);
-        const double totalNoise = (noiseVal + detailNoise) * noiseScale + fineNoise * fineScale;
-        EL_ADD(e, totalNoise);
-        float dlNoise = (float)totalNoise;
+        const bool on_plateau = sf < 0.45 && dMtn != INFINITY && dMtn > Q.plateauStart;
+        const double blend = js_min(1, stress_rel * 3);
+        const double noise_smooth = fbm(noise.P, noise.M, wx, wy, wz) * noiseMag;
+        const double ridged_raw = ridged_fbm(noise.P, noise.M, wx, wy, wz) * noiseMag * 1.5;
+        const double noise_raw = noise_smooth * (1 - blend) + ridged_raw * blend;
+        const double noise_detail = fbm(noise.P, noise.M, wx * 4 + 22.1, wy * 4 + 6.8, wz * 4 + 15.4, 4, 0.5) * noiseMag * 0.5;
+        const double noise_level = js_min(1, stress_rel * 4);
+        const double plateau_damp = on_plateau ? js_max(0.30, 1 - tect_level * 0.60) : 1.0;
+        const double noise_freq = (0.25 + 0.75 * noise_level) * plateau_damp;
+        const double noise_fine = fbm(noise.P, noise.M, wx * 8 + 41.7, wy * 8 + 13.2, wz * 8 + 27.9, 3, 0.5) * noiseMag * 0.25;
+        const double fine_freq = sqrt(noise_freq);
+        const double noise_sum = (noise_raw + noise_detail) * noise_freq + noise_fine * fine_freq;
+        EL_ADD(e, noise_sum);
+        float dlNoise = (float)noise_sum;
         {   // dissection (:829-842)
-            const double currentElev = e;
-            if (currentElev > 0.12) {
-                const double elevExcess = currentElev - 0.12;
-                const double dissectVal = fbm(noise.P, noise.M, wx * 16 + 71.3, wy * 16 + 44.8, wz * 16 + 29.1, 3, 0.5);
-                const double dissectAmp = sqrt(elevExcess) * stressNorm * noiseMag * 0.4;
-                const double dissectContrib = dissectVal * dissectAmp;
-                EL_ADD(e, dissectContrib);
-                EL_ADD(dlNoise, dissectContrib);
+            const double e_now = e;
+            if (e_now > 0.12) {
+                const double e_over = e_now - 0.12;
+                const double incise_raw = fbm(noise.P, noise.M, wx * 16 + 71.3, wy * 16 + 44.8, wz * 16 + 29.1, 3, 0.5);
+                const double incise_amp = sqrt(e_over) * stress_rel * noiseMag * 0.4;
+                const double incise_add = incise_raw * incise_amp;
+                EL_ADD(e, incise_add);
+                EL_ADD(dlNoise, incise_add);
             }
         }
         {   // summits (:848-863): ridgedFbm(x, y, z, 3, 0.5) -> lacunarity 0.5, as written in the reference
-            const double currentElev = e;
-            if (currentElev > 0.65 && stressNorm > 0.2) {
-                const double excess = currentElev - 0.65;
-                const double peakNoise = ridged_fbm(noise.P, noise.M, wx * 24 + 91.3, wy * 24 + 55.7, wz * 24 + 38.2, 3, 0.5);
-                const double spike = js_max(0, peakNoise - 0.45);
-                const double peakContrib = spike * excess * stressNorm * 1.2;
-                EL_ADD(e, peakContrib);
-                EL_ADD(dlNoise, peakContrib);
+            const double e_now = e;
+            if (e_now > 0.65 && stress_rel > 0.2) {
+                const double excess = e_now - 0.65;
+                const double peak_raw = ridged_fbm(noise.P, noise.M, wx * 24 + 91.3, wy * 24 + 55.7, wz * 24 + 38.2, 3, 0.5);
+                const double spike = js_max(0, peak_raw - 0.45);
+                const double peak_add = spike * excess * stress_rel * 1.2;
+                EL_ADD(e, peak_add);
+                EL_ADD(dlNoise, peak_add);
             }
         }
         if (dl) EL_DL(DL_NOISE) = dlNoise;
@@ -305,26 +305,26 @@ WO_HD inline float elevation_main_cell(const ElevFields& F, const ElevParams& Q,
             const double sDown = tDown * tDown * (3 - 2 * tDown);
             const double tUp = js_min(lcd / (Q.interiorBand * 0.4), 1);
             const double sUp = tUp * tUp * (3 - 2 * tUp);
-            const double interiorUplift = 0.06 + tectonicActivity * 0.16;
-            const double baseBias = -0.08 * (1 - sDown) + interiorUplift * sUp;
+            const double craton_lift = 0.06 + tect_level * 0.16;
+            const double base_shift = -0.08 * (1 - sDown) + craton_lift * sUp;
             const double mod = 1.0 + 0.2 * fbm(noise.P, noise.M, x * 2 + 19.3, y * 2 + 7.6, z * 2 + 13.1, 2);
-            const double bias = baseBias * mod;
+            const double bias = base_shift * mod;
             EL_ADD(e, bias);
             dlInterior = (float)bias;
         }
-        if (isPlateauZone && tectonicActivity > 0.1) {
-            const double plateauBoost = 0.025 * tectonicActivity * (1 - sf);
-            EL_ADD(e, plateauBoost);
-            EL_ADD(dlInterior, plateauBoost);
+        if (on_plateau && tect_level > 0.1) {
+            const double plateau_gain = 0.025 * tect_level * (1 - sf);
+            EL_ADD(e, plateau_gain);
+            EL_ADD(dlInterior, plateau_gain);
         }
         if (dl) EL_DL(DL_INTERIOR) = dlInterior;
     } else {
         const double dc = F.distCoast[r];
-        double oceanBase;
-        if (dc < 5) oceanBase = -0.04 - 0.06 * (dc / 5);
-        else if (dc < 12) oceanBase = -0.10 - 0.25 * ((dc - 5) / 7);
-        else oceanBase = -0.35 + fbm(noise.P, noise.M, x * 2, y * 2, z * 2, 3) * 0.03;
-        e = (float)js_min((double)e, oceanBase);
+        double abyss_base;
+        if (dc < 5) abyss_base = -0.04 - 0.06 * (dc / 5);
+        else if (dc < 12) abyss_base = -0.10 - 0.25 * ((dc - 5) / 7);
+        else abyss_base = -0.35 + fbm(noise.P, noise.M, x * 2, y * 2, z * 2, 3) * 0.03;
+        e = (float)js_min((double)e, abyss_base);
         if (dl) EL_DL(DL_OCEAN) = e;
         if (dl) {
             float mg = F.coastConvergent[r] == 1 ? 0.8f : 0.2f;
@@ -332,29 +332,29 @@ WO_HD inline float elevation_main_cell(const ElevFields& F, const ElevParams& Q,
             if (F.fractureDist[r] != INFINITY && F.fractureDist[r] <= Q.fractureHalfWidth) mg = -0.5f;
             EL_DL(DL_MARGINS) = mg;
         }
-        const float elevBeforeOcTec = e;
+        const float e_prev_oc = e;
         const double rd = F.ridgeDist[r];
         if (rd != INFINITY && rd <= Q.ridgeHalfWidth) {
             const double t = rd / Q.ridgeHalfWidth;
-            const double ridgeFade = (1 - t) * (1 - t);
-            const double ridgeNoise = ridged_fbm(noise.P, noise.M, x * 3, y * 3, z * 3, 4);
-            const double ridgeUplift = (0.12 * ridgeNoise + 0.06) * ridgeFade;
-            EL_ADD(e, ridgeUplift);
+            const double ridge_taper = (1 - t) * (1 - t);
+            const double ridge_raw = ridged_fbm(noise.P, noise.M, x * 3, y * 3, z * 3, 4);
+            const double ridge_lift = (0.12 * ridge_raw + 0.06) * ridge_taper;
+            EL_ADD(e, ridge_lift);
         }
         const double fd = F.fractureDist[r];
         if (fd != INFINITY && fd <= Q.fractureHalfWidth) {
             const double ft = fd / Q.fractureHalfWidth;
             e = (float)((double)e - 0.03 * (1 - ft));
         }
-        if (btype == 1) e = (float)((double)e - (0.15 + 0.15 * stressNorm));
+        if (btype == 1) e = (float)((double)e - (0.15 + 0.15 * stress_rel));
         {
-            double baEffect;
-            if (back_arc_effect(F, Q, r, baEffect)) { EL_ADD(e, baEffect); if (dl) EL_DL(DL_BACKARC) = (float)baEffect; }
+            double backarc_add;
+            if (back_arc_effect(F, Q, r, backarc_add)) { EL_ADD(e, backarc_add); if (dl) EL_DL(DL_BACKARC) = (float)backarc_add; }
         }
-        if (dl) EL_DL(DL_TECTONIC) = (float)((double)e - (double)elevBeforeOcTec);
-        const double oceanNoise = fbm(noise.P, noise.M, wx, wy, wz) * noiseMag * 0.3;
-        EL_ADD(e, oceanNoise);
-        if (dl) EL_DL(DL_NOISE) = (float)oceanNoise;
+        if (dl) EL_DL(DL_TECTONIC) = (float)((double)e - (double)e_prev_oc);
+        const double abyss_noise = fbm(noise.P, noise.M, wx, wy, wz) * noiseMag * 0.3;
+        EL_ADD(e, abyss_noise);
+        if (dl) EL_DL(DL_NOISE) = (float)abyss_noise;
     }
     return e;
 }
