@@ -18,8 +18,14 @@ L = C.CDLL(str(REPO / "tests" / "emu" / "_build" / "libemu.so"))
 p = C.c_void_p
 L.emu_flood_host.argtypes = [C.c_int32, p, p, p, p, p, C.c_double, C.c_int32, C.c_int32, p]
 t = time.time(); mesh, xyz, nd = S.build_sphere(cells, 0.75, 1); print(f"mesh {time.time()-t:.1f} s", flush=True)
-om = O.Mesh(mesh.adjOffset, mesh.adjList)
-t = time.time(); e0 = O.warp_terrain(om, O.synthetic_terrain(xyz, 1), xyz, 1, 0.75); print(f"terrain {time.time()-t:.1f} s", flush=True)
+t = time.time()
+try:                                   # on a GPU box the HIP path makes the (bit-identical) terrain in milliseconds
+    from planet_heightmap_generation_amd import terrain_post as TP
+    pl = TP.Planet(mesh, xyz, nd); pl.synthetic_terrain(1); pl.warp_terrain_resident(1, 0.75); e0 = pl.download(); pl.close()
+except Exception:
+    om = O.Mesh(mesh.adjOffset, mesh.adjList)
+    e0 = O.warp_terrain(om, O.synthetic_terrain(xyz, 1), xyz, 1, 0.75)
+print(f"terrain {time.time()-t:.1f} s", flush=True)
 oc = (e0 <= 0).astype(np.uint8)
 P = lambda a: a.ctypes.data_as(p)
 e = e0.copy(); st = np.zeros(11)
