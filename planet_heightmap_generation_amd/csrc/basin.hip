@@ -423,7 +423,7 @@ void basin_layout(wo_planet* p, bool slotIdentity) {
     if (!library) {
         uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
         int32_t* const vb[2] = {p->d_basinVals[0], p->d_basinVals[1]};
-        sorted = radix_sort_pairs(p, FAM_BASIN_SORT, kb, vb, L, 0, ((bitsL - shift) + 7) / 8 * 8, p->d_basinSlot, radix_scratch(p, 1), p->N, p->rsFlip[1]);
+        sorted = radix_sort_pairs(p, FAM_BASIN_SORT, kb, vb, L, 0, 16 /* always two digits: the sort's two group-total buffers swap roles every pass and only stay consistent over an even number of passes; key bits above bitsL - shift are zero */, p->d_basinSlot, radix_scratch(p, 1), p->N, p->rsFlip[1]);
     } else {
         hipEvent_t a = nullptr, b = nullptr;
         if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }

@@ -70,7 +70,11 @@ public:
             job_ = &job; chunks_ = chunks; next_.store(0); remaining_.store(chunks); error_ = nullptr; ++gen_;
         }
         cv_.notify_all();
-        work(job, chunks);                                   // the caller takes chunks too
+        {   // the caller takes chunks too; a job that itself calls parallel_ranges must find the pool unavailable on this thread as
+            // well (it owns jobLock_: locking it again from the same thread would be undefined behaviour)
+            struct InJob { bool& f; bool was; explicit InJob(bool& x) : f(x), was(x) { f = true; } ~InJob() { f = was; } } guard(tl_in_worker());
+            work(job, chunks);
+        }
         std::unique_lock<std::mutex> g(m_);
         cvDone_.wait(g, [&] { return remaining_.load() == 0 && active_ == 0; });
         job_ = nullptr;

@@ -352,9 +352,12 @@ struct StageClock {
             acc[e.first] += ms;
             p->eventPool.push_back(e.second.first); p->eventPool.push_back(e.second.second);
         }
+        ev.clear();
         p->stageTiming.clear();
         for (auto& n : order) { const auto& c = seen[n]; p->stageTiming.push_back({n, acc[n] * (c.second > 0 ? (double)c.first / (double)c.second : 1.0)}); }
     }
+    // a call that ends by exception (RedoWithChecks, a failed exchange) never reaches finish(): its events go back to the pool
+    ~StageClock() { for (auto& e : ev) { p->eventPool.push_back(e.second.first); p->eventPool.push_back(e.second.second); } }
 };
 
 // ---------------------------------------------------------------------------------------------------

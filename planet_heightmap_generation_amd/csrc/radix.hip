@@ -189,6 +189,10 @@ int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t*
                      uint32_t* scratch, int32_t nMax, int& flip) {
     const int passes = (endBit - beginBit + 7) / 8;
     if (passes <= 0 || n <= 0) return 0;
+    // every pass clears the group totals the NEXT pass adds into, up to this sort's group count: with an even number of passes per
+    // sort the buffer a sort starts on is always the one its predecessor's last pass cleared; an odd count would swap the roles and
+    // let a later, larger sort start on totals a smaller one left behind
+    if (passes & 1) throw HipError{"radix_sort_pairs: the number of digits must be even"};
     if (n > nMax) throw HipError{"radix_sort_pairs: more pairs than the scratch was sized for"};
     hipStream_t s = cur_stream(p);
     const int tiles = rs_tiles(n), groups = rs_groups(n);

@@ -50,7 +50,7 @@ def test_bench_two_ranks_emit_the_ensemble_line_and_the_one_planet_leg(tmp_path)
     import os
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            str(REPO / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--cells", "200000", "--iters", "8", "--steps", "1", "--warmup", "1",
-           "--no-cpu", "--no-profile", "--in-flight", "0", "--one-planet-cells", "300000", "--one-planet-iters", "8"]
+           "--no-cpu", "--no-profile", "--in-flight", "0", "--one-planet-cells", "300000", "--one-planet-iters", "8", "--one-planet-parity-iters", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
