@@ -104,6 +104,7 @@ struct Options {
     bool floodTiesById = false;        // WO_FLOOD_TIES=id         accept the cell-id order between equal labels (device flood)
     bool floodTiming = false;          // WO_FLOOD_TIMING          stage laps -> stderr
     bool stageTimingAll = false;       // WO_STAGE_TIMING=all      bracket every iteration
+    bool graphs = false;               // WO_GRAPH=1               hipGraph replay of the steady composite iteration (measured slower: planet.hip)
     int  relaxedSortEvery = 1;         // WO_RELAXED_SORT_EVERY=K  RELAXED MODE (not parity): re-sort landCells every K-th iteration only
     static Options from_env();
 };

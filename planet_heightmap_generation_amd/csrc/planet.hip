@@ -343,6 +343,7 @@ struct StageClock {
         hipEvent_t a = profile_event(p), b = profile_event(p); WO_HIP(hipEventRecord(a, p->ctx->stream)); ev.push_back({name, {a, b}});
     }
     void end() { if (open) WO_HIP(hipEventRecord(ev.back().second.second, p->ctx->stream)); open = false; }
+    void count_only(const char* name) { ++seen[name].first; }       // an occurrence that is not bracketed (an iteration replayed from the graph)
     void finish() {
         WO_HIP(hipStreamSynchronize(p->ctx->stream));
         std::map<std::string, double> acc; std::vector<std::string> order;
@@ -770,11 +771,40 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
     const bool stageAll = p->opt.stageTimingAll;
+    // One composite iteration as a hipGraph.  Outside the glacial iterations and the flood, an iteration with both the hydraulic and
+    // the thermal step is the same ~25 launches on two streams with the same arguments every time (the elevation buffers swap
+    // twice, every radix sort has an even number of passes, the solve launch's tag is constant): it is captured once per call —
+    // the side stream's fork and join become dependencies of the graph — and replayed, which takes the host out of the loop.
+    // MEASURED SLOWER on ROCm 7.2 / MI355X (10 M cells, 200 iterations, 167 of them replayed: 499.5 ms per step against 384.1 with
+    // plain launches, profiles/r04j_*; same field, CRC checked): a graph launch costs more than the ~25 stream launches it
+    // replaces, whose gaps (~130 us of a 1.35 ms iteration) the host already hides by running ahead of the device.  Off by
+    // default; WO_GRAPH=1 switches it on (test_graph_replay_route_agrees).  Iterations whose stages are timed (every 8th),
+    // profiled runs and every other cross-check route always take the plain path.
+    struct IterGraph {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        ~IterGraph() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+    } iterGraph;
+    const Options& O = p->opt;
+    const bool graphRoute = O.graphs && !p->profiling && !checkEveryPass && basinSolve && p->patchVersion >= 0 && O.flowClimbCap == 0x7fffffff && !O.flowEventsStream &&
+                            !O.noEventLists && !O.basinStats && !O.sortLibrary && O.relaxedSortEvery <= 1 && p->maxDeg <= 16 && total > 16;
+    int64_t graphReplays = 0;
     for (int32_t iter = 0; iter < total; ++iter) {
         clk.on = true;
         if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
         clk.on = stageAll || p->profiling || total <= 16 || iter % 8 == 0;
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
+        const bool graphable = graphRoute && !clk.on && !gNow && hNow && iter < tIters && iter >= 2 && p->side != nullptr;
+        if (graphable && iterGraph.exec) {
+            WO_HIP(hipGraphLaunch(iterGraph.exec, s));
+            ++graphReplays; ++sorts; ++basinPasses; ++patchLaunches; maxSolve = std::max<int64_t>(maxSolve, 1); ++p->basinLaunches;
+            for (const char* st : {"sort", "receivers", "flow", "solve", "thermal"}) clk.count_only(st);
+            continue;
+        }
+        const bool capturing = graphable;
+        if (capturing) WO_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        struct CaptureGuard {       // an exception inside a capture must not leave the stream capturing
+            hipStream_t s; bool on; ~CaptureGuard() { if (on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } }
+        } captureGuard{s, capturing};
         // WO_RELAXED_SORT_EVERY=K (relaxed mode, NOT the reference's semantics: SURVEY 7.3): landCells is re-sorted only every K-th
         // iteration; in between the passes run with a stale visiting order (still a consistent order: every pass compares ranks
         // pairwise, so the dataflow is well defined, it is just not the reference's).  Measured, never reported as parity.
@@ -1039,6 +1069,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             swap_elev(p);
             clk.end();
         }
+        if (capturing) {
+            captureGuard.on = false;
+            WO_HIP(hipStreamEndCapture(s, &iterGraph.graph));
+            WO_HIP(hipGraphInstantiate(&iterGraph.exec, iterGraph.graph, nullptr, nullptr, 0));
+            WO_HIP(hipGraphLaunch(iterGraph.exec, s));                 // the captured iteration itself
+            ++graphReplays;
+        }
     }
     clk.on = true;
     leftovers_so_far();
@@ -1065,7 +1102,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
                      {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_replays", (double)floodRun.host.replays}, {"flood_host_replayed_landmasses", (double)floodRun.host.replayedLandmasses}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
                      {"flood_host_pass23_ms", floodRun.host.pass23Ms},
-                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}};
+                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"iterations_replayed_from_graph", (double)graphReplays}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
@@ -1166,6 +1203,7 @@ Options Options::from_env() {
     o.floodTiesById = str("WO_FLOOD_TIES") == "id";
     o.floodTiming = set("WO_FLOOD_TIMING");
     o.stageTimingAll = str("WO_STAGE_TIMING") == "all";
+    if (set("WO_GRAPH")) o.graphs = std::atoi(std::getenv("WO_GRAPH")) != 0;
     if (set("WO_RELAXED_SORT_EVERY")) o.relaxedSortEvery = std::max(1, std::atoi(std::getenv("WO_RELAXED_SORT_EVERY")));
     return o;
 }

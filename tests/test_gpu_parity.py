@@ -830,3 +830,26 @@ def test_land_count_shrinks_and_grows_on_one_planet(TP, oracle):
         pl.erode_composite(got, mask, *args)
         assert np.array_equal(got, ref), (int((mask == 0).sum()), int((got != ref).sum()))
     pl.close()
+
+
+def test_graph_replay_route_agrees(TP, oracle, monkeypatch):
+    """WO_GRAPH=1: the steady composite iteration (no glacial step, no flood) captured once per call as a hipGraph — main and
+    side stream — and replayed.  Measured slower than plain launches on this stack, so it is off by default; as a route it must
+    give the oracle's field bit for bit, and it must really have replayed."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(200000, 0.75, 14)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(14)
+    e0 = pl.download()
+    oc = (e0 <= 0).astype(np.uint8)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    args = (24, 3e-4, 0.5, 1.0, 24, 1.16, 0.015, 2, 0.5)
+    ref = oracle.erode_composite(om, e0, xyz, oc, *args, nd)
+    monkeypatch.setenv("WO_GRAPH", "1")
+    got = e0.copy()
+    pl.erode_composite(got, oc, *args)
+    st = pl.last_erode_stats()
+    monkeypatch.delenv("WO_GRAPH")
+    assert st["iterations_replayed_from_graph"] >= 10, st
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    pl.close()
