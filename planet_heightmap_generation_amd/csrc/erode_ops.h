@@ -860,54 +860,34 @@ WO_HD inline void thermal_excess_cell(const Fields& F, int32_t r, double talus) 
 template <class Masked>
 WO_HD inline float thermal_apply_row(const Fields& F, double h, int32_t myRank, double myTotal, int32_t b, const int32_t (&nbs)[WO_ROW], int deg,
                                      double talus, double kThermal, Masked masked) {
-    const double myTransfer = kThermal * myTotal * 0.5;
     float mh[WO_ROW], dd[WO_ROW];
-    double tx[WO_ROW]; int32_t rk[WO_ROW]; bool snd[WO_ROW];
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) mh[k] = masked(nbs[k]);
     load_row_dist(F, b, deg, dd);
-    {   // no slope towards or from c can exceed the talus angle (talus_may_exceed; an ocean neighbour's +inf never sends: its
-        // totalExcess is 0): neither c nor a neighbour has an event on c, delta stays 0
-        bool cand = false;
-#pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) {
-            const double nh = mh[k], d = nd_or_eps(dd[k]);
-            cand = cand || (k < deg && nh != (double)INFINITY && talus_may_exceed(fabs(nh - h), d, talus));
-        }
-        if (!cand) return (float)(h + 0.0);
-    }
-#pragma unroll
-    for (int k = 0; k < WO_ROW; ++k) {
-        const double nh = mh[k], d = nd_or_eps(dd[k]);
-        snd[k] = k < deg && nh > h && talus_may_exceed(nh - h, d, talus) && ((nh - h) / d > talus);
-        tx[k] = snd[k] ? F.totalExcess[nbs[k]] : 0.0;
-        rk[k] = snd[k] ? F.rank[nbs[k]] : 0;
-    }
+    // One slope per neighbour, whichever way it points: (h - nh) / d and (nh - h) / d are the same quotient up to the sign, so the
+    // serial loop's `slope` of the higher cell of the pair is |nh - h| / d either way, and the share it moves is
+    // (f32(excess) / total) * (kThermal * total * 0.5) with the SENDER's total — c's own (c sends on its own turn) or the
+    // neighbour's (it sends on its turn).  Two divisions per steep pair instead of five in the wave's instruction stream; the
+    // exact pre-test (talus_may_exceed) skips both where the slope cannot exceed the talus angle.  An ocean neighbour's masked
+    // height is +inf: never a sender (its totalExcess is 0), and never lower than c.
     double inSh[WO_ROW], outSh[WO_ROW]; int32_t inRk[WO_ROW]; bool outOn[WO_ROW];
     bool hasOut = false, hasIn = false;
 #pragma unroll
     for (int k = 0; k < WO_ROW; ++k) {
         inRk[k] = 0x7fffffff; inSh[k] = 0; outSh[k] = 0; outOn[k] = false;
-        if (k >= deg) continue;
-        const double nh = mh[k];             // +inf for ocean neighbours: a sender whose totalExcess is 0
-        const double d = nd_or_eps(dd[k]);
-        if (nh < h) {                           // c sends to nb on c's own turn
-            const double slope = (h - nh) / d;
-            if (slope > talus && myTotal > 0) {
-                hasOut = true; outOn[k] = true;
-                const float excess = (float)((slope - talus) * d);
-                outSh[k] = ((double)excess / myTotal) * myTransfer;
-            }
-        } else if (snd[k]) {                    // nb sends to c on nb's turn
-            const double slope = (nh - h) / d;
-            const double tot = tx[k];
-            if (tot > 0) {
-                const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
-                inSh[k] = ((double)excess / tot) * (kThermal * tot * 0.5);
-                inRk[k] = rk[k];
-                hasIn = true;
-            }
-        }
+        const double nh = mh[k], d = nd_or_eps(dd[k]);
+        const double gap = fabs(nh - h);
+        if (!(k < deg && nh != (double)INFINITY && talus_may_exceed(gap, d, talus))) continue;
+        const double slope = gap / d;
+        if (!(slope > talus)) continue;
+        const bool sends = nh < h;                 // c is the higher cell: it sends to nb on its own turn; else nb sends to c on nb's turn
+        if (!sends && !(nh > h)) continue;
+        const double tot = sends ? myTotal : F.totalExcess[nbs[k]];
+        if (!(tot > 0)) continue;
+        const float excess = (float)((slope - talus) * d);        // excVal is a Float32Array
+        const double share = ((double)excess / tot) * (kThermal * tot * 0.5);
+        if (sends) { hasOut = true; outOn[k] = true; outSh[k] = share; }
+        else { hasIn = true; inSh[k] = share; inRk[k] = F.rank[nbs[k]]; }
     }
     if (!hasIn && !hasOut) return (float)(h + 0.0);   // e += delta with delta == 0 (also maps -0 -> +0 like the f32 add)
     float delta = 0.0f;
