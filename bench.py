@@ -61,11 +61,11 @@ ONE_OFF = {"soil_creep": (82.0 * 0.8, 4.0), "warp_terrain": (0.0, 20.0 + 100.0 *
 GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend")      # ice_round: k_ice_climb, carve_round: k_carve_granules (one launch each per glacial step)
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload at the full iteration count (separate passes;
 # profiles/collect_pmc.sh); used for roofline.traffic of the dominant kernel unless WO_BENCH_PMC=1 asks for a live collection.
-PMC_FILE = REPO / "profiles" / "r03_pmc_fetch_write_per_kernel_10m_200iters.json"
+PMC_FILE = REPO / "profiles" / "r04_pmc_fetch_write_per_kernel_10m_200iters.json"
 FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": ("void wo::k_solve_setup_batched<true>", "wo::k_solve_setup"), "sort_radix": "wo::k_rs_scatter",
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
                  "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_snap": "wo::k_flow_climb", "carve_round": "wo::k_carve_round_pairs",
-                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_coop", "wo::k_solve_stream")}
+                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_flowing", "void wo::k_solve_coop")}
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5)
