@@ -61,3 +61,16 @@ def test_bench_two_ranks_emit_the_ensemble_line_and_the_one_planet_leg(tmp_path)
     assert leg["config"]["cells"] == 300001 and leg["value"] > 0 and "crc32" in leg["parity"]
     assert len(leg["per_rank"]) == 2 and sum(x["land_cells"] for x in leg["per_rank"]) > 0
     assert abs(out["value"] - 200001 * 8 * 1 * 2 / (out["ms_per_step"] / 1e3) / 1e6) < 1e-6 * out["value"]
+
+
+def test_committed_pmc_file_covers_the_default_paths_kernels():
+    """bench.py refuses (SystemExit) a PMC file without counters for a kernel family the profiled step launched.  The committed file
+    must therefore name the kernels of the default route's per-iteration families — checked here, where a stale file costs a test
+    and not the round's bench line."""
+    import bench
+    have = [k.replace("(anonymous namespace)::", "") for k, v in json.loads(bench.PMC_FILE.read_text()).items() if isinstance(v, dict)]
+    for fam in ("sort_radix", "sort_keys", "receivers", "flow_snap", "flow_final", "solve_setup", "solve_basin", "thermal_excess", "thermal_apply"):
+        if fam not in bench.FAMILY_KERNEL:
+            continue
+        names = bench.FAMILY_KERNEL[fam] if isinstance(bench.FAMILY_KERNEL[fam], tuple) else (bench.FAMILY_KERNEL[fam],)
+        assert any(h.startswith(names) for h in have), (fam, names)
