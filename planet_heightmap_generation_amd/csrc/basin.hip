@@ -249,6 +249,54 @@ __global__ __launch_bounds__(64 * NW, 6) void k_solve_coop(Fields F, int32_t L, 
 //   * a polling pass issues its three LDS reads together (clamped word: the task's own) and waits once.
 // Same tasks, same inputs: bit-identical results (single-assignment dataflow).
 // ---------------------------------------------------------------------------------------------------------------------
+// The two divisions of a turn whose divisor is a per-task constant (1 + factor, cellDist[t]) without the divisor's part of the
+// division on the dependency chain.  hipcc expands x / y into v_div_scale of both operands, v_rcp, two Newton steps on the reciprocal
+// (4 fma), then q0 = x * r, e = fma(-y, q0, x), q = fma(e, r, q0) (v_div_fmas) and v_div_fixup; when neither operand needs scaling the
+// scales are identities and the fix-up passes q through, so everything before q0 depends on y alone: recip_refined() is that part,
+// run when the record arrives (off the chain), div_tail() the three dependent operations that remain — the same instructions on the
+// same values, hence the same bits (checked on 8.6e9 operand pairs in round 2, profiles/microbench/fastdiv.hip, and by the CRC of the
+// benched field).  "No scaling" holds for every operand a turn can see when factor_ok(): the dividends are sums / differences of
+// f32 heights (0 or >= 2^-149) times a factor in [2^-300, 2^300], the divisors 1 + factor and an f32 distance.  A task that is not
+// ok takes the plain divisions (the whole wave, for that pass).  Round 3 measured a form with the range tests ON the chain: slower.
+__device__ inline double recip_refined(double y) {
+    const double r0 = __builtin_amdgcn_rcp(y);
+    const double f0 = __builtin_fma(-y, r0, 1.0);
+    const double r1 = __builtin_fma(r0, f0, r0);
+    const double f1 = __builtin_fma(-y, r1, 1.0);
+    return __builtin_fma(r1, f1, r1);
+}
+__device__ inline double div_tail(double x, double y, double r) {
+    const double q0 = x * r;
+    const double e = __builtin_fma(-y, q0, x);
+    return __builtin_fma(e, r, q0);
+}
+__device__ inline bool factor_ok(double f, float cellDistT, bool hasT2) {
+    const bool fOk = f == 0.0 || (f >= 0x1p-300 && f <= 0x1p300);                    // (NaN / inf fail both)
+    const bool dOk = !hasT2 || (cellDistT >= 0x1p-126f && cellDistT <= 0x1p100f);   // a normal f32
+    return fOk && dOk;
+}
+// solve_apply_flat with the two constant divisors' reciprocals in hand
+__device__ inline SolveOut solve_apply_recip(const SolveTask& T, double factor, double y1, double r1, double y2, double r2, double er, double et, double et2, int32_t tag) {
+    const bool hasT = (T.flags & 4u) != 0, tOcean = (T.flags & 1u) != 0, hasT2 = (T.flags & 8u) != 0;
+    const double hr = et > 0 ? et : 0;
+    double hn = div_tail(er + factor * hr, y1, r1);
+    hn = hn < hr ? hr : hn;
+    hn = hn < 0 ? 0 : hn;
+    const double eroded = er - hn;
+    const double sl = div_tail(fabs(et - et2), y2, r2);
+    const double slope = hasT2 ? sl : 0.0;
+    const double depositFrac = 0.5 / (1 + slope * 50);
+    const double deposit = eroded * depositFrac;
+    float tv = (float)(et + deposit);
+    tv = ((double)tv > hn) ? (float)hn : tv;
+    const bool deposits = eroded > 0 && !tOcean;
+    SolveOut o;
+    o.self.tag = tag; o.dep.tag = tag;
+    o.self.v = hasT ? (float)hn : (float)er;
+    o.dep.v = hasT ? (deposits ? tv : (float)et) : 0.0f;
+    return o;
+}
+
 template <int NW, bool STATS>
 __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
                                                                int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag,
@@ -334,9 +382,14 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
         const bool n0b = r0 >= 0, n1b = r1 >= 0, n2b = r2 >= 0;
         const float fr = (float)er, ft = (float)et, ft2 = (float)et2;      // inputs that are already in hand (exact: they came from floats)
         const SolvePrepared pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
+        // (off the chain: the record has just arrived, the predecessors have not)
+        const double y1 = 1 + pre.factor, y2 = (double)T.cellDistT;
+        const double rc1 = recip_refined(y1), rc2 = recip_refined(y2);
+        const bool recipOk = !mine || factor_ok(pre.factor, T.cellDistT, (T.flags & 8u) != 0);
         bool open = mine;
         SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
         if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
+        const bool waveRecipOk = !__any(!recipOk);
         while (__any(open)) {
             const unsigned long long g0 = ring_get(w0), g1 = ring_get(w1), g2 = ring_get(w2);
             const int32_t t0 = (int32_t)(g0 >> 32), t1 = (int32_t)(g1 >> 32), t2 = (int32_t)(g2 >> 32);
@@ -347,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
                 const double ver = n0b ? (double)__uint_as_float((uint32_t)g0) : (double)fr;
                 const double vet = n1b ? (double)__uint_as_float((uint32_t)g1) : (double)ft;
                 const double vet2 = n2b ? (double)__uint_as_float((uint32_t)g2) : (double)ft2;
-                const SolveOut oo = solve_apply_flat(T, pre, ver, vet, vet2, launchTag);
+                const SolveOut oo = waveRecipOk ? solve_apply_recip(T, pre.factor, y1, rc1, y2, rc2, ver, vet, vet2, launchTag) : solve_apply_flat(T, pre, ver, vet, vet2, launchTag);
                 if (ready) {
                     o = oo;
                     if (STATS) {        // predecessors beyond the ring window count as depth 0 (they finished long ago)
