@@ -297,18 +297,25 @@ __device__ inline SolveOut solve_apply_recip(const SolveTask& T, double factor, 
     return o;
 }
 
-template <int NW, bool STATS>
-__global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
+// Waves per range: TWO (measured at 10 M cells, solve launches per step: 1 wave 66.7 ms, 2 waves 45.5, 4 waves 48.2, 8 waves 77.7; lag 1 / 2 / 6
+// super-chunks with two waves: 45.6 / 45.5 / 52.5).  A wave spends ~2 000 clocks in a pass that holds a turn (WO_BASIN_STATS: 80 % of the
+// slowest range's time is inside turns, 75 % of its passes hold one) and a hand-off to another wave costs about as much again, so fewer,
+// fuller waves win until one wave has to take every level alone.
+template <int NW, bool STATS, int LAG_ = 2>
+__global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
                                                                int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag,
                                                                unsigned long long* stats) {
     constexpr int SC = 64 * NW;                        // tasks per super-chunk
-    constexpr int LAG = 2, LOOKBACK = LAG + 2;
-    constexpr int RING = 8 * SC;                       // >= (LOOKBACK + LAG + 1) super-chunks, power of two
-    static_assert(LOOKBACK + LAG + 1 <= 8, "ring too small for the lag");
+    constexpr int LAG = LAG_, LOOKBACK = LAG + 2;
+    constexpr int RCHUNKS = (LOOKBACK + LAG + 1 <= 8) ? 8 : 16;
+    constexpr int RING = RCHUNKS * SC;                 // >= (LOOKBACK + LAG + 1) super-chunks, power of two
+    static_assert(LOOKBACK + LAG + 1 <= RCHUNKS, "ring too small for the lag");
     __shared__ unsigned long long s_ring[2 * RING];
     __shared__ int32_t s_prog[NW];                     // super-chunks each wave has finished
     __shared__ int32_t s_level[STATS ? RING : 1];      // WO_BASIN_STATS (diagnostic): depth of every task in the dependency DAG
     __shared__ int32_t s_maxLevel;
+    __shared__ unsigned long long s_passes[STATS ? NW : 1], s_readyPasses[STATS ? NW : 1], s_clk[3];
+    unsigned long long myPasses = 0, myReady = 0, cRead = 0, cTurn = 0, cRest = 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long cStart = STATS ? clock64() : 0;
     if (STATS && tid == 0) s_maxLevel = 0;
@@ -391,11 +398,14 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
         if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
         const bool waveRecipOk = !__any(!recipOk);
         while (__any(open)) {
+            const long long c0 = STATS ? clock64() : 0;
             const unsigned long long g0 = ring_get(w0), g1 = ring_get(w1), g2 = ring_get(w2);
             const int32_t t0 = (int32_t)(g0 >> 32), t1 = (int32_t)(g1 >> 32), t2 = (int32_t)(g2 >> 32);
+            const long long c1 = STATS ? (long long)(clock64() + (t0 & 0)) : 0;       // (after the reads have arrived)
             const bool ok = (!n0b | (t0 == x0)) & (!n1b | (t1 == x1)) & (!n2b | (t2 == x2));
             const bool bad = (n0b & (t0 == -x0)) | (n1b & (t1 == -x1)) | (n2b & (t2 == -x2));
             const bool ready = open & ok;
+            if (STATS) { ++myPasses; if (__any(ready)) ++myReady; }
             if (__any(ready)) {
                 const double ver = n0b ? (double)__uint_as_float((uint32_t)g0) : (double)fr;
                 const double vet = n1b ? (double)__uint_as_float((uint32_t)g1) : (double)ft;
@@ -415,6 +425,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
                     open = false;
                 }
             }
+            const long long c2 = STATS ? clock64() : 0;
+            if (STATS) { cRead += (unsigned long long)(c1 - c0); cTurn += (unsigned long long)(c2 - c1); }
             if (__any(open & bad)) {                                     // a predecessor is blocked (never on real layouts: WO_BASIN_SCRAMBLE)
                 if (open & bad) { blocked = true; ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
             }
@@ -425,13 +437,20 @@ __global__ __launch_bounds__(64 * NW, 4) void k_solve_flowing(Fields F, int32_t 
         if (lane == 0) __hip_atomic_store(&s_prog[wave], ci + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // after this wave's ring words (a wave's LDS operations execute in order)
     }
     if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
-    if (STATS) {        // the range that took longest: {clocks, slots, DAG depth seen through the ring}
+    if (STATS) {        // the range that took longest: {clocks, slots, DAG depth seen through the ring}, and its waves' polling passes
+        if (lane == 0) { s_passes[wave] = myPasses; s_readyPasses[wave] = myReady; }
+        if (tid == 0) { s_clk[0] = cRead; s_clk[1] = cTurn; s_clk[2] = myPasses; }
         __syncthreads();
         if (tid == 0) {
             const unsigned long long c = (unsigned long long)(clock64() - cStart);
             const unsigned long long packed = (c << 24) | (unsigned long long)(s_maxLevel & 0xffffff);
             const unsigned long long old = atomicMax(&stats[0], packed);
-            if (packed > old) stats[1] = (unsigned long long)(E - S);       // (racy by design: diagnostic)
+            if (packed > old) {       // (racy by design: diagnostic)
+                stats[1] = (unsigned long long)(E - S);
+                unsigned long long mp = 0, mr = 0;
+                for (int w = 0; w < NW; ++w) { mp = s_passes[w] > mp ? s_passes[w] : mp; mr = s_readyPasses[w] > mr ? s_readyPasses[w] : mr; }
+                stats[2] = mp; stats[3] = mr; stats[4] = s_clk[0]; stats[5] = s_clk[1]; stats[6] = s_clk[2];
+            }
         }
     }
 }
@@ -501,19 +520,20 @@ void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_
         return;
     }
     if (!p->opt.basinStats) {
-        launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, false>, grid, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
+        launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, false>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
         return;
     }
     // WO_BASIN_STATS=1 (diagnostic): the slowest range of the launch, its clocks and the depth of its dependency DAG -> stderr
     static unsigned long long* dstats = nullptr;
-    if (!dstats) WO_HIP(hipMalloc((void**)&dstats, 2 * sizeof(unsigned long long)));
-    WO_HIP(hipMemsetAsync(dstats, 0, 2 * sizeof(unsigned long long), cur_stream(p)));
-    launch(p, FAM_SOLVE_BASIN, k_solve_flowing<4, true>, grid, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    unsigned long long h[2];
+    if (!dstats) WO_HIP(hipMalloc((void**)&dstats, 8 * sizeof(unsigned long long)));
+    WO_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(unsigned long long), cur_stream(p)));
+    launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, true>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    unsigned long long h[8];
     WO_HIP(hipStreamSynchronize(cur_stream(p)));
     WO_HIP(hipMemcpy(h, dstats, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[basin stats] slowest range: %llu slots, %llu clocks, DAG depth (ring window) %llu -> %.0f clocks per level\n", h[1], h[0] >> 24, h[0] & 0xffffffull,
-            (double)(h[0] >> 24) / (double)std::max<unsigned long long>(1, h[0] & 0xffffffull));
+    fprintf(stderr, "[basin stats] slowest range: %llu slots, %llu clocks, DAG depth (ring window) %llu -> %.0f clocks per level; busiest wave: %llu polling passes, %llu with a turn\n", h[1], h[0] >> 24, h[0] & 0xffffffull,
+            (double)(h[0] >> 24) / (double)std::max<unsigned long long>(1, h[0] & 0xffffffull), h[2], h[3]);
+    fprintf(stderr, "[basin stats]   wave 0 of it: %llu passes, clocks in the ring reads %llu, in the turn (incl. ring writes) %llu\n", h[6], h[4], h[5]);
 }
 
 void basin_free(wo_planet* p) {
