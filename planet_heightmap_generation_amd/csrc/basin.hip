@@ -314,8 +314,8 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
     __shared__ int32_t s_prog[NW];                     // super-chunks each wave has finished
     __shared__ int32_t s_level[STATS ? RING : 1];      // WO_BASIN_STATS (diagnostic): depth of every task in the dependency DAG
     __shared__ int32_t s_maxLevel;
-    __shared__ unsigned long long s_passes[STATS ? NW : 1], s_readyPasses[STATS ? NW : 1], s_clk[3];
-    unsigned long long myPasses = 0, myReady = 0, cRead = 0, cTurn = 0, cRest = 0;
+    __shared__ unsigned long long s_passes[STATS ? NW : 1], s_readyPasses[STATS ? NW : 1], s_clk[4];
+    unsigned long long myPasses = 0, myReady = 0, cRead = 0, cTurn = 0, cRest = 0, cWait = 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long cStart = STATS ? clock64() : 0;
     if (STATS && tid == 0) s_maxLevel = 0;
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
         const int32_t q = base + tid;
         const bool mine = q < E;
         // not more than LAG super-chunks ahead of the slowest wave (see above)
+        const long long cw0 = STATS ? clock64() : 0;
         if (ci > LAG) {
             for (;;) {
                 int32_t mn = 0x7fffffff;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
                 __builtin_amdgcn_s_sleep(1);
             }
         }
+        const long long cw1 = STATS ? clock64() : 0;
         if (storePrev) store_prev(q - SC);                             // a super-chunk late: the wait for this super-chunk's loads at the top of the loop would otherwise also wait for a store issued a moment ago
         const SolveTask T = T1;
         T1 = T2;
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
         SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
         if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
         const bool waveRecipOk = !__any(!recipOk);
+        if (STATS) { const long long cw2 = clock64() + (long long)(__float_as_int((float)er) & 0); cRest += (unsigned long long)(cw2 - cw1); cWait += (unsigned long long)(cw1 - cw0); }
         while (__any(open)) {
             const long long c0 = STATS ? clock64() : 0;
             const unsigned long long g0 = ring_get(w0), g1 = ring_get(w1), g2 = ring_get(w2);
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
                 const SolveOut oo = waveRecipOk ? solve_apply_recip(T, pre.factor, y1, rc1, y2, rc2, ver, vet, vet2, launchTag) : solve_apply_flat(T, pre, ver, vet, vet2, launchTag);
                 if (ready) {
                     o = oo;
-                    if (STATS) {        // predecessors beyond the ring window count as depth 0 (they finished long ago)
+                    if (STATS && LAG_ != 3) {        // predecessors beyond the ring window count as depth 0 (they finished long ago); (LAG_ == 3: diagnostic build without the depth bookkeeping)
                         int32_t lv = 0;
                         if (n0b) lv = max(lv, s_level[w0 >> 1]);
                         if (n1b) lv = max(lv, s_level[w1 >> 1]);
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
     if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
     if (STATS) {        // the range that took longest: {clocks, slots, DAG depth seen through the ring}, and its waves' polling passes
         if (lane == 0) { s_passes[wave] = myPasses; s_readyPasses[wave] = myReady; }
-        if (tid == 0) { s_clk[0] = cRead; s_clk[1] = cTurn; s_clk[2] = myPasses; }
+        if (tid == 0) { s_clk[0] = cWait; s_clk[1] = cTurn; s_clk[2] = myPasses; s_clk[3] = cRest; }
         __syncthreads();
         if (tid == 0) {
             const unsigned long long c = (unsigned long long)(clock64() - cStart);
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
                 stats[1] = (unsigned long long)(E - S);
                 unsigned long long mp = 0, mr = 0;
                 for (int w = 0; w < NW; ++w) { mp = s_passes[w] > mp ? s_passes[w] : mp; mr = s_readyPasses[w] > mr ? s_readyPasses[w] : mr; }
-                stats[2] = mp; stats[3] = mr; stats[4] = s_clk[0]; stats[5] = s_clk[1]; stats[6] = s_clk[2];
+                stats[2] = mp; stats[3] = mr; stats[4] = s_clk[0]; stats[5] = s_clk[1]; stats[6] = s_clk[2]; stats[7] = s_clk[3];
             }
         }
     }
@@ -527,13 +530,14 @@ void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_
     static unsigned long long* dstats = nullptr;
     if (!dstats) WO_HIP(hipMalloc((void**)&dstats, 8 * sizeof(unsigned long long)));
     WO_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(unsigned long long), cur_stream(p)));
-    launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, true>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    if (p->opt.basinStatsNoDepth) launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, true, 3>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
+    else launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, true>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
     unsigned long long h[8];
     WO_HIP(hipStreamSynchronize(cur_stream(p)));
     WO_HIP(hipMemcpy(h, dstats, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[basin stats] slowest range: %llu slots, %llu clocks, DAG depth (ring window) %llu -> %.0f clocks per level; busiest wave: %llu polling passes, %llu with a turn\n", h[1], h[0] >> 24, h[0] & 0xffffffull,
             (double)(h[0] >> 24) / (double)std::max<unsigned long long>(1, h[0] & 0xffffffull), h[2], h[3]);
-    fprintf(stderr, "[basin stats]   wave 0 of it: %llu passes, clocks in the ring reads %llu, in the turn (incl. ring writes) %llu\n", h[6], h[4], h[5]);
+    fprintf(stderr, "[basin stats]   wave 0 of it: %llu passes; clocks waiting for the other wave %llu, from there to the first poll (stores, record / far loads, classify) %llu, inside turns %llu\n", h[6], h[4], h[7], h[5]);
 }
 
 void basin_free(wo_planet* p) {

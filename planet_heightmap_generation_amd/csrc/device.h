@@ -89,7 +89,8 @@ struct Options {
     bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror
     bool sortLibrary = false;          // WO_SORT=hipcub           the library's radix sort instead of radix.hip
     bool basinBarrierKernel = false;   // WO_BASIN_KERNEL=barrier  k_solve_coop (one barrier per super-chunk) instead of k_solve_flowing
-    bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr
+    bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr (=2: without the depth bookkeeping, which doubles the kernel's time)
+    bool basinStatsNoDepth = false;
     bool basinScramble = false;        // WO_BASIN_SCRAMBLE=1      test hook: a deliberately wrong layout (leftovers for the patch finisher)
     bool tileLds = false;              // WO_TILE_LDS=1            neighbour window of a workgroup's tile staged in LDS
     bool noSolvePatch = false;         // WO_NO_SOLVE_PATCH        level-synchronous solve rounds

@@ -1188,7 +1188,7 @@ Options Options::from_env() {
     o.layoutIndex = str("WO_LAYOUT") == "index";
     o.sortLibrary = str("WO_SORT") == "hipcub";
     o.basinBarrierKernel = str("WO_BASIN_KERNEL") == "barrier";
-    o.basinStats = on("WO_BASIN_STATS");
+    o.basinStats = on("WO_BASIN_STATS"); o.basinStatsNoDepth = str("WO_BASIN_STATS") == "2";
     o.basinScramble = on("WO_BASIN_SCRAMBLE");
     o.tileLds = on("WO_TILE_LDS");
     o.noSolvePatch = set("WO_NO_SOLVE_PATCH");
