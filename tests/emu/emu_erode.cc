@@ -613,3 +613,36 @@ extern "C" int emu_assign_elevation(int32_t N, const int32_t* off, const int32_t
 }
 
 extern "C" double emu_pair_intensity(int32_t a, int32_t b) { return pair_intensity(a, b); }
+
+// The two forms of a solve turn (erode_ops.h): solve_apply, as the serial loop writes it, and solve_apply_flat, every expression
+// evaluated and selected (what a wave of k_solve_flowing runs for whichever lanes are ready).  n random tasks over every flag
+// combination, heights and factors of the magnitudes the solve sees plus the awkward ones (0, equal heights, huge / tiny factors,
+// missing t2 with cellDistT 0); returns the number of tasks whose outputs differ in any bit.
+extern "C" int64_t emu_solve_turn_forms_differ(int64_t n, uint64_t seed) {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    auto unit = [&]() { return (double)(rnd() >> 11) / 9007199254740992.0; };
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        SolveTask T{};
+        const uint32_t combo = (uint32_t)(rnd() % 7);
+        // flags: bit0 target is ocean, bit1 t2 is ocean, bit2 has a target, bit3 has a t2
+        static const uint32_t kFlags[7] = {0u, 4u, 4u | 1u, 4u | 8u, 4u | 8u | 2u, 4u | 8u, 4u};
+        T.flags = kFlags[combo];
+        auto height = [&]() { const uint64_t k = rnd() % 10; return k == 0 ? 0.0f : k == 1 ? 1e-7f : k == 2 ? 1.5f : (float)(unit() * 1.3); };
+        float er = height(), et = height(), et2 = height();
+        if (rnd() % 8 == 0) et = er;                      // flats
+        if (rnd() % 8 == 0) et2 = et;
+        if (rnd() % 16 == 0) et = -et;                    // (heights below zero reach the clamp)
+        const uint64_t fk = rnd() % 12;
+        T.factor = fk == 0 ? 0.0 : fk == 1 ? 1e-300 : fk == 2 ? 1e30 : fk == 3 ? 1e-12 : unit() * std::pow(10.0, (double)(int)(rnd() % 7) - 3.0);
+        T.cellDistT = (T.flags & 8u) ? (float)(1e-4 + unit() * 2e-3) : 0.0f;
+        if ((T.flags & 8u) && rnd() % 16 == 0) T.cellDistT = 1e-6f;
+        T.e0r = er; T.e0t = et; T.e0t2 = et2;
+        const SolvePrepared P = solve_prepare(T, 3e-4, 0.5, 1.0);
+        const SolveOut a = solve_apply(T, P, (double)er, (double)et, (double)et2, 7);
+        const SolveOut b = solve_apply_flat(T, P, (double)er, (double)et, (double)et2, 7);
+        if (std::memcmp(&a, &b, sizeof(a)) != 0) ++bad;
+    }
+    return bad;
+}

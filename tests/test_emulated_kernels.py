@@ -122,3 +122,15 @@ def test_solve_event_lists_equal_row_scans(emu, oracle, monkeypatch):
         rc = emu.emu_erode_composite(mesh.numRegions, P(mesh.adjOffset), P(mesh.adjList), P(e), P(xyz), P(oc), 9, 3e-4, 0.5, 1.0, 9,
                                      1.16, 0.015, 0, 0.8, P(nd), P(stats))
         assert rc == 0 and np.array_equal(e, ref), (off, int((e != ref).sum()))
+
+
+def test_the_branch_free_solve_turn_equals_the_plain_one(emu):
+    """erode_ops.h: solve_apply_flat (what a wave of the basin solve runs for whichever lanes are ready: every expression
+    evaluated, the conditions select) against solve_apply (the serial loop's turn) on two million random tasks over all flag
+    combinations and the awkward operands: not one output bit may differ."""
+    import ctypes as C
+    L = emu
+    L.emu_solve_turn_forms_differ.restype = C.c_int64
+    L.emu_solve_turn_forms_differ.argtypes = [C.c_int64, C.c_uint64]
+    for seed in (1, 2, 3, 4):
+        assert L.emu_solve_turn_forms_differ(500000, seed) == 0
