@@ -104,6 +104,8 @@ struct KeyHeap4 {
     hvec<HeapItem>& d;
     size_t n = 0;
     explicit KeyHeap4(hvec<HeapItem>& storage) : d(storage) {}
+    const HeapItem* front() const { return d.data(); }        // [0] is the next pop; the first few entries are the likely next ones (prefetch hints)
+    size_t front_count() const { return n; }
     void push(int32_t c, float kc) {
         size_t i = n++;
         if (d.size() < n + 8) d.resize(d.size() * 2 + 1024);
@@ -291,7 +293,7 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
         });
         for (auto& v : part) S.seedCell.insert(S.seedCell.end(), v.begin(), v.end());      // ranges ascend with the thread index
     }
-    S.surface.resize(L); S.state.resize(L); S.root.resize(L); S.eL.resize(L);
+    S.surface.resize(L); S.state.resize(L); S.root.resize(L); S.eL.resize(L); S.localIdx.resize(L);
     S.order.resize(L); S.order2.resize(L); S.bits.resize(L); S.bits2.resize(L); S.list2.resize(L);
     lap("seeds+alloc");
     {   // Landmasses: connected components of the compact land graph.  The flood never crosses water (ocean cells are
@@ -375,8 +377,11 @@ void flood_gather(const float* e, FloodScratch& S) {
     const int32_t* landCell = S.landCell.data();
     float* eL = S.eL.data();
     FloodCell* st = S.state.data();
+    if ((int32_t)S.seen.size() < L) S.seen.resize(L);
+    uint8_t* seen = S.seen.data();
     parallel_ranges(L, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
+        std::memset(seen + b, 0, (size_t)(en - b));
     });
 }
 
@@ -472,21 +477,28 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
     const float* eL = S.eL.data();
     FloodCell* st = S.state.data();
     int32_t* stamp = S.stamp.data();
+    // "claimed?" is asked six times per pop and answered from one byte per cell (the landmass's share of `seen` stays in the core's
+    // L2; the 16-byte records it used to be read from are 4 lines per pop that the frontier, which jumps all over the landmass, had
+    // to fetch from further away); heights come from the compact eL (this landmass's passes 2/3, the only writers of its eL, run
+    // after its walk).  The records are only written here (claims) and read for the popped cell (prefetched while it nears the top).
+    uint8_t* seen = S.seen.data();
     if (store.size() < 1024) store.resize(1024);
     Heap heap(store);             // any exact priority queue will do here (see KeyHeap4)
     for (int32_t q = 0; q < nSeeds; ++q) {                  // :118-128, ascending r
         const int32_t s = seeds[q], i = S.seedCell[s];
         st[i].drain = TO_OCEAN;
         st[i].root = s;
+        seen[i] = 1;
         heap.push(i, (float)((double)eL[i] + cell_noise(landCell[i])));
     }
     int32_t famCounter = 0;
     TieGroup groups[64]; int nOpen = 0;
     while (heap.n > 0) {
-        const float kc = store.data()[0].key;
+        const float kc = heap.front()[0].key;
         const int32_t c = heap.pop();
-        const FloodHeapItem* hp = store.data();
-        const bool tieTop = heap.n > 0 && hp[0].key == kc;
+        const FloodHeapItem* hp = heap.front();
+        const size_t nFront = heap.front_count();
+        const bool tieTop = nFront > 0 && hp[0].key == kc;
         if (tieTop || nOpen) {
             while (nOpen && kc > groups[nOpen - 1].level) --nOpen;
             if (nOpen && kc == groups[nOpen - 1].level) groups[nOpen - 1].fam = ++famCounter;       // the next tied cell: a new family
@@ -496,16 +508,12 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
             }
         }
         {
-            const size_t lim2 = heap.n < 7 ? heap.n : 7;
+            const size_t lim2 = nFront < 7 ? nFront : 7;
             for (size_t q = 0; q < lim2; ++q) {
                 const int32_t cc = hp[q].cell;
                 __builtin_prefetch(&offL[cc]); __builtin_prefetch(&st[cc]);
             }
-            if (heap.n > 0) {
-                const int32_t c0 = hp[0].cell;
-                for (int32_t j = offL[c0]; j < offL[c0 + 1]; ++j) __builtin_prefetch(&st[adjL[j]]);
-            }
-            for (size_t q = 1; q < lim2 && q < 3; ++q) __builtin_prefetch(&adjL[offL[hp[q].cell]]);
+            for (size_t q = 0; q < lim2 && q < 3; ++q) __builtin_prefetch(&adjL[offL[hp[q].cell]]);
         }
         const int32_t curFam = nOpen ? groups[nOpen - 1].fam : 0;
         const double lim = (double)st[c].surface + EPS;
@@ -513,8 +521,7 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
         const int32_t rootC = st[c].root;
         for (int32_t i = offL[c]; i < iEnd; ++i) {
             const int32_t nb = adjL[i];
-            FloodCell& sn = st[nb];
-            if (sn.drain != UNVISITED) {
+            if (seen[nb]) {
                 if (curFam) {
                     const int32_t sv = stamp[nb];
                     if (sv) for (int g = 0; g < nOpen; ++g)
@@ -522,15 +529,18 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
                 }
                 continue;
             }
+            seen[nb] = 1;
+            FloodCell& sn = st[nb];
             sn.drain = c;
             sn.root = rootC;
             if (curFam) stamp[nb] = curFam;
+            const double en = (double)eL[nb];
             float k;
-            if ((double)sn.e < lim) {
+            if (en < lim) {
                 sn.surface = (float)lim;
                 k = (float)((double)sn.surface + cell_noise(landCell[nb]));
             } else {
-                k = (float)((double)sn.e + cell_noise(landCell[nb]));
+                k = (float)(en + cell_noise(landCell[nb]));
             }
             heap.push(nb, k);
         }
@@ -538,7 +548,14 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
 }
 void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
                    std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
-    walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);      // (the binary heap was measured slower: 35 against 31-32 ms for the 402 k-cell landmass)
+    // Where a walk's time goes (round 4, the 402 k-cell landmass in the build container, research/flood_walk_bench.py; the op log of the walk
+    // replayed on the queue alone, and the recorded pop order replayed on the expansion alone): queue 20-24 ms, expansion 15-20 ms (13-17 with
+    // every row prefetched, 12-16 without the noise hash).  The heap holds 11 600 entries on average, 88 % of the pops come out in ascending
+    // order, 86 % of the pushes carry the cell's own key (height + noise), 14 % a raised one.  Tried on the queue: a ring of 1024 unsorted
+    // buckets of width 2^-15 with only the current bucket a heap — exact, 16-20 ms on the replay, 5-10 % of a real walk: not kept; the binary
+    // heap: slower (35 against 31-32 ms on the GPU box).  What would halve the queue (replay: 8.7 ms): ranks of the cells' own keys sorted
+    // beforehand, the frontier a bitmap over the ranks, a heap for the raised keys only — the sort has to come from somewhere off the critical path.
+    walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
 }
 int flood_workers(int64_t items) {
     static const int capThreads = [] { const char* e = std::getenv("WO_FLOOD_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 24; }();
@@ -613,7 +630,123 @@ void flood_import_pass1(const int32_t* par, const float* surface, const int32_t*
 // Passes 2 and 3 of one drainage tree (:152-214).  cells: the tree's land indices in ascending ORIGINAL id (the order pass 2
 // visits them in); on return sorted by (surface, id), the order of pass 3.  surface may be null (then st[].surface).
 namespace {
-struct TreeCtx { const FloodCell* st; float* eL; const float* surface; double carveStrength; uint8_t* onPath; };
+struct TreeCtx { const FloodCell* st; float* eL; const float* surface; double carveStrength; uint8_t* onPath; int32_t* localIdx = nullptr; int32_t chainsMin = 0; };
+
+// Pass 2 of a BIG tree (:152-196), same turns in the same order on the same values, laid out for the memory system.  A turn of the
+// reference walks the whole drain path of its cell (find the peak), then rewrites a window of 0.6 x its length around the peak: in
+// the 41 k-cell tree of the bench planet's largest landmass that is 20 k turns x 360 cells = 7.2 M dependent pointer steps
+// through 16-byte records plus as many gathered read-modify-writes, 15-20 ms on one thread AFTER the landmass's walk — the tail
+// of the flood stage.  Here the tree is first cut into chains (heavy-path decomposition: every cell continues its chain into the
+// child with the largest subtree, so a path to the sea crosses at most log2(n) chains) and the heights are copied into one
+// array in chain order, upstream end first: the drain path of any cell is then a handful of contiguous stretches, the peak
+// search is a linear scan, the carve a linear read-modify-write with the weights (which depend on the distance to the peak only)
+// taken from a small array computed once per turn instead of twice.  The arithmetic is the reference's, expression for expression
+// (kernel sum accumulated in path order, weight = term / sum, float store, clamp at 0).  Returns false (nothing changed) if the
+// tree is not a single rooted tree of claimed cells — the caller then takes the plain form.
+// trees of at least this many cells take the chain form (WO_FLOOD_CHAINS_MIN, read per call: the tests run both forms; 0 = never)
+inline int32_t flood_chains_min() { const char* v = std::getenv("WO_FLOOD_CHAINS_MIN"); return v ? std::atoi(v) : 2048; }
+struct ChainScratch {
+    std::vector<int32_t> par, kids, kidStart, order, sz, heavy, posOf, headPos, jump, cellAt;
+    std::vector<float> E;
+    std::vector<double> term;
+};
+bool tree_pass2_chains(const TreeCtx& X, const int32_t* cells, int32_t n, int64_t& lenSum, int64_t& nDeficit) {
+    const double EPS = 1e-7;
+    static thread_local ChainScratch C;
+    const FloodCell* st = X.st;
+    float* eL = X.eL;
+    int32_t* loc = X.localIdx;
+    const double carveStrength = X.carveStrength;
+    auto surf = [&](int32_t i) { return X.surface ? X.surface[i] : st[i].surface; };
+    for (int32_t q = 0; q < n; ++q) loc[cells[q]] = q;
+    C.par.resize(n); C.kidStart.assign((size_t)n + 1, 0);
+    int32_t rootQ = -1, nRoots = 0;
+    for (int32_t q = 0; q < n; ++q) {
+        const int32_t d = st[cells[q]].drain;
+        if (d >= 0) { const int32_t pq = loc[d]; if (pq < 0 || pq >= n || cells[pq] != d) return false; C.par[q] = pq; ++C.kidStart[pq + 1]; }
+        else { C.par[q] = -1; rootQ = q; ++nRoots; }
+    }
+    if (nRoots != 1) return false;
+    for (int32_t q = 0; q < n; ++q) C.kidStart[q + 1] += C.kidStart[q];
+    C.kids.resize(n); C.order.resize(n);
+    {   // children lists, then breadth-first order from the seed cell (parents before children)
+        std::vector<int32_t>& fill = C.sz; fill.assign(C.kidStart.begin(), C.kidStart.end() - 1);
+        for (int32_t q = 0; q < n; ++q) if (C.par[q] >= 0) C.kids[fill[C.par[q]]++] = q;
+        int32_t head = 0, tail = 0;
+        C.order[tail++] = rootQ;
+        while (head < tail) { const int32_t v = C.order[head++]; for (int32_t j = C.kidStart[v]; j < C.kidStart[v + 1]; ++j) C.order[tail++] = C.kids[j]; }
+        if (tail != n) return false;                        // a cycle or a second component: not a tree
+    }
+    C.sz.assign(n, 1); C.heavy.assign(n, -1);
+    for (int32_t i = n - 1; i > 0; --i) { const int32_t v = C.order[i]; C.sz[C.par[v]] += C.sz[v]; }
+    for (int32_t i = 1; i < n; ++i) { const int32_t v = C.order[i], p = C.par[v]; if (C.heavy[p] < 0 || C.sz[v] > C.sz[C.heavy[p]]) C.heavy[p] = v; }
+    C.posOf.resize(n); C.headPos.resize(n); C.jump.assign(n, -1); C.cellAt.resize(n); C.E.resize(n);
+    {   // chain by chain in breadth-first order of the chain heads: positions grow towards the sea inside a chain
+        int32_t base = 0;
+        for (int32_t i = 0; i < n; ++i) {
+            const int32_t v = C.order[i];
+            if (C.par[v] >= 0 && C.heavy[C.par[v]] == v) continue;         // continues its parent's chain
+            int32_t m = 0;
+            for (int32_t u = v; u >= 0; u = C.heavy[u]) ++m;
+            const int32_t top = base + m - 1;
+            int32_t at = top;
+            for (int32_t u = v; u >= 0; u = C.heavy[u], --at) { C.posOf[u] = at; C.headPos[at] = top; C.cellAt[at] = cells[u]; C.E[at] = eL[cells[u]]; }
+            C.jump[top] = C.par[v] >= 0 ? C.posOf[C.par[v]] : -1;        // the head's receiver: its chain was laid out earlier
+            base += m;
+        }
+    }
+    float* E = C.E.data();
+    const int32_t* headPos = C.headPos.data();
+    const int32_t* jump = C.jump.data();
+    int32_t segA[64], segB[64], segK[64];
+    for (int32_t q = 0; q < n; ++q) {
+        const int32_t r = cells[q], pr = C.posOf[q];
+        const double deficit = (double)surf(r) - (double)E[pr];      // against the CURRENT height (:154)
+        if (deficit <= EPS) continue;
+        ++nDeficit;
+        int nseg = 0; int32_t len = 0, peakIdx = -1;
+        float peakElev = -INFINITY;
+        for (int32_t a = pr; a >= 0;) {
+            const int32_t b = headPos[a];
+            segA[nseg] = a; segB[nseg] = b; segK[nseg] = len; ++nseg;
+            for (int32_t p = a; p <= b; ++p) if (E[p] > peakElev) { peakElev = E[p]; peakIdx = len + (p - a); }
+            len += b - a + 1;
+            a = jump[b];
+        }
+        if (X.onPath) for (int s = 0; s < nseg; ++s) for (int32_t p = segA[s]; p <= segB[s]; ++p) X.onPath[C.cellAt[p]] = 1;
+        lenSum += len;
+        if (peakIdx < 0) continue;
+        const double carveAmount = deficit * carveStrength;
+        const double rc = std::ceil((double)len * 0.3);
+        const int32_t radius = rc > 3.0 ? (int32_t)rc : 3;
+        const int32_t k0 = peakIdx - radius > 0 ? peakIdx - radius : 0;
+        const int32_t k1 = peakIdx + radius < len - 1 ? peakIdx + radius : len - 1;
+        const int32_t m = k1 - k0 + 1;
+        if ((int32_t)C.term.size() < m) C.term.resize((size_t)m + 256);
+        double* term = C.term.data();
+        for (int32_t i = 0; i < m; ++i) term[i] = 1 - std::fabs((double)(k0 + i - peakIdx)) / (radius + 1);
+        double kernelSum = 0;
+        for (int32_t i = 0; i < m; ++i) kernelSum += term[i];
+        if (kernelSum > 0) {
+            for (int s = 0; s < nseg; ++s) {
+                const int32_t ks = segK[s], ke = ks + (segB[s] - segA[s]);
+                const int32_t lo = k0 > ks ? k0 : ks, hi = k1 < ke ? k1 : ke;
+                float* Es = E + (segA[s] - ks);
+                const double* ts = term - k0;
+                for (int32_t k = lo; k <= hi; ++k) {
+                    const double w = ts[k] / kernelSum;
+                    float v = (float)((double)Es[k] - carveAmount * w);
+                    if (v < 0) v = 0;
+                    Es[k] = v;
+                }
+            }
+        }
+        E[pr] = (float)((double)E[pr] + deficit * (1 - carveStrength));
+    }
+    for (int32_t q = 0; q < n; ++q) eL[cells[q]] = E[C.posOf[q]];
+    return true;
+}
+
 void tree_pass23(const TreeCtx& X, int32_t* cells, int32_t n, std::vector<int32_t>& path, int64_t& lenSum, int64_t& nDeficit) {
     const double EPS = 1e-7;
     const FloodCell* st = X.st;
@@ -621,7 +754,9 @@ void tree_pass23(const TreeCtx& X, int32_t* cells, int32_t n, std::vector<int32_
     const double carveStrength = X.carveStrength;
     uint8_t* onPath = X.onPath;
     auto surf = [&](int32_t i) { return X.surface ? X.surface[i] : st[i].surface; };
-    for (int32_t q = 0; q < n; ++q) {
+    const bool chained = X.localIdx && X.chainsMin > 0 && n >= X.chainsMin && tree_pass2_chains(X, cells, n, lenSum, nDeficit);
+
+    for (int32_t q = 0; q < n && !chained; ++q) {
         const int32_t r = cells[q];
         const double deficit = (double)surf(r) - (double)eL[r];      // against the CURRENT height (:154)
         if (deficit <= EPS) continue;
@@ -772,7 +907,7 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
     };
     T.lap("group2");
     std::atomic<int64_t> nDeficit{0}, totLen{0};
-    const TreeCtx ctx{st, eL, surface, carveStrength, onPath};
+    const TreeCtx ctx{st, eL, surface, carveStrength, onPath, S.localIdx.data(), flood_chains_min()};
     for_trees(cnt2, [&](int32_t tree) {
         static thread_local std::vector<int32_t> path;
         int64_t myLen = 0, myDef = 0;
@@ -926,8 +1061,9 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     float* eL = S.eL.data();
     int32_t* list2 = S.list2.data();
     constexpr int32_t BIG = 32768, CHUNK = 4096;
+    const int32_t chainsMin = flood_chains_min();
     struct BigJob {
-        int32_t k = -1; std::vector<int32_t> cnt, chunkStart; bool track = false;
+        int32_t k = -1; std::vector<int32_t> cnt, chunkStart, chunkOrder; bool track = false;
         std::atomic<int> ready{0}; std::atomic<size_t> nextChunk{0}, doneChunks{0};
     };
     struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; std::vector<int32_t> altComp; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; };
@@ -943,15 +1079,27 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         std::vector<BigJob> big(nBig);
         std::atomic<int32_t> next{0}, bigLeft{nBig};
         auto run_chunks = [&](BigJob& J, std::vector<int32_t>& path) {
-            const TreeCtx ctx{st, eL, nullptr, carveStrength, J.track ? S.onPath.data() : nullptr};
+            const TreeCtx ctx{st, eL, nullptr, carveStrength, J.track ? S.onPath.data() : nullptr, S.localIdx.data(), chainsMin};
             const size_t nChunks = J.chunkStart.size() - 1;
             const int32_t base = S.compCellStart[J.k];
             for (;;) {
-                const size_t c = J.nextChunk.fetch_add(1);
-                if (c >= nChunks) break;
+                const size_t cq = J.nextChunk.fetch_add(1);
+                if (cq >= nChunks) break;
+                const size_t c = (size_t)J.chunkOrder[cq];
                 int64_t a = 0, b = 0;
                 for (int32_t t = J.chunkStart[c]; t < J.chunkStart[c + 1]; ++t)
-                    if (J.cnt[t + 1] > J.cnt[t]) tree_pass23(ctx, list2 + base + J.cnt[t], J.cnt[t + 1] - J.cnt[t], path, a, b);
+                    if (J.cnt[t + 1] > J.cnt[t]) {
+                        const int32_t nT = J.cnt[t + 1] - J.cnt[t];
+                        const bool timed = T.on && nT >= 16384;
+                        const auto tt0 = timed ? std::chrono::steady_clock::now() : tRound0;
+                        const int64_t a0 = a, b0 = b;
+                        tree_pass23(ctx, list2 + base + J.cnt[t], nT, path, a, b);
+                        if (timed) {
+                            const auto now = std::chrono::steady_clock::now();
+                            std::fprintf(stderr, "[flood] landmass %d: tree of %d cells, passes 2+3 %.2f ms (%lld deficit cells, %lld path steps), done at %.1f ms\n", J.k, nT,
+                                         std::chrono::duration<double, std::milli>(now - tt0).count(), (long long)(b - b0), (long long)(a - a0), std::chrono::duration<double, std::milli>(now - tRound0).count());
+                        }
+                    }
                 if (J.doneChunks.fetch_add(1) + 1 == nChunks) bigLeft.fetch_sub(1);
             }
         };
@@ -1018,10 +1166,14 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     J.chunkStart.clear(); J.chunkStart.push_back(0);
                     for (int32_t t = 0, last = 0; t < nTrees; ++t) if (c[t + 1] - c[last] >= CHUNK) { J.chunkStart.push_back(t + 1); last = t + 1; }
                     if (J.chunkStart.back() != nTrees) J.chunkStart.push_back(nTrees);
+                    // biggest chunks first: the largest tree (41 k of this landmass's 402 k cells on the bench planet) is the longest single job of the tail
+                    J.chunkOrder.resize(J.chunkStart.size() - 1);
+                    for (size_t x = 0; x < J.chunkOrder.size(); ++x) J.chunkOrder[x] = (int32_t)x;
+                    std::stable_sort(J.chunkOrder.begin(), J.chunkOrder.end(), [&](int32_t x, int32_t y) { return c[J.chunkStart[x + 1]] - c[J.chunkStart[x]] > c[J.chunkStart[y + 1]] - c[J.chunkStart[y]]; });
                     J.ready.store(1, std::memory_order_release);
                     run_chunks(J, path);
                 } else {
-                    const TreeCtx ctx{st, eL, nullptr, carveStrength, track ? S.onPath.data() : nullptr};
+                    const TreeCtx ctx{st, eL, nullptr, carveStrength, track ? S.onPath.data() : nullptr, S.localIdx.data(), chainsMin};
                     int64_t a = 0, b = 0;
                     for (int32_t t = 0; t < nTrees; ++t) if (c[t + 1] > c[t]) tree_pass23(ctx, list2 + base + c[t], c[t + 1] - c[t], path, a, b);
                 }

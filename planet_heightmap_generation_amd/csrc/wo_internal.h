@@ -35,6 +35,8 @@ struct FloodScratch {
     std::vector<int32_t> compCellStart;      // per seeded landmass: its cells in compCells (ascending original id inside)
     hvec<int32_t> compCells, seedLocal;      // seedLocal[s]: position of seed s among its landmass's seeds
     hvec<int32_t> stamp;                     // tie-family id of the claim that reached a cell (0 = outside any tie group)
+    hvec<int32_t> localIdx;                  // pass 2 of a big tree: a cell's position in its tree's cell list (tree_pass2_chains)
+    hvec<uint8_t> seen;                      // pass 1 of the landmass walks: the cell has been claimed (one byte per land cell)
     hvec<uint8_t> onPath;                    // pass 2: the cell lay on a carve path (only tracked when pass 1 left open parents)
     std::vector<hvec<FloodHeapItem>> workerHeaps;
     // replay of the single heap (flood_host.cc: replay_dirty_landmasses)
