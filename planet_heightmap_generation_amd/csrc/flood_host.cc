@@ -467,9 +467,10 @@ namespace {
 struct TieGroup { float level; int32_t firstFam, fam; };
 struct Contest { int32_t cell, other; float level; };
 
-template <class Heap>
+struct WalkStats { int64_t pops = 0, descending = 0, raised = 0, heapSum = 0, heapMax = 0; };     // WO_FLOOD_TIMING: the largest landmass's walk
+template <class Heap, bool STATS = false>
 void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
-                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
+                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats* ws = nullptr) {
     const double EPS = 1e-7;
     const int32_t* landCell = S.landCell.data();
     const int32_t* offL = S.offL.data();
@@ -493,8 +494,10 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
     }
     int32_t famCounter = 0;
     TieGroup groups[64]; int nOpen = 0;
+    float highest = -INFINITY;
     while (heap.n > 0) {
         const float kc = heap.front()[0].key;
+        if (STATS) { ++ws->pops; ws->heapSum += (int64_t)heap.n; if ((int64_t)heap.n > ws->heapMax) ws->heapMax = (int64_t)heap.n; if (kc < highest) ++ws->descending; else highest = kc; }
         const int32_t c = heap.pop();
         const FloodHeapItem* hp = heap.front();
         const size_t nFront = heap.front_count();
@@ -539,12 +542,17 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
             if (en < lim) {
                 sn.surface = (float)lim;
                 k = (float)((double)sn.surface + cell_noise(landCell[nb]));
+                if (STATS) ++ws->raised;
             } else {
                 k = (float)(en + cell_noise(landCell[nb]));
             }
             heap.push(nb, k);
         }
     }
+}
+void walk_landmass_with_stats(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
+                              std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats& ws) {
+    walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
 }
 void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
                    std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
@@ -1115,11 +1123,14 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     // --- pass 1 of landmass k
                     me.contests.clear();
                     const auto tw0 = std::chrono::steady_clock::now();
-                    walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
+                    WalkStats ws;
+                    if (T.on && q == 0) walk_landmass_with_stats(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested, ws);
+                    else walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
                     // (measured and dropped in round 3: a bucket queue — 2^16 buckets of width 2^-14 behind a two-level bitmap — instead of the
                     // binary heap for the walks, which do not depend on the order of equal keys: 83-130 ms against 45-60 ms for this landmass in
                     // the build container; the heap of one landmass stays in cache, the buckets' vectors do not)
-                    if (T.on && q == 0) std::fprintf(stderr, "[flood] walk of the largest landmass (%d cells): %.1f ms\n", S.compSize[k], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
+                    if (T.on && q == 0) std::fprintf(stderr, "[flood] walk of the largest landmass (%d cells): %.1f ms; heap mean %lld max %lld entries, %lld pops below the level reached, %lld raised keys, %d seeds\n", S.compSize[k], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(),
+                                                     (long long)(ws.heapSum / std::max<int64_t>(ws.pops, 1)), (long long)ws.heapMax, (long long)ws.descending, (long long)ws.raised, S.compSeedStart[k + 1] - S.compSeedStart[k]);
                     const size_t alt0 = me.alt.size();
                     for (const Contest& ct : me.contests) {
                         ++me.contested;
