@@ -106,6 +106,7 @@ struct KeyHeap4 {
     explicit KeyHeap4(hvec<HeapItem>& storage) : d(storage) {}
     const HeapItem* front() const { return d.data(); }        // [0] is the next pop; the first few entries are the likely next ones (prefetch hints)
     size_t front_count() const { return n; }
+    void prime() {}
     void push(int32_t c, float kc) {
         size_t i = n++;
         if (d.size() < n + 8) d.resize(d.size() * 2 + 1024);
@@ -141,6 +142,69 @@ struct KeyHeap4 {
             h[i] = last;
         }
         return top;
+    }
+};
+
+// A queue for walks whose heap grows large.  The second flood of a step meets eroded terrain: 86 % of the cells of the bench planet's
+// largest landmass are pushed with a RAISED key (level + EPS + noise, noise < 0.01) and wait for the level to pass their noise, so the
+// heap holds 100 000 entries on average (170 000 at most; 11 600 in the first flood) — nine levels of a 4-ary heap over 800 KB.  All
+// these keys sit within ~0.01 of the level.  So: buckets of width 2^-15 on a ring of 1024 (a window of 0.031 above the current bucket),
+// unsorted; only the CURRENT bucket is a heap (a few hundred entries), which also takes every key below it; keys beyond the window go
+// to an ordinary heap and come back when the ring reaches them.  A push is an append, a pop works on a small heap.  Exact: the
+// bucket index is a monotone function of the key, the current heap orders by the key itself, and equal keys always share a bucket
+// (the tie test of the walk looks at the next key of the current heap: once that heap is empty every remaining key is strictly larger).
+struct RingQueue {
+    static constexpr int NB = 1024;
+    static constexpr int64_t FAR_BELOW = -(int64_t(1) << 40);
+    KeyHeap4 cur, over;
+    size_t n = 0;
+    int64_t b0 = FAR_BELOW;                              // until prime(): every push goes to `over`
+    struct Ring { std::vector<HeapItem> b[NB]; uint64_t occ[NB / 64]; hvec<HeapItem> overStore; };
+    Ring& R;
+    static Ring& ring() { static thread_local Ring* r = new Ring(); return *r; }
+    explicit RingQueue(hvec<HeapItem>& storage) : cur(storage), over(ring().overStore), R(ring()) {
+        if (R.overStore.size() < 1024) R.overStore.resize(1024);
+        std::memset(R.occ, 0, sizeof(R.occ));
+        for (auto& v : R.b) v.clear();
+    }
+    static int64_t bucket_of(float k) { return (int64_t)(k * 32768.0f); }      // exact scaling; truncation is monotone
+    const HeapItem* front() const { return cur.d.data(); }
+    size_t front_count() const { return cur.n; }
+    void push(int32_t c, float k) {
+        ++n;
+        const int64_t bi = bucket_of(k);
+        if (bi <= b0) cur.push(c, k);
+        else if (bi - b0 < NB) { const int s = (int)(bi & (NB - 1)); R.b[s].push_back(HeapItem{k, c}); R.occ[s >> 6] |= 1ull << (s & 63); }
+        else over.push(c, k);
+    }
+    void advance() {                                       // cur is empty, n > 0: the next occupied bucket becomes the current one
+        int64_t br = INT64_MAX;
+        {
+            const int start = (int)((b0 + 1) & (NB - 1));
+            int w = start >> 6; uint64_t m = R.occ[w] & (~0ull << (start & 63));
+            for (int step = 0; step <= NB / 64; ++step) {
+                if (m) { const int s = (w << 6) + __builtin_ctzll(m); br = b0 + 1 + ((s - start) & (NB - 1)); break; }
+                w = (w + 1) & (NB / 64 - 1);
+                m = R.occ[w];
+                if (step == NB / 64 - 1) m &= ~(~0ull << (start & 63));       // back at the first word: the bits before `start`
+            }
+        }
+        const int64_t bo = over.n ? bucket_of(over.d.data()[0].key) : INT64_MAX;
+        const int64_t b = br < bo ? br : bo;
+        b0 = b;
+        if (br == b) {
+            const int s = (int)(b & (NB - 1));
+            for (const HeapItem& it : R.b[s]) cur.push(it.cell, it.key);
+            R.b[s].clear(); R.occ[s >> 6] &= ~(1ull << (s & 63));
+        }
+        while (over.n && bucket_of(over.d.data()[0].key) <= b) { const float k = over.d.data()[0].key; const int32_t c = over.pop(); cur.push(c, k); }
+    }
+    void prime() { if (cur.n == 0 && n > 0) advance(); }
+    int32_t pop() {
+        const int32_t c = cur.pop();
+        --n;
+        if (cur.n == 0 && n > 0) advance();
+        return c;
     }
 };
 
@@ -492,6 +556,7 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
         seen[i] = 1;
         heap.push(i, (float)((double)eL[i] + cell_noise(landCell[i])));
     }
+    heap.prime();
     int32_t famCounter = 0;
     TieGroup groups[64]; int nOpen = 0;
     float highest = -INFINITY;
@@ -550,20 +615,27 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
         }
     }
 }
-void walk_landmass_with_stats(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
+// landmasses of at least WO_FLOOD_RING_MIN cells (default 4096; read per call: the tests run both queues) walk on the ring queue
+inline bool walk_on_ring(int32_t nCells) { const char* v = std::getenv("WO_FLOOD_RING_MIN"); return nCells >= (v ? std::atoi(v) : 4096); }
+void walk_landmass_with_stats(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
                               std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats& ws) {
-    walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
+    if (walk_on_ring(nCells)) walk_landmass_h<RingQueue, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
+    else walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
 }
-void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
+void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
                    std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
-    // Where a walk's time goes (round 4, the 402 k-cell landmass in the build container, research/flood_walk_bench.py; the op log of the walk
-    // replayed on the queue alone, and the recorded pop order replayed on the expansion alone): queue 20-24 ms, expansion 15-20 ms (13-17 with
-    // every row prefetched, 12-16 without the noise hash).  The heap holds 11 600 entries on average, 88 % of the pops come out in ascending
-    // order, 86 % of the pushes carry the cell's own key (height + noise), 14 % a raised one.  Tried on the queue: a ring of 1024 unsorted
-    // buckets of width 2^-15 with only the current bucket a heap — exact, 16-20 ms on the replay, 5-10 % of a real walk: not kept; the binary
-    // heap: slower (35 against 31-32 ms on the GPU box).  What would halve the queue (replay: 8.7 ms): ranks of the cells' own keys sorted
-    // beforehand, the frontier a bitmap over the ranks, a heap for the raised keys only — the sort has to come from somewhere off the critical path.
-    walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
+    // Where a walk's time goes (round 4, the 402 k-cell landmass of the bench planet; research/flood_walk_bench.py replays the walk's op log
+    // on the queue alone and the recorded pop order on the expansion alone).  FIRST flood of a step (fresh terrain): heap 11 600 entries on
+    // average, 88 % of the pops in ascending order, 86 % of the pushes carry the cell's own key (height + noise); queue 20-24 ms and
+    // expansion 15-20 ms in the build container; 27-31 ms for the walk on the GPU box with either queue.  SECOND flood (after 150 erosion
+    // iterations): 86 % of the pushes carry a RAISED key (level + EPS + noise) and wait for the level to pass their noise — 100 000 entries on
+    // average, 170 000 at most, 44 % of the pops below the level already reached: 44.6-46.7 ms on the 4-ary heap, 34.1-36.9 ms on the ring
+    // (GPU box, bucket widths 2^-15 ... 2^-18 alike; no difference in the build container, whose cores have twice the L2).  The binary heap
+    // was slower than the 4-ary one (35 against 31-32 ms).  What would halve the first flood's queue (replay: 8.7 ms against 20): ranks of the
+    // cells' own keys sorted beforehand, the frontier a bitmap over the ranks, a heap for the raised keys only — the sort would have to come
+    // from somewhere off the critical path, and the second flood has few such keys.
+    if (walk_on_ring(nCells)) walk_landmass_h<RingQueue>(S, seeds, nSeeds, store, contests, nGroups, nNested);
+    else walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
 }
 int flood_workers(int64_t items) {
     static const int capThreads = [] { const char* e = std::getenv("WO_FLOOD_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 24; }();
@@ -589,7 +661,7 @@ bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep) {
         for (;;) {
             const int32_t k = next.fetch_add(1);
             if (k >= nComp) break;
-            walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], contests[w], ng[w], nn[w]);
+            walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], contests[w], ng[w], nn[w]);
         }
     };
     if (nt == 1) worker(0);
@@ -1124,8 +1196,8 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     me.contests.clear();
                     const auto tw0 = std::chrono::steady_clock::now();
                     WalkStats ws;
-                    if (T.on && q == 0) walk_landmass_with_stats(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested, ws);
-                    else walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
+                    if (T.on && q == 0) walk_landmass_with_stats(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], me.contests, me.groups, me.nested, ws);
+                    else walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
                     // (measured and dropped in round 3: a bucket queue — 2^16 buckets of width 2^-14 behind a two-level bitmap — instead of the
                     // binary heap for the walks, which do not depend on the order of equal keys: 83-130 ms against 45-60 ms for this landmass in
                     // the build container; the heap of one landmass stays in cache, the buckets' vectors do not)

@@ -17,7 +17,8 @@ subprocess.run(["make", "-s", "-C", str(REPO / "tests" / "emu")], check=True)
 L = C.CDLL(os.environ.get("WO_FWB_LIB", str(REPO / "tests" / "emu" / "_build" / "libemu.so")))    # WO_FWB_LIB: the same sources built another way (e.g. clang -O3, as libworogen is)
 p = C.c_void_p
 L.emu_flood_host.argtypes = [C.c_int32, p, p, p, p, p, C.c_double, C.c_int32, C.c_int32, p]
-cache = Path(os.environ.get("WO_FWB_CACHE", "/tmp")) / f"fwb_{cells}.npz"
+late = os.environ.get("WO_FWB_LATE")          # the planet after ~100 erosion iterations (research/make_late_terrain.py): what the second flood of a step meets
+cache = Path(os.environ.get("WO_FWB_CACHE", "/tmp")) / (f"fwb_{cells}_late.npz" if late else f"fwb_{cells}.npz")
 if cache.exists():                      # the planet of an earlier run of this script
     z = np.load(cache); xyz, e0 = z["xyz"], z["e0"]
     class M: pass
@@ -33,7 +34,7 @@ else:
         e0 = O.warp_terrain(om, O.synthetic_terrain(xyz, 1), xyz, 1, 0.75)
     print(f"terrain {time.time()-t:.1f} s", flush=True)
     np.savez(cache, xyz=xyz, e0=e0, off=mesh.adjOffset, adj=mesh.adjList)
-oc = (e0 <= 0).astype(np.uint8)
+oc = z["oc"] if (cache.exists() and "oc" in z.files) else (e0 <= 0).astype(np.uint8)
 P = lambda a: a.ctypes.data_as(p)
 e = e0.copy(); st = np.zeros(11)
 t = time.time()

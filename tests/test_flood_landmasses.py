@@ -302,3 +302,23 @@ def test_chain_form_of_the_carve_pass_equals_oracle(emu, oracle, chains_min, mon
             for mode in (1, 0):
                 e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, cs, mode)
                 assert np.array_equal(e, ref), (chains_min, cs, mode, int((e != ref).sum()), st)
+
+
+@pytest.mark.parametrize("ring_min", [1, 1 << 30])
+def test_both_walk_queues_equal_oracle(emu, oracle, ring_min, monkeypatch):
+    """The landmass walks pop from a ring of key buckets (flood_host.cc: RingQueue; landmasses of >= 4096 cells by default) or from the
+    4-ary heap.  WO_FLOOD_RING_MIN is read per call: every landmass / none on the ring.  Fresh terrain, terrain after erosion (most keys
+    raised: the heap grows large) and quantised terrain (equal keys everywhere: the tie bookkeeping reads the queue's next key)."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    monkeypatch.setenv("WO_FLOOD_RING_MIN", str(ring_min))
+    mesh, xyz, nd = S.build_sphere(50000, 0.75, 13)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    fresh = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, 13), xyz, 13, 0.75)
+    oc = (fresh <= 0).astype(np.uint8)
+    eroded = oracle.erode_composite(om, fresh, xyz, oc, 12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 2, 0.5, nd)
+    quant = np.where(oc == 1, fresh, np.maximum(np.floor(fresh * 512) / 512, 1.0 / 512)).astype(np.float32)
+    for name, e0 in (("fresh", fresh), ("eroded", eroded), ("quantised", quant)):
+        for cs in (0.5, 0.85):
+            ref = oracle.priority_flood_carve(om, e0, oc, cs)
+            e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, cs, 1)
+            assert np.array_equal(e, ref), (name, ring_min, cs, int((e != ref).sum()), st)
