@@ -534,7 +534,8 @@ struct Contest { int32_t cell, other; float level; };
 struct WalkStats { int64_t pops = 0, descending = 0, raised = 0, heapSum = 0, heapMax = 0; };     // WO_FLOOD_TIMING: the largest landmass's walk
 template <class Heap, bool STATS = false>
 void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
-                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats* ws = nullptr) {
+                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats* ws = nullptr,
+                   const FloodHeapItem* resume = nullptr, size_t nResume = 0) {
     const double EPS = 1e-7;
     const int32_t* landCell = S.landCell.data();
     const int32_t* offL = S.offL.data();
@@ -549,7 +550,9 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
     uint8_t* seen = S.seen.data();
     if (store.size() < 1024) store.resize(1024);
     Heap heap(store);             // any exact priority queue will do here (see KeyHeap4)
-    for (int32_t q = 0; q < nSeeds; ++q) {                  // :118-128, ascending r
+    if (resume) {                                           // a walk that the replay of the single heap began: its frontier, as that heap held it
+        for (size_t q = 0; q < nResume; ++q) heap.push(resume[q].cell, resume[q].key);
+    } else for (int32_t q = 0; q < nSeeds; ++q) {           // :118-128, ascending r
         const int32_t s = seeds[q], i = S.seedCell[s];
         st[i].drain = TO_OCEAN;
         st[i].root = s;
@@ -621,6 +624,11 @@ void walk_landmass_with_stats(FloodScratch& S, const int32_t* seeds, int32_t nSe
                               std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats& ws) {
     if (walk_on_ring(nCells)) walk_landmass_h<RingQueue, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
     else walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
+}
+void walk_landmass_resume(FloodScratch& S, const std::vector<FloodHeapItem>& frontier, int32_t nCells, hvec<FloodHeapItem>& store,
+                          std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
+    if (walk_on_ring(nCells)) walk_landmass_h<RingQueue>(S, nullptr, 0, store, contests, nGroups, nNested, nullptr, frontier.data(), frontier.size());
+    else walk_landmass_h<KeyHeap4>(S, nullptr, 0, store, contests, nGroups, nNested, nullptr, frontier.data(), frontier.size());
 }
 void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
                    std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
@@ -1020,7 +1028,10 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
 // reference's, in the same order, so its array — and with it every choice between equal keys — is the reference's.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
-void replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e) {
+// stopLevel: the replay ends as soon as the heap's smallest key exceeds it (+inf: runs to the end); then `frontier[k]` receives the
+// entries the heap still holds for dirty landmass k, in array order, and true is returned.  See flood_landmass_pipeline.
+bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e, float stopLevel,
+                             std::vector<std::vector<FloodHeapItem>>* frontier) {
     const double EPS = 1e-7;
     FloodTimer T;
     const int32_t L = S.L;
@@ -1041,6 +1052,7 @@ void replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
             for (int64_t q = b; q < en; ++q) {                       // back to the start state of pass 1 (flood_gather)
                 const int32_t i = cells[q];
                 dirty[i] = 1;
+                S.localIdx[i] = k;                                   // (scratch of the carve pass, free until round 2: which landmass a frontier entry belongs to)
                 const float v = e[landCell[i]];
                 eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1;
             }
@@ -1084,9 +1096,12 @@ void replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
         if (dirty[i]) { st[i].drain = TO_OCEAN; st[i].root = (int32_t)s; }
         heap.push(i, (float)((double)st[i].e + cell_noise(landCell[i])));    // a seed's surface is its height at the start of the call (state copy: eL of a clean landmass is carved by now)
     }
-    int64_t realPops = 0;
+    int64_t realPops = 0, pops = 0;
+    bool stopped = false;
     while (heap.n > 0) {
+        if (S.heapStore.data()[0].key > stopLevel) { stopped = true; break; }
         const int32_t c = heap.pop();
+        ++pops;
         {
             const FloodHeapItem* hp = S.heapStore.data();
             const size_t lim2 = heap.n < 7 ? heap.n : 7;
@@ -1112,8 +1127,14 @@ void replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
             heap.push(nb, k);
         }
     }
+    if (stopped && frontier) {
+        const FloodHeapItem* hp = S.heapStore.data();
+        for (size_t q = 0; q < heap.n; ++q) if (dirty[hp[q].cell]) (*frontier)[S.localIdx[hp[q].cell]].push_back(hp[q]);
+    }
     T.lap("replay");
-    if (T.on) std::fprintf(stderr, "[flood] replay: %lld cells walked for real of %d\n", (long long)realPops, L);
+    if (T.on) std::fprintf(stderr, "[flood] replay: %lld cells walked for real of %d; %s after %lld pops (level %.9g), %zu entries left in the heap\n", (long long)realPops, L,
+                           stopped ? "stopped" : "ran to the end", (long long)pops, (double)stopLevel, heap.n);
+    return stopped;
 }
 }  // namespace
 
@@ -1146,7 +1167,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         int32_t k = -1; std::vector<int32_t> cnt, chunkStart, chunkOrder; bool track = false;
         std::atomic<int> ready{0}; std::atomic<size_t> nextChunk{0}, doneChunks{0};
     };
-    struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; std::vector<int32_t> altComp; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; };
+    struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; std::vector<int32_t> altComp; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; float maxLevel = -INFINITY; bool noLevel = false; };
     std::vector<Local> loc(nt);
     std::vector<uint8_t> dirty(std::max(nComp, 1), 0);
     const int forceDirty = [] { const char* v = std::getenv("WO_FLOOD_FORCE_DIRTY"); return v ? std::atoi(v) : -1; }();     // test hook (read per call): treat this landmass (by rank in size) as undecided
@@ -1207,6 +1228,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     for (const Contest& ct : me.contests) {
                         ++me.contested;
                         bool open = false;
+                        if (ct.other < 0) me.noLevel = true; else if (ct.level > me.maxLevel) me.maxLevel = ct.level;
                         if (ct.other >= 0) {
                             const FloodCell& x = st[ct.cell];
                             const float kx = (float)((double)x.surface + cell_noise(S.landCell[ct.cell]));
@@ -1310,7 +1332,38 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     if (T.on) std::fprintf(stderr, "[flood] landmasses %d, workers %d, tie groups %lld (nested %lld), contested %lld, open parents %lld, undecided %lld -> %d landmasses through the replay\n",
                            rep.landmasses, rep.workers, (long long)rep.groups, (long long)rep.nested, (long long)rep.contested, (long long)rep.openParents, (long long)rep.unresolved, rep.replayed);
     if (!redo.empty()) {
-        replay_dirty_landmasses(S, dirty, e);
+        // The replay has to reproduce the reference's heap only up to the last equal-key decision that matters: every contested cell of
+        // the first round (open parents included: they change the array) belongs to a tie group, and once the heap's smallest key has
+        // passed the highest of those groups' levels no decision is left that the landmass walks could not vouch for themselves.  From
+        // there each undecided landmass goes on alone, on a queue of its own seeded with the entries the single heap held for it —
+        // concurrently, with the tie bookkeeping of a first-round walk; should that meet a contested cell after all (the history below
+        // the level may differ from the first round's), the replay is run again, to the end.
+        float stopLevel = -INFINITY;
+        bool toTheEnd = forceDirty >= 0;                     // (the test hook has no level: its landmass is replayed in full)
+        for (const Local& l : loc) { if (l.noLevel) toTheEnd = true; if (l.maxLevel > stopLevel) stopLevel = l.maxLevel; }
+        if (toTheEnd) stopLevel = INFINITY;
+        if (const char* v = std::getenv("WO_FLOOD_REPLAY_STOP")) stopLevel = (float)std::atof(v);      // test hook (read per call)
+        std::vector<std::vector<FloodHeapItem>> frontier(nComp);
+        if (replay_dirty_landmasses(S, dirty, e, stopLevel, &frontier)) {
+            std::atomic<int> contestedAgain{0};
+            uint8_t* seen = S.seen.data();
+            int32_t* stamp = S.stamp.data();
+            parallel_ranges((int64_t)redo.size(), [&](int64_t b, int64_t en, int) {
+                for (int64_t q = b; q < en; ++q) {
+                    const int32_t k = redo[q];
+                    const int32_t* cells = S.compCells.data() + S.compCellStart[k];
+                    const int32_t n = S.compCellStart[k + 1] - S.compCellStart[k];
+                    for (int32_t x = 0; x < n; ++x) { const int32_t i = cells[x]; seen[i] = st[i].drain != UNVISITED; stamp[i] = 0; }
+                    static thread_local hvec<FloodHeapItem> store;
+                    std::vector<Contest> contests; int64_t g = 0, nn = 0;
+                    walk_landmass_resume(S, frontier[k], n, store, contests, g, nn);
+                    if (!contests.empty()) contestedAgain.fetch_add(1);
+                }
+            }, 1);
+            T.lap("resumed");
+            if (T.on) std::fprintf(stderr, "[flood] %zu landmasses resumed on their own queues above level %.9g%s\n", redo.size(), (double)stopLevel, contestedAgain.load() ? "; a contested cell turned up: full replay" : "");
+            if (contestedAgain.load()) replay_dirty_landmasses(S, dirty, e, INFINITY, nullptr);
+        }
         run_round(redo, true);
         T.lap("round 2");
     }
