@@ -409,6 +409,11 @@ __device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
     const float cdTL = F.cellDist[tc], e0tL = F.e[tc];
     const int32_t p0 = event_before(Er, r, rr);
     const int32_t p0c = p0 >= 0 ? p0 : r;
+    // everything else a list is needed for is taken from it as soon as it is there, so that no list stays live across the levels below
+    const bool overflowR = Er.rank[0] == -2;
+    int32_t lastR = -1;
+#pragma unroll
+    for (int q = 0; q < WO_EVENTS; ++q) if (Er.rank[q] >= 0) lastR = Er.cell[q];
     const int32_t s0 = SLOT ? F.slotOf[p0c] : p0c;
     const bool tLand = t >= 0 && trt.rank >= 0;                     // ocean cells carry rank -1
     const float cdT = tLand ? cdTL : 0.0f;
@@ -420,13 +425,17 @@ __device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
     const float e0t2L = F.e[t2c];
     const int32_t p1 = tLand ? event_before(EtL, r, rr) : -1;
     const int32_t p1c = p1 >= 0 ? p1 : r;
+    const bool overflowT = tLand && EtL.rank[0] == -2;
+    int32_t lastT = -1;
+#pragma unroll
+    for (int q = 0; q < WO_EVENTS; ++q) if (tLand && EtL.rank[q] >= 0) lastT = EtL.cell[q];
     const int32_t s1 = SLOT ? F.slotOf[p1c] : p1c;
     const bool t2Land = t2 >= 0 && trt2.rank >= 0;
     // level 4: the slot of the latest earlier event on t2
     const int32_t p2 = t2Land ? event_before(Et2L, r, rr) : -1;
     const int32_t p2c = p2 >= 0 ? p2 : r;
     const int32_t s2 = SLOT ? F.slotOf[p2c] : p2c;
-    if (Er.rank[0] == -2 || (tLand && EtL.rank[0] == -2) || (t2Land && Et2L.rank[0] == -2)) return false;     // row scans: deferred
+    if (overflowR || overflowT || (t2Land && Et2L.rank[0] == -2)) return false;     // row scans: deferred
     SolveTask T;
     T.predSelf = p0 >= 0 ? 2 * s0 + (p0 == r ? 0 : 1) : -1;
     T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
@@ -448,10 +457,7 @@ __device__ inline bool solve_setup_cell_batched(const Fields& F, int32_t r) {
         }
     }
     if (F.solveFinals) {
-        // which task leaves the last event on r and on t: the last valid entry of the (descending-rank) lists
-        int32_t lastR = -1, lastT = -1;
-#pragma unroll
-        for (int q = 0; q < WO_EVENTS; ++q) { if (Er.rank[q] >= 0) lastR = Er.cell[q]; if (tLand && EtL.rank[q] >= 0) lastT = EtL.cell[q]; }
+        // which task leaves the last event on r and on t: the last valid entry of the (descending-rank) lists (lastR, lastT above)
         T.pad_[0] = r; T.pad_[1] = tLand ? t : -1;
         if (lastR == r) T.flags |= 16u;
         if (tLand && lastT == r) T.flags |= 32u;
@@ -481,8 +487,12 @@ __device__ inline void solve_setup_finals_by_rows(const Fields& F, int32_t r) {
 // Tasks that need the row scans are collected per workgroup (LDS) and set up by the workgroup's first lanes once its main pass is
 // over: the slow path then runs in one partly filled wave per workgroup instead of inside nearly every wave, and no global
 // counter is involved (one returning atomic per wave on a single word was measured to serialise the whole launch: 374 us).
+// (occupancy hints of 5 / 6 / 8 waves per SIMD make this kernel spill on its hot path: 32.4 / 33.3 / 38.3 ms per step against 30.0 at the 114 VGPRs it takes by itself)
+#ifndef WO_SETUP_WAVES
+#define WO_SETUP_WAVES 1
+#endif
 template <bool SLOT>
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup_batched(Fields F, int32_t* zeroA, int32_t nA, int32_t* zeroB, int32_t nB) {
+__global__ __launch_bounds__(WO_BLOCK, WO_SETUP_WAVES) void k_solve_setup_batched(Fields F, int32_t* zeroA, int32_t nA, int32_t* zeroB, int32_t nB) {
     __shared__ int32_t s_deferred[WO_BLOCK];
     __shared__ int32_t s_n;
     // the solve launch's counters (tasks left pending per patch, per launch) start at zero: cleared here instead of by two launches of their own
@@ -796,10 +806,16 @@ __global__ __launch_bounds__(WO_BLOCK) void k_thermal_excess(Fields F, double ta
     WO_XCD_LAND(i, r) thermal_excess_cell_t(F, r, talus, M);
 }
 // meshes whose largest degree is <= 16 (jittered Fibonacci spheres: 10-11 at 10^4..10^6 cells, 13 at 10^7) keep the event
-// lists in registers (12- or 16-entry private arrays are promoted to VGPRs: 103 / 115 VGPRs, no scratch); larger degrees
-// use the LDS form
+// lists of the rare rows of more than WO_ROW neighbours in private arrays; larger degrees use the LDS form.
+// Occupancy: left alone the compiler promotes the arrays to registers (103 / 115 VGPRs, 4 waves per SIMD, no scratch); asked for
+// >= 5 waves it keeps them in scratch (62 VGPRs, 272 B per lane, 8 waves per SIMD) — and since 99.9 % of the rows take
+// thermal_apply_row, which never touches them, the launch is 27 % SHORTER that way (10 M cells: 28.0 -> 20.6 ms per step, round 4;
+// the kernel waits on its gathers 37 % of the time and issues f64 arithmetic the rest: twice the waves hide more of both).
+#ifndef WO_THERMAL_WAVES
+#define WO_THERMAL_WAVES 6
+#endif
 template <int MAXIN>
-__global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply_reg(Fields F, float* out, double talus, double kThermal) {
+__global__ __launch_bounds__(WO_BLOCK, WO_THERMAL_WAVES) void k_thermal_apply_reg(Fields F, float* out, double talus, double kThermal) {
     __shared__ float s_tile[WO_TILE_WIN];
     const TileWindow M = stage_tile(F, F.me, s_tile, WO_XCD_LAND_BASE());
     WO_XCD_LAND(i, r) {
