@@ -141,6 +141,8 @@ struct wo_planet {
     // erode scratch (allocated on first erodeComposite)
     bool scratch = false;
     bool landIdentity = false;          // erode_composite under the land-first mirror: landIdx[i] == i
+    int64_t floodPrefixMirror = -1, floodPrefixStatic = -1;      // (mirror version, flood static version) for which the mirror's first L ids were checked to be the flood's land order
+    bool floodPrefixOk = false;
     int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
     uint32_t* d_keys[2] = {nullptr, nullptr};
     float *d_cellDist = nullptr, *d_flow = nullptr;

@@ -438,13 +438,14 @@ struct FloodTimer {
 // land elevations into the compact arrays + the start state of pass 1 (:107-113)
 void flood_gather(const float* e, FloodScratch& S) {
     const int32_t L = S.L;
+    const bool landOrder = S.landOrder;             // e holds the land heights only, in land-index order (FloodScratch::landOrder)
     const int32_t* landCell = S.landCell.data();
     float* eL = S.eL.data();
     FloodCell* st = S.state.data();
     if ((int32_t)S.seen.size() < L) S.seen.resize(L);
     uint8_t* seen = S.seen.data();
     parallel_ranges(L, [&](int64_t b, int64_t en, int) {
-        for (int64_t i = b; i < en; ++i) { const float v = e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
+        for (int64_t i = b; i < en; ++i) { const float v = landOrder ? e[i] : e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
         std::memset(seen + b, 0, (size_t)(en - b));
     });
 }
@@ -1012,7 +1013,8 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
             if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) return false;
         }
     }
-    parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
+    if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
+    else parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
 }
@@ -1053,7 +1055,7 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
                 const int32_t i = cells[q];
                 dirty[i] = 1;
                 S.localIdx[i] = k;                                   // (scratch of the carve pass, free until round 2: which landmass a frontier entry belongs to)
-                const float v = e[landCell[i]];
+                const float v = S.landOrder ? e[i] : e[landCell[i]];
                 eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1;
             }
         });
@@ -1368,7 +1370,8 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         T.lap("round 2");
     }
     const int32_t* landCell = S.landCell.data();
-    parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
+    if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
+    else parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
 }

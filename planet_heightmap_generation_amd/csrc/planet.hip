@@ -520,6 +520,45 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("H2D"); }
 }
 
+// The flood stage of a planet inside its land-first mirror.  The mirror numbers the land cells 0 .. L-1 in Morton order of their positions,
+// which is the order of the host flood's own land list (both come from morton_order_cells on the same mask; checked once per (mirror,
+// flood tables) pair by comparing the two lists): the first L floats of the mirrored field ARE the flood's land heights.  So the stage
+// copies 4 L bytes each way instead of 4 N (11 instead of 40 MB at the benched size), the host passes index them directly
+// (FloodScratch::landOrder) and the field never leaves the mirror (no scatter into the planet's order before, no gather after).
+static bool flood_land_is_mirror_prefix(wo_planet* p) {
+    auto& M = p->mirror;
+    const FloodScratch& S = p->flood;
+    if (p->floodPrefixMirror != M.version || p->floodPrefixStatic != S.staticVersion) {
+        p->floodPrefixMirror = M.version; p->floodPrefixStatic = S.staticVersion;
+        p->floodPrefixOk = S.L == p->L && M.h_perm.size() == (size_t)p->N && (size_t)S.L <= M.h_perm.size() &&
+                           std::memcmp(M.h_perm.data(), S.landCell.data(), sizeof(int32_t) * (size_t)S.L) == 0;
+    }
+    return p->floodPrefixOk;
+}
+static void flood_stage_land(wo_planet* p, double carveStrength, FloodRun& R) {
+    hipStream_t s = p->ctx->stream;
+    FloodScratch& S = p->flood;
+    const size_t bytes = (size_t)S.L * sizeof(float);
+    const bool timing = p->opt.floodTiming;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flood stage] %-12s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+        t0 = now;
+    };
+    if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("drain gpu"); }
+    WO_HIP(hipMemcpyAsync(p->h_pinned, p->d_e, bytes, hipMemcpyDeviceToHost, s));
+    WO_HIP(hipStreamSynchronize(s));
+    lap("D2H (land)");
+    S.landOrder = true;
+    try { flood_host_passes(p->h_pinned, carveStrength, S, &R.host); } catch (...) { S.landOrder = false; throw; }
+    S.landOrder = false;
+    lap("host passes");
+    WO_HIP(hipMemcpyAsync(p->d_e, p->h_pinned, bytes, hipMemcpyHostToDevice, s));
+    if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("H2D (land)"); }
+}
+
 static void coast_flags(wo_planet* p) {
     launch(p, FAM_COAST, k_coast, xcd_grid(p->N), WO_BLOCK, p->fields(), p->d_coast);
 }
@@ -751,9 +790,15 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         leftovers_so_far();                    // the host is about to read the field
         clk.begin("priority_flood");
         auto t0 = std::chrono::steady_clock::now();
-        mir.suspend();
-        flood_stage(p, cs, floodRun);
-        mir.resume();
+        // inside the land-first mirror, with the mask and the flood's tables in place: the land heights straight from the mirrored field
+        const bool landOnly = mir.on && p->landIdentity && !p->floodX.on && !p->opt.floodDevice && p->h_ocean_valid && p->flood.staticValid &&
+                              p->flood.staticN == p->N && p->flood.L > 0 && flood_land_is_mirror_prefix(p);
+        if (landOnly) flood_stage_land(p, cs, floodRun);
+        else {
+            mir.suspend();
+            flood_stage(p, cs, floodRun);
+            mir.resume();
+        }
         floodHostMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         clk.end();
     };

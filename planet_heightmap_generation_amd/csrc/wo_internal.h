@@ -23,6 +23,7 @@ struct FloodScratch {
     bool staticValid = false; int32_t staticN = -1; int32_t L = 0; int64_t staticVersion = 0;
     hvec<int32_t> landCell, landIndex, offL, adjL, seedCell, landByR;   // landByR: land indices in ascending original id
     // per call (land-index space)
+    bool landOrder = false;                  // the caller's height array holds the land cells only, element i = land index i (landCell order), instead of every cell by id
     hvec<float> surface, eL;                 // surface / root: compact copies of the pass-1 results for passes 2 and 3
     hvec<FloodCell> state;
     hvec<int32_t> root, order, order2, list2;

@@ -282,7 +282,8 @@ extern "C" void emu_warp(int32_t N, const int32_t* off, const int32_t* adj, floa
 
 // priorityFloodCarve through the host stage's two pass-1 routes.  mode 0: the serial heap walk; mode 1: one heap per
 // landmass with the tie-group checks (falls back to the serial walk when it cannot vouch for the result).
-// stats: [calls, serialPass1, tieGroups, contested, openParents, unresolved, pathRedo, pass1Ms, pass23Ms] (mode + 10: two more slots, [replays, replayedLandmasses])
+// stats: [calls, serialPass1, tieGroups, contested, openParents, unresolved, pathRedo, pass1Ms, pass23Ms] (mode + 10: two more slots, [replays, replayedLandmasses];
+// mode + 100: the heights go in and out in land order)
 extern "C" void emu_flood_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, const uint8_t* ocean, double cs,
                                int32_t mode, int32_t repeats, double* stats) {
     FloodScratch S;
@@ -292,7 +293,15 @@ extern "C" void emu_flood_host(int32_t N, const int32_t* off, const int32_t* adj
     std::vector<float> e0(e, e + N);
     for (int32_t k = 0; k < (repeats < 1 ? 1 : repeats); ++k) {
         std::memcpy(e, e0.data(), sizeof(float) * (size_t)N);
-        if (mode % 10 == 0) { ++hs.calls; ++hs.serialPass1; flood_gather(e, S); flood_pass1_host(S); flood_pass23_host(e, cs, S); }
+        if (mode >= 100) {                                  // the heights handed over in land order (FloodScratch::landOrder), as the mirrored planet does
+            std::vector<float> land(S.L);
+            for (int32_t i = 0; i < S.L; ++i) land[i] = e[S.landCell[i]];
+            S.landOrder = true;
+            flood_host_passes(land.data(), cs, S, &hs);
+            S.landOrder = false;
+            for (int32_t i = 0; i < S.L; ++i) e[S.landCell[i]] = land[i];
+        }
+        else if (mode % 10 == 0) { ++hs.calls; ++hs.serialPass1; flood_gather(e, S); flood_pass1_host(S); flood_pass23_host(e, cs, S); }
         else flood_host_passes(e, cs, S, &hs);
     }
     if (stats) {
