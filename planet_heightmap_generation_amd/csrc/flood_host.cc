@@ -37,16 +37,7 @@ namespace wo {
 
 namespace {
 
-// js/terrain-post.js:100-105 — Number (double) products reduced mod 2^32 afterwards
-inline double cell_noise(int32_t r) {
-    const double p = (double)r * 2654435761.0;
-    uint32_t h = (uint32_t)(uint64_t)p;
-    const int32_t x = (int32_t)((h >> 16) ^ h);
-    const double q = (double)x * 73244475.0;
-    h = (uint32_t)(int64_t)q;
-    h = (h >> 16) ^ h;
-    return ((double)h / 4294967295.0) * 0.01;
-}
+inline double cell_noise(int32_t r) { return flood_cell_noise_of(r); }      // (wo_internal.h: shared with the device)
 
 // Binary min-heap of (key, cell) pairs with the reference's exact sift rules (js/terrain-post.js:18-46):
 // sift-up stops on >=, sift-down compares left with the moving item, then right with the smaller of the two.
@@ -176,6 +167,7 @@ struct RingQueue {
         if (bi <= b0) cur.push(c, k);
         else if (bi - b0 < NB) { const int s = (int)(bi & (NB - 1)); R.b[s].push_back(HeapItem{k, c}); R.occ[s >> 6] |= 1ull << (s & 63); }
         else over.push(c, k);
+        if (primed && cur.n == 0) advance();              // the queue was empty (its last entry just popped): the invariant "n > 0 => the current heap holds the front" again
     }
     void advance() {                                       // cur is empty, n > 0: the next occupied bucket becomes the current one
         int64_t br = INT64_MAX;
@@ -199,7 +191,8 @@ struct RingQueue {
         }
         while (over.n && bucket_of(over.d.data()[0].key) <= b) { const float k = over.d.data()[0].key; const int32_t c = over.pop(); cur.push(c, k); }
     }
-    void prime() { if (cur.n == 0 && n > 0) advance(); }
+    bool primed = false;
+    void prime() { primed = true; if (cur.n == 0 && n > 0) advance(); }
     int32_t pop() {
         const int32_t c = cur.pop();
         --n;
@@ -207,6 +200,39 @@ struct RingQueue {
         return c;
     }
 };
+
+// Test support (tests/emu): the ring against the 4-ary heap on a random operation sequence; returns the number of pops whose key differs.
+inline int64_t queues_differ(int64_t ops, uint64_t seed) {
+    hvec<HeapItem> sa(1024), sb(1024);
+    KeyHeap4 a(sa); RingQueue b(sb);
+    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 7;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    auto unit = [&]() { return (double)(rnd() >> 11) / 9007199254740992.0; };
+    int64_t bad = 0; int32_t id = 0; float level = 0.01f;
+    for (int q = 0; q < 64; ++q) { const float k = (float)(unit() * 0.3); a.push(id, k); b.push(id, k); ++id; }      // "seeds": before prime()
+    b.prime();
+    bool draining = false;
+    for (int64_t op = 0; op < ops; ++op) {
+        if (a.n == 0) draining = false;
+        if (!draining && rnd() % 4096 == 0) draining = true;                      // now and then: pop until empty
+        const bool doPop = a.n > 0 && (draining || rnd() % 100 < 50);
+        if (doPop) {
+            const float ka = a.front()[0].key, kb = b.front()[0].key;
+            a.pop(); b.pop();
+            if (std::memcmp(&ka, &kb, 4) != 0) ++bad;
+            if (ka > level) level = ka;
+        } else {
+            const uint64_t kind = rnd() % 100;
+            float k = kind < 80 ? (float)(level + unit() * 0.012) : kind < 95 ? (float)(level - unit() * 0.01) : (float)(level + unit() * 0.5);
+            if (k < 0) k = 0;
+            if (rnd() % 64 == 0) k = level;                                       // equal keys
+            a.push(id, k); b.push(id, k); ++id;
+        }
+        if (a.n != b.n) return -1;
+    }
+    while (a.n > 0) { const float ka = a.front()[0].key, kb = b.front()[0].key; a.pop(); b.pop(); if (std::memcmp(&ka, &kb, 4) != 0) ++bad; }
+    return bad + (b.n != 0);
+}
 
 inline uint32_t asc_bits(float f) {
     if (f == 0.0f) f = 0.0f;
@@ -240,6 +266,7 @@ void radix_sort_u32(KV& keys, VV& vals) {     // stable LSD, 11/11/10 bits
 constexpr int32_t UNVISITED = -2, TO_OCEAN = -3, NO_TARGET = -1;
 
 }  // namespace
+int64_t flood_queues_differ(int64_t ops, uint64_t seed) { return queues_differ(ops, seed); }
 
 // Everything that depends only on (mesh, positions, r_isOcean): Morton order, compact land numbering and CSR, the
 // open-ocean component (largest, first wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose
@@ -640,9 +667,11 @@ void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_
     // iterations): 86 % of the pushes carry a RAISED key (level + EPS + noise) and wait for the level to pass their noise — 100 000 entries on
     // average, 170 000 at most, 44 % of the pops below the level already reached: 44.6-46.7 ms on the 4-ary heap, 34.1-36.9 ms on the ring
     // (GPU box, bucket widths 2^-15 ... 2^-18 alike; no difference in the build container, whose cores have twice the L2).  The binary heap
-    // was slower than the 4-ary one (35 against 31-32 ms).  What would halve the first flood's queue (replay: 8.7 ms against 20): ranks of the
-    // cells' own keys sorted beforehand, the frontier a bitmap over the ranks, a heap for the raised keys only — the sort would have to come
-    // from somewhere off the critical path, and the second flood has few such keys.
+    // was slower than the 4-ary one (35 against 31-32 ms).  Built, measured and removed in round 4: the ranks of the cells' OWN keys sorted on the
+    // device before the stage (4 radix passes + 3 copies: 0.8 ms), the frontier of those keys a bitmap over the ranks and only the raised keys in
+    // the ring — exact (device keys and ranks == the host's arithmetic on every cell, fields == oracle), 8.7 against 20 ms on the queue-only replay
+    // with ranks per landmass, but with ranks over the whole planet (a landmass's bits are sparse in it) the first flood's walk went 27.6-28.8 ->
+    // 25-26 ms and the second flood's, whose keys are mostly raised, 34 -> 41-50 ms: a loss per step.
     if (walk_on_ring(nCells)) walk_landmass_h<RingQueue>(S, seeds, nSeeds, store, contests, nGroups, nNested);
     else walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
 }

@@ -16,6 +16,22 @@ int mesh_csr(int V, int numSides, const int* triangles, const int* halfedges,
 void neighbor_dist(int V, const int* adjOffset, const int* adjList, const float* xyz, float* out);
 
 // flood_host.cc
+#if defined(__HIPCC__)
+#define WO_FLOOD_HD __host__ __device__
+#else
+#define WO_FLOOD_HD
+#endif
+// cellNoise of priorityFloodCarve, js/terrain-post.js:100-105 — Number (double) products reduced mod 2^32 afterwards.  Host and
+// device run the same IEEE double operations: the same bits.
+WO_FLOOD_HD inline double flood_cell_noise_of(int32_t r) {
+    const double p = (double)r * 2654435761.0;
+    uint32_t h = (uint32_t)(uint64_t)p;
+    const int32_t x = (int32_t)((h >> 16) ^ h);
+    const double q = (double)x * 73244475.0;
+    h = (uint32_t)(int64_t)q;
+    h = (h >> 16) ^ h;
+    return ((double)h / 4294967295.0) * 0.01;
+}
 struct FloodHeapItem { float key; int32_t cell; };
 struct FloodCell { float e; int32_t drain; float surface; int32_t root; };   // one 16-byte record per land cell: a pop touches one line for all four
 struct FloodScratch {
@@ -61,6 +77,7 @@ void morton_order_cells(int32_t N, const float* xyz, hvec<int32_t>& cells);
 void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e,
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);
 // the pieces of the call above, used by the device flood (pass 1 on the GPU, passes 2/3 per drainage tree on the host)
+int64_t flood_queues_differ(int64_t ops, uint64_t seed);            // test support: RingQueue against the 4-ary heap on a random operation sequence
 void flood_cell_noise(const FloodScratch& S, double* out);            // cellNoise per land cell, compact order
 void flood_gather(const float* e, FloodScratch& S);                   // land elevations -> compact arrays, pass-1 start state
 void flood_pass1_host(FloodScratch& S);                               // serial heap walk (reference order incl. heap tie mechanics)

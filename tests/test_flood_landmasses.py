@@ -401,3 +401,14 @@ def test_heights_handed_over_in_land_order(emu, oracle, monkeypatch):
         e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, cs, 101)
         monkeypatch.delenv("WO_FLOOD_FORCE_DIRTY")
         assert np.array_equal(e, ref) and st["replays"] == 1, (cs, int((e != ref).sum()), st)
+
+
+
+def test_ring_queue_pops_in_key_order_also_after_running_empty(emu):
+    """flood_host.cc: RingQueue against the 4-ary heap on random operation sequences shaped like a walk's (keys a little above the level
+    reached, some below it, a few far above the ring's window) in which the queue runs EMPTY again and again and is refilled — as in a
+    landmass that touches the open ocean in one cell: the popped keys must be the heap's, one for one."""
+    emu.emu_flood_queues_differ.restype = C.c_int64
+    emu.emu_flood_queues_differ.argtypes = [C.c_int64, C.c_uint64]
+    for seed in (1, 2, 3):
+        assert emu.emu_flood_queues_differ(400000, seed) == 0

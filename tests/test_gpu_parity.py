@@ -876,3 +876,30 @@ def test_decomposed_shares_when_some_shares_have_no_land(TP, oracle):
     merged, stats, secs, plan = D.erode_shares_concurrently(TP, mesh, xyz, nd, e0, oc, shares, args, (3, 0.1125))
     assert any(c.size == 0 for c in plan.cells)
     assert np.array_equal(merged, ref), int((merged != ref).sum())
+
+
+
+@pytest.mark.gpu
+def test_flood_stage_inside_the_mirror_copies_the_land_only(TP, oracle, monkeypatch, capfd):
+    """Inside the land-first mirror the flood stage copies the first L floats of the mirrored field — the land heights, in the host flood's
+    own land order — instead of the whole field in the planet's order (planet.hip: flood_stage_land).  The first flood of a call after the
+    mask changed takes the full route (it rebuilds the host tables), the second one and every flood of the calls that follow the land-only
+    route (WO_FLOOD_TIMING names it on stderr); the field after 12 composite iterations must be the oracle's bit for bit, call after call."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(600_000, 0.75, 3)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    e0 = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, 3), xyz, 3, 0.75)
+    oc = (e0 <= 0).astype(np.uint8)
+    ref = oracle.erode_composite(om, e0, xyz, oc, 12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 0, 0.0, nd)
+    monkeypatch.setenv("WO_FLOOD_TIMING", "1")
+    pl = TP.Planet(mesh, xyz, nd)
+    seen_land_only = 0
+    for call in range(3):
+        got = e0.copy()
+        capfd.readouterr()
+        pl.erode_composite(got, oc, 12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 0, 0.0)
+        log = capfd.readouterr().err
+        assert int((got != ref).sum()) == 0, call
+        seen_land_only += log.count("D2H (land)")
+    assert seen_land_only >= 3, seen_land_only
+    pl.close()
