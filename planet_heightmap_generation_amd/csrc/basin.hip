@@ -102,12 +102,21 @@ __global__ __launch_bounds__(WO_BLOCK) void k_basin_slots(const int32_t* __restr
     }
 }
 
+// (Round 4: the list used to hold 256 ranges of >= 1 536 slots, and a pass of the benched planet has 240-330 of those: whichever 256 the atomic
+// happened to admit were listed, and some of the longest ranges — 8-10 k slots, the ones that set the length of the launch — started late with the
+// unlisted.  With 2 048 places for ranges of >= 2 048 slots every long range is listed: solve launches 45.4 -> 38.2 ms per step.)
 // Long ranges first.  A launch of the solve lasts as long as its longest range (one workgroup walking the biggest drainage
 // component), and workgroups are handed out in block order: a long range whose block comes late starts late, with the chip
 // already emptying.  The ranges of at least WO_LONG_RANGE slots are listed here (after all range starts are known), the first
 // WO_LONG_MAX blocks of the solve launch take them, and the block that would have met such a range in its turn skips it.
 // big[0] = count, big[1 + i] = range index; flag[k] = 1: range k is on the list.
-constexpr int32_t WO_LONG_RANGE = 1536, WO_LONG_MAX = 256;
+#ifndef WO_LONG_RANGE_SLOTS
+#define WO_LONG_RANGE_SLOTS 2048
+#endif
+#ifndef WO_LONG_LIST
+#define WO_LONG_LIST 2048
+#endif
+constexpr int32_t WO_LONG_RANGE = WO_LONG_RANGE_SLOTS, WO_LONG_MAX = WO_LONG_LIST;
 __device__ inline int32_t range_end(const int32_t* __restrict__ rangeStart, int32_t k, int32_t nRanges, int32_t L) {
     for (int32_t j = k + 1; j < nRanges; ++j) { const int32_t v = rangeStart[j]; if (v != WO_RANGE_NONE) return v; }
     return L;
