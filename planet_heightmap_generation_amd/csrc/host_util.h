@@ -177,7 +177,7 @@ inline void mesh_components(int32_t N, const int32_t* off, const int32_t* adj, M
             }
         }
     });
-    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) if (member((int32_t)r)) parent[r] = find((int32_t)r); });
+    parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t r = b; r < e; ++r) if (member((int32_t)r)) par((int32_t)r)->store(find((int32_t)r), std::memory_order_relaxed); });      // (other threads' find() may pass through r meanwhile: its root is a valid parent at any time)
 }
 
 // Park-Miller LCG exactly as the reference seeds and steps it (js/rng.js:3-6).
