@@ -583,6 +583,7 @@ def main():
     ap.add_argument("--one-planet-cells", type=int, default=40_000_000, help="N > 1, default mode: after the ensemble region, ONE planet of this many cells over all GPUs "
                                                                               "(BASELINE config 4; nested object `one_planet` of the line); 0 = skip")
     ap.add_argument("--one-planet-iters", type=int, default=200)
+    ap.add_argument("--one-planet-timeout", type=float, default=900.0, help="seconds after which the one-planet leg is given up and the line is printed without it")
     ap.add_argument("--one-planet-steps", type=int, default=1)
     ap.add_argument("--one-planet-parity-iters", type=int, default=20, help="one extra untimed step at this iteration count, whose CRC the committed oracle checksum covers (0 = skip)")
     ap.add_argument("--one-planet-warmup", type=int, default=1)
@@ -774,11 +775,7 @@ def main():
     if rank == 0 and world == 1 and not virt and not args.no_relaxed:
         one_step(pl, seed, params); pl.sync()
         relaxed = relaxed_mode_leg(pl, seed, params, pl.download(), N)
-    one_planet = None
-    if world > 1 and not decomposed_mode and args.mode == "auto" and args.one_planet_cells > 0:
-        pl.close()
-        one_planet = one_planet_leg(TP, args, rank, world, dist, local_rank)
-    if rank == 0:
+    def emit(one_planet):
         value = whole_job_value(N, iters, args.steps, 1 if decomposed_mode else world, wall)
         out = {
             "metric": "Mcells·iter/s, terrain-post erosion stack", "value": value, "unit": "Mcells·iter/s",
@@ -799,7 +796,29 @@ def main():
             "stage_ms_last_step": {k: round(v, 2) for k, v in stages.items()},
             "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "host_numa_node": numa_node, "hip_event_ms_per_step": ev_ms / args.steps,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+
+    one_planet = None
+    if world > 1 and not decomposed_mode and args.mode == "auto" and args.one_planet_cells > 0:
+        pl.close()
+        # The one-planet leg exchanges between ranks inside the flood stage (a path that has never had real peers on this pool): should it not
+        # come back, the ensemble measurement above must not be lost with it — after the timeout rank 0 prints the line without the leg and
+        # every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                emit({"error": f"the one-planet leg did not finish within {args.one_planet_timeout} s; the ensemble figures of this line are complete"})
+            sys.stderr.write(f"[bench] rank {rank}: one-planet leg timed out\n")
+            sys.stderr.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.one_planet_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        one_planet = one_planet_leg(TP, args, rank, world, dist, local_rank)
+        watchdog.cancel()
+    if rank == 0:
+        emit(one_planet)
     pl.close()
     if dist is not None:
         dist.destroy_process_group()
