@@ -47,7 +47,7 @@ sys.path.insert(0, str(REPO))
 PASSES = {
     "sort":      {"budget": (8.0, 0.0),   "kernels": {"sort_keys": (2.0, 0.0), "sort_radix": (6.0, 0.0), "rank_scatter": (0.0, 0.0)}},
     "receivers": {"budget": (68.0, 4.0),  "kernels": {"receivers": (68.0, 4.0)}},
-    "flow":      {"budget": (16.0, 4.0),  "kernels": {"flow_snap": (8.0, 0.0), "flow_final": (8.0, 4.0), "flow_init": (0.0, 0.0), "flow_apply": (0.0, 0.0)}},
+    "flow":      {"budget": (16.0, 4.0),  "kernels": {"flow_climb": (8.0, 0.0), "flow_final": (8.0, 4.0), "flow_init": (0.0, 0.0), "flow_apply": (0.0, 0.0)}},
     "solve":     {"budget": (45.0, 0.0),  "kernels": {"solve_setup": (33.0, 0.0), "solve_basin": (8.0, 0.0), "solve_patch": (8.0, 0.0), "solve_round": (8.0, 0.0),
                                                        "solve_tail": (0.0, 0.0), "solve_final": (4.0, 0.0), "basin_layout": (0.0, 0.0), "basin_sort": (0.0, 0.0),
                                                        "level_sort": (0.0, 0.0), "river_order": (0.0, 0.0)}},
@@ -62,10 +62,11 @@ GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "c
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload at the full iteration count (separate passes;
 # profiles/collect_pmc.sh); used for roofline.traffic of the dominant kernel unless WO_BENCH_PMC=1 asks for a live collection.
 PMC_FILE = REPO / "profiles" / "r04_pmc_fetch_write_per_kernel_10m_200iters.json"
-FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": ("void wo::k_solve_setup_batched<true>", "wo::k_solve_setup"), "sort_radix": "wo::k_rs_scatter",
+FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": ("void wo::k_solve_setup_batched<true>", "wo::k_solve_setup"), "sort_radix": ("wo::k_rs_scatter", "wo::k_rs_count"),
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
-                 "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_snap": "wo::k_flow_climb", "carve_round": "wo::k_carve_round_pairs",
+                 "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_climb": "wo::k_flow_climb", "carve_round": "wo::k_carve_granules",
                  "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_flowing", "void wo::k_solve_coop")}
+KERNEL_GROUPS = {"basin_sort": "sort_radix"}      # profile families that are call sites of the same HIP kernels
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 
 PARAMS = dict(hIters=200, K=3e-4, m=0.5, dt=1.0, tIters=200, talusSlope=1.16, kThermal=0.015, gIters=10, glacialStrength=0.5)
@@ -573,12 +574,17 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-relaxed", action="store_true", help="skip the relaxed-mode measurement (N = 1)")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the step through the host-array entry points (value_with_transfers)")
+    ap.add_argument("--timed-only", action="store_true", help="nothing but warm-up and the timed steps (what a rocprofv3 trace of the timed region wants): "
+                                                               "= --no-cpu --no-profile --no-relaxed --no-transfers --in-flight 0")
     ap.add_argument("--in-flight", type=int, default=6, help="planets in flight for the supplementary ensemble figure (0 = skip)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo + --share-gpu: rehearse the multi-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use device 0")
     ap.add_argument("--mode", choices=("auto", "decomposed", "ensemble"), default="auto",
                     help="N > 1: 'ensemble' = one planet per GPU (weak scaling, BASELINE config 5, default), 'decomposed' = one planet over all GPUs by landmass (strong); "
                          "N = 1 with 'decomposed': the partitioned code path, --shares landmass shares one after the other")
+    ap.add_argument("--seeds-per-rank", type=int, default=0, help="N > 1, ensemble: distinct planets (seeds 1 + rank + k x N) a rank cycles through, one per step; "
+                                                                   "0 = min(steps, 64 / N) (BASELINE config 5: 64 seeds per job), 1 = the same planet every step")
     ap.add_argument("--shares", type=int, default=8, help="N = 1, --mode decomposed: number of landmass shares")
     ap.add_argument("--one-planet-cells", type=int, default=40_000_000, help="N > 1, default mode: after the ensemble region, ONE planet of this many cells over all GPUs "
                                                                               "(BASELINE config 4; nested object `one_planet` of the line); 0 = skip")
@@ -588,6 +594,9 @@ def main():
     ap.add_argument("--one-planet-parity-iters", type=int, default=20, help="one extra untimed step at this iteration count, whose CRC the committed oracle checksum covers (0 = skip)")
     ap.add_argument("--one-planet-warmup", type=int, default=1)
     args = ap.parse_args()
+    if args.timed_only:
+        args.no_cpu = args.no_profile = args.no_relaxed = args.no_transfers = True
+        args.in_flight = 0
 
     rank, local_rank, world = dist_env()
     import torch
@@ -643,13 +652,35 @@ def main():
         pl.apply_soil_creep_resident(*CREEP); pl.sync()
         unpart_ms = (time.perf_counter() - tu) * 1e3
         step = lambda: virt.step(seed, params)
+    # BASELINE config 5 (N > 1, ensemble): "10 M cells x 64 random seeds, one planet per GPU" — rank r erodes the planets of seeds
+    # 1 + r + k x N (k = 0, 1, ...: round-robin over the ranks, 64 seeds per job at most), one planet per timed step, cycling when the
+    # job has more steps than seeds.  Every planet is built, uploaded and run once BEFORE the timed region (mesh + mask-dependent
+    # tables: the one-time upload SURVEY 8(d) excludes); inside it a step is the resident stack on the next planet of the cycle.
+    fleet, fleet_seeds = [pl], [seed]
+    if world > 1 and not decomposed_mode and args.seeds_per_rank != 1:
+        want = args.seeds_per_rank if args.seeds_per_rank > 0 else max(1, min(args.steps, 64 // world))
+        for k in range(1, want):
+            sk = 1 + rank + k * world
+            mk, xk, nk, tk = build_inputs(args.cells, sk)
+            q = TP.Planet(mk, xk, nk, ctx=pl.ctx)
+            q.synthetic_terrain(sk); q.save_state()
+            fleet.append(q); fleet_seeds.append(sk)
+            t_mesh += tk
+            del mk, xk, nk
+        turn = [0]
+
+        def step():
+            i = turn[0] % len(fleet); turn[0] += 1
+            one_step(fleet[i], fleet_seeds[i], params)
     cold_ms = None
-    for w in range(args.warmup):
+    for w in range(max(args.warmup, len(fleet) if len(fleet) > 1 else 0)):      # every planet of the cycle once (its tables), at least --warmup steps
         tc = time.perf_counter()
         step()
         if w == 0:
             pl.sync()
             cold_ms = (time.perf_counter() - tc) * 1e3       # first step: mask-dependent tables, scratch allocation, launch-count prediction
+    if len(fleet) > 1:
+        turn[0] = 0
     barrier()
     t0 = time.perf_counter()
     pl.timer_start()
@@ -662,6 +693,17 @@ def main():
     stats = pl.last_erode_stats()
     stages = pl.last_stage_timing()
     crc = parity_crc(pl, args.cells, max(params["hIters"], params["tIters"], params["gIters"])) if (rank == 0 and seed == 1) else None
+    # config 5: which seeds this job ran, and for each the CRC of its field against the oracle's where tests/golden/crc_config3.json has one
+    seeds_run = None
+    if world > 1 and not decomposed_mode:
+        it_ = max(params["hIters"], params["tIters"], params["gIters"])
+        mine = [dict(rank=rank, seed=sk, steps=len([i for i in range(args.steps) if i % len(fleet) == j]), **parity_crc(q, args.cells, it_, sk))
+                for j, (q, sk) in enumerate(zip(fleet, fleet_seeds))]
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        seeds_run = sorted((e for lst in allr for e in lst), key=lambda e: e["seed"])
+    for q in fleet[1:]:
+        q.close()
     L = int(stats.get("land_cells", 0))
     iters = max(params["hIters"], params["tIters"], params["gIters"])
 
@@ -716,8 +758,15 @@ def main():
                 ent.update(**({"pass": kernel_pass[k]} if k in kernel_pass else {}), algorithmic_GB=round(kb / 1e9, 3), achieved_GBs=round(kb / 1e9 / (kms / 1e3), 1),
                            frac=round(kb / 1e9 / (kms / 1e3) / HBM_PEAK_GBS, 5))
             fams[k] = ent
-        # the dominant kernel: largest total time among the kernels that carry algorithmic bytes
-        fam, (ms, launches) = max(((k, v) for k, v in rep.items() if (kernel_bytes_total(k) or 0) > 0), key=lambda kv: kv[1][0])
+        # the dominant kernel: largest total time among the kernels that carry algorithmic bytes — by KERNEL, not by call site:
+        # the in-tree radix sort (k_rs_count + k_rs_scatter) is launched by the elevation sort (family sort_radix, which carries the
+        # sort pass's bytes) and by the basin layout (family basin_sort, 0 algorithmic bytes): one kernel, both call sites' time
+        grouped = {}
+        for k, (kms, kl) in rep.items():
+            g = KERNEL_GROUPS.get(k, k)
+            a = grouped.setdefault(g, [0.0, 0])
+            a[0] += kms; a[1] += kl
+        fam, (ms, launches) = max(((k, v) for k, v in grouped.items() if (kernel_bytes_total(k) or 0) > 0), key=lambda kv: kv[1][0])
         bytes_per_launch = kernel_bytes_total(fam) / launches
         avg_launch_s = ms / 1e3 / launches
         achieved = bytes_per_launch / avg_launch_s / 1e9
@@ -744,12 +793,16 @@ def main():
                                  + ", ".join(missing) + " — re-collect with profiles/collect_pmc.sh (or WO_BENCH_PMC=1 / WO_BENCH_ALLOW_STALE_PMC=1)")
         if pmc_all and fam in FAMILY_KERNEL:
             names = FAMILY_KERNEL[fam] if isinstance(FAMILY_KERNEL[fam], tuple) else (FAMILY_KERNEL[fam],)
-            pmc = next((v for k, v in pmc_all.items() if isinstance(v, dict) and k.replace("(anonymous namespace)::", "").startswith(names)), None)
-            if pmc and "FETCH_SIZE_KB" in pmc and "WRITE_SIZE_KB" in pmc:
-                traffic = (pmc["FETCH_SIZE_KB"]["per_launch"] + pmc["WRITE_SIZE_KB"]["per_launch"]) * 1024.0
+            hits = [v for k, v in pmc_all.items() if isinstance(v, dict) and k.replace("(anonymous namespace)::", "").startswith(names) and "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v]
+            if hits:
+                # a family of several kernels (the radix sort: count + scatter): all their bytes over all their launches, like `achieved`
+                hits = hits if fam in KERNEL_GROUPS.values() else hits[:1]
+                traffic = sum(v["FETCH_SIZE_KB"]["total"] + v["WRITE_SIZE_KB"]["total"] for v in hits) * 1024.0 / max(1, sum(v["FETCH_SIZE_KB"]["launches"] for v in hits))
                 traffic_note = ("traffic_source: " + src + "; bytes per launch = (FETCH_SIZE + WRITE_SIZE) KB; FETCH_SIZE on gfx950 under-reports wide coalesced "
                                 "reads by 2x and is uncalibrated for narrow gathers (MI355X_MICROARCH.md), so this is a lower bound")
-        roofline = dict(bound="hbm", kernel=fam, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+        kn = FAMILY_KERNEL.get(fam, fam)
+        kernel_name = " + ".join(kn) if (isinstance(kn, tuple) and fam == "sort_radix") else (kn[0] if isinstance(kn, tuple) else kn)
+        roofline = dict(bound="hbm", kernel=kernel_name.replace("void ", ""), family=fam, call_sites=[k for k in rep if KERNEL_GROUPS.get(k, k) == fam], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, traffic_note=traffic_note, launches=launches, avg_launch_us=avg_launch_s * 1e6,
                         algorithmic_bytes_per_launch=bytes_per_launch,
                         note="algorithmic bytes: the kernel's share of its pass's SURVEY 8(d) budget (the shares of a pass add up to the budget: PASSES in bench.py); "
@@ -767,7 +820,7 @@ def main():
         cpu = cpu_baseline(mesh, xyz, nd, seed, args.cpu_iters, iters, pl)
 
     transfers = None
-    if rank == 0 and world == 1 and not virt:
+    if rank == 0 and world == 1 and not virt and not args.no_transfers:
         ms_t, field_t = with_transfers_ms(pl, seed, params)
         transfers = dict(value_with_transfers=N * iters / (ms_t / 1e3) / 1e6, ms_per_step=ms_t, crc32_equals_resident_run=(parity_crc(field_t, args.cells, iters, seed)["crc32"] == crc["crc32"]) if crc else None,
                          note="one step through the host-array entry points of the JS call surface (wo_warp_terrain, wo_erode_composite, wo_soil_creep: r_elevation H2D + D2H and r_isOcean H2D per call); `value` is the resident rate")
@@ -775,7 +828,12 @@ def main():
     if rank == 0 and world == 1 and not virt and not args.no_relaxed:
         one_step(pl, seed, params); pl.sync()
         relaxed = relaxed_mode_leg(pl, seed, params, pl.download(), N)
-    def emit(one_planet):
+    # everything the line needs is worked out HERE, before the one-planet leg: its watchdog may only print (no torch / GPU call from the
+    # timer thread: a collective that never gets its peers would block a device synchronisation for ever)
+    d2d_GBs = round(d2d_bandwidth_GBs(local_rank), 1) if rank == 0 else None
+    host_threads = host_thread_usage()
+
+    def build_line(one_planet):
         value = whole_job_value(N, iters, args.steps, 1 if decomposed_mode else world, wall)
         out = {
             "metric": "Mcells·iter/s, terrain-post erosion stack", "value": value, "unit": "Mcells·iter/s",
@@ -791,12 +849,20 @@ def main():
             "decomposition": dec.summary() if dec else (virt.summary(unpart_ms) if virt else None),
             "value_with_transfers": transfers["value_with_transfers"] if transfers else None, "with_transfers": transfers, "one_planet": one_planet, "relaxed_mode": relaxed,
             "roofline": roofline, "cpu_baseline": cpu, "ensemble_in_flight": ensemble,
-            "parity": crc, "cold_first_step_ms": cold_ms, "host_threads": host_thread_usage(),
-            "hbm_d2d_copy_GBs_measured": round(d2d_bandwidth_GBs(local_rank), 1),
+            "parity": crc, "ensemble_seeds": seeds_run, "cold_first_step_ms": cold_ms, "host_threads": host_threads,
+            "hbm_d2d_copy_GBs_measured": d2d_GBs,
             "stage_ms_last_step": {k: round(v, 2) for k, v in stages.items()},
             "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "host_numa_node": numa_node, "hip_event_ms_per_step": ev_ms / args.steps,
         }
-        print(json.dumps(out), flush=True)
+        return out
+
+    import threading
+    printed = threading.Lock()          # the line is printed once: by the main thread or by the watchdog, whoever takes this first
+
+    def emit(line):
+        if printed.acquire(blocking=False):
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
 
     one_planet = None
     if world > 1 and not decomposed_mode and args.mode == "auto" and args.one_planet_cells > 0:
@@ -804,11 +870,11 @@ def main():
         # The one-planet leg exchanges between ranks inside the flood stage (a path that has never had real peers on this pool): should it not
         # come back, the ensemble measurement above must not be lost with it — after the timeout rank 0 prints the line without the leg and
         # every rank leaves.
-        import threading
+        fallback_line = json.dumps(build_line({"error": f"the one-planet leg did not finish within {args.one_planet_timeout} s; the ensemble figures of this line are complete"})) if rank == 0 else None
 
-        def give_up():
+        def give_up():          # timer thread: print the prepared string and leave; nothing here touches torch, HIP or the library
             if rank == 0:
-                emit({"error": f"the one-planet leg did not finish within {args.one_planet_timeout} s; the ensemble figures of this line are complete"})
+                emit(fallback_line)
             sys.stderr.write(f"[bench] rank {rank}: one-planet leg timed out\n")
             sys.stderr.flush()
             os._exit(0)
@@ -818,7 +884,7 @@ def main():
         one_planet = one_planet_leg(TP, args, rank, world, dist, local_rank)
         watchdog.cancel()
     if rank == 0:
-        emit(one_planet)
+        emit(json.dumps(build_line(one_planet)))
     pl.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64 * NW, 6) void k_solve_coop(Fields F, int32_t L, 
                 if (sq >= S && sq >= base - (RING - SC)) { rw = g & (2 * RING - 1); expect = sq + 1; return; }
                 const int32_t tag = (int32_t)(far >> 32);
                 const bool own = sq >= S;                                                        // written by this workgroup, long ago
-                if (tag <= 0 || (!own && tag >= launchTag)) { blocked = true; return; }
+                // valid: this workgroup's own output of THIS launch (launchTag: 1 in a checked pass, whose outputs were cleared; in an unchecked
+                // pass a number no earlier pass used — nothing is cleared and whatever an earlier pass left there carries another tag).  A
+                // predecessor outside the range is never valid in this launch: the layout promised there is none.
+                if (!own || tag != launchTag) { blocked = true; return; }
                 v = __uint_as_float((uint32_t)far);
             };
             classify(T.predSelf, a0, er, r0, x0); classify(T.predT, a1, et, r1, x1); classify(T.predT2, a2, et2, r2, x2);
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
                 if (mn >= ci - LAG) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");      // the far loads below read what the owners stored before their release of s_prog
         }
         const long long cw1 = STATS ? clock64() : 0;
         if (storePrev) store_prev(q - SC);                             // a super-chunk late: the wait for this super-chunk's loads at the top of the loop would otherwise also wait for a store issued a moment ago
@@ -385,7 +389,10 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
                 if (sq >= S && sq >= base - LOOKBACK * SC) { rw = g & (2 * RING - 1); expect = sq + 1; return; }
                 const int32_t tag = (int32_t)(far >> 32);
                 const bool own = sq >= S;                                                        // written by this workgroup, long ago
-                if (tag <= 0 || (!own && tag >= launchTag)) { blocked = true; return; }
+                // valid: this workgroup's own output of THIS launch (launchTag: 1 in a checked pass, whose outputs were cleared; in an unchecked
+                // pass a number no earlier pass used — nothing is cleared and whatever an earlier pass left there carries another tag).  A
+                // predecessor outside the range is never valid in this launch: the layout promised there is none.
+                if (!own || tag != launchTag) { blocked = true; return; }
                 v = __uint_as_float((uint32_t)far);
             };
             classify(T.predSelf, a0, er, r0, x0); classify(T.predT, a1, et, r1, x1); classify(T.predT2, a2, et2, r2, x2);

@@ -147,6 +147,10 @@ constexpr int WO_ROW = 8;
 // instructions and address computations per wave for the same lines.
 struct alignas(4) RowI4 { int32_t v[4]; };
 struct alignas(4) RowF4 { float v[4]; };
+// MEASURED AND REMOVED (round 5, profiles/r05b_*): a fixed-stride copy of the rows (8 neighbour slots + 8 distances per cell at 8 * r, so that
+// a thread needs no adjOffset[r] before it can ask for its row: two dependent load levels instead of three).  Bit-identical, and no faster:
+// receivers 21.8 against 20.0 ms per step, thermal 40.9 against 38.6 — these passes are not bound by the depth of their load chain but by the
+// lines they move (a 32-byte slot per row is 1.3x the bytes of a six-neighbour CSR row).
 WO_HD inline int load_row(const Fields& F, int32_t r, int32_t& b, int32_t (&nb)[WO_ROW]) {
     b = F.off[r];
     const int deg = F.off[r + 1] - b;
@@ -312,7 +316,7 @@ WO_HD inline float warp_blend(float origF, float warpedF, double warpBias, bool 
 // elev(c): the elevation of cell c — F.e[c], or the workgroup's LDS copy of its tile's neighbourhood (kernels_impl.h: TileWindow)
 template <class Elev>
 WO_HD inline int32_t receiver_cell_t(const Fields& F, int32_t r, Elev elev) {
-    if (F.ocean[r]) { F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z; return -1; }
+    if (F.ocean[r]) { if (F.target) F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z; return -1; }
     const double h = elev(r);
     int32_t bestNb = -1, bestJ = -1;
     double bestDrop = -INFINITY;
@@ -351,7 +355,7 @@ WO_HD inline int32_t receiver_cell_t(const Fields& F, int32_t r, Elev elev) {
             }
         }
     }
-    F.target[r] = bestNb;
+    if (F.target) F.target[r] = bestNb;          // (the device passes read the target out of tr[]: Fields::target is nullptr there)
     { TargetRank v; v.target = bestNb; v.rank = F.rank[r]; F.tr[r] = v; }
     if (bestNb >= 0) { const float d = F.dist[bestJ]; F.cellDist[r] = (d == 0.0f || d != d) ? (float)1e-6 : d; }
     return bestNb;
@@ -361,7 +365,7 @@ WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) { return receiver
 
 // Flow (js/terrain-post.js:604-611).  fwd edge: receiver is land and ranked after the donor.
 WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
-    const int32_t t = F.target[r];
+    const int32_t t = F.tr[r].target;
     if (t < 0 || F.ocean[t]) return -1;
     return (F.rank[r] < F.rank[t]) ? t : -1;
 }
@@ -609,7 +613,7 @@ WO_HD inline void solve_setup_cell_rows(const Fields& F, int32_t r) {
 WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     if (F.ocean[r]) return;
     SolveTask T;
-    const int32_t t = F.target[r];
+    const int32_t t = F.tr[r].target;
     T.predSelf = granule_index(F, r, latest_event_before(F, r, r));
     T.predT = -1; T.predT2 = -1; T.flags = 0; T.pad_[0] = T.pad_[1] = 0;
     T.e0r = F.e[r]; T.e0t = 0; T.e0t2 = 0; T.cellDistT = 0;
@@ -620,7 +624,7 @@ WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
         if (F.ocean[t]) T.flags |= 1u;
         else {
             T.predT = granule_index(F, t, latest_event_before(F, t, r));
-            const int32_t t2 = F.target[t];
+            const int32_t t2 = F.tr[t].target;
             T.cellDistT = F.cellDist[t];
             if (t2 >= 0 && T.cellDistT > 0) {
                 T.flags |= 8u;

@@ -179,8 +179,10 @@ __global__ __launch_bounds__(WO_BLOCK) void k_init_rank(int32_t* rank, int32_t N
 __global__ __launch_bounds__(WO_BLOCK) void k_erode_ocean_init(Fields F) {
     WO_GRID_STRIDE(r, F.N) {
         if (!F.ocean[r]) continue;
-        F.target[r] = -1; TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z;
-        F.accA[r] = 0; F.jumpA[r] = -1; F.flow[r] = 0.0f; F.totalExcess[r] = 0.0; F.me[r] = INFINITY;
+        if (F.target) F.target[r] = -1;
+        TargetRank z; z.target = -1; z.rank = -1; F.tr[r] = z;
+        if (F.accA) F.accA[r] = 0;
+        F.jumpA[r] = -1; F.flow[r] = 0.0f; F.totalExcess[r] = 0.0; F.me[r] = INFINITY;
     }
 }
 // ---- neighbour cells staged into LDS ----
@@ -224,7 +226,8 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         const int32_t t = receiver_cell_t(F, r, E);
         int32_t j = -1; const uint32_t a = 1;
         if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
-        F.accA[r] = a; F.jumpA[r] = j; F.accCnt[r] = 1ull;
+        if (F.accA) F.accA[r] = a;                           // (the pointer doubling's accumulator: nullptr on the default route, where k_flow_climb retires every cell)
+        F.jumpA[r] = j; F.accCnt[r] = 1ull;
         if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
         if (F.lateDonor && t >= 0 && !F.ocean[t] && !(F.rank[r] < F.rank[t])) F.lateDonor[t] = 1;      // r's total is added to t's flow by the totals pass, not forwarded
         if (F.basinJ) {                                      // start state of the drainage-component search (basin.hip: k_basin_init's job, one launch less on the layout's chain)

@@ -24,7 +24,7 @@ namespace wo {
 
 const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
-    "ocean_from_elevation", "sort_keys", "sort_radix", "rank_scatter", "receivers", "flow_init", "flow_snap",
+    "ocean_from_elevation", "sort_keys", "sort_radix", "rank_scatter", "receivers", "flow_init", "flow_climb",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
     "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort", "solve_basin", "misc"};
 
@@ -57,8 +57,8 @@ static void ensure_scratch(wo_planet* p) {
     const size_t N = (size_t)p->N;
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
-    p->d_rank = dalloc<int32_t>(N); p->d_target = dalloc<int32_t>(N);
-    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_ev = dalloc<EventList>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
+    p->d_rank = dalloc<int32_t>(N);
+    p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); WO_HIP(hipMemset(p->d_out, 0, N * sizeof(SolveOut)));   /* tags of the unchecked basin passes count up from here: no stale tag may look like a coming one */ p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_ev = dalloc<EventList>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_accCnt = dalloc<unsigned long long>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
@@ -79,7 +79,7 @@ static void ensure_scratch(wo_planet* p) {
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = opt.tileLds ? 1 : 0; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = d_target; F.tr = d_tr; F.ev = opt.noEventLists ? nullptr : d_ev; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = nullptr; F.tr = d_tr; F.ev = opt.noEventLists ? nullptr : d_ev; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -269,13 +269,13 @@ static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double 
 // Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
 // basin: the store order is the group-major one of basin_layout() and the first launch of the pass is k_solve_basin, which
 // normally leaves nothing pending; whatever it does leave (layout off: see basin.hip) is finished by k_solve_patch launches.
-static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin, bool countersCleared = false, bool deferCheck = false) {
+static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double m, double dt, bool basin, bool countersCleared = false, bool deferCheck = false, int32_t passTag = 1) {
     hipStream_t s = p->ctx->stream;
     const int np = p->numPatches;
     if (basin && deferCheck && countersCleared) {
         // the one launch of the basin solve, and no look at what it left: tasks left pending are counted into a word that is not
         // cleared during the call and looked at where the host synchronises anyway (erode_composite: RedoWithChecks)
-        basin_solve_launch(p, F, 1, p->d_pendingEver);
+        basin_solve_launch(p, F, passTag, p->d_pendingEver);
         p->lastPatchLaunches = 1;
         return 1;
     }
@@ -684,6 +684,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     if (gStrength != gStrength) gStrength = 0;
     const int32_t total = std::max(hIters, std::max(tIters, gIters));
     p->stageTiming.clear(); p->erodeStats.clear();
+    p->floodX.calls = 0; p->floodX.gathers = 0; p->floodX.globalFloods = 0;       // per call (the stats of a step, not of the planet's life)
     if (total <= 0) return;
     ensure_scratch(p);
     hipStream_t s = p->ctx->stream;
@@ -978,12 +979,15 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             const bool basinOverlap = true;
             const int climbCap = p->opt.flowClimbCap;
             const bool climbAll = climbCap == 0x7fffffff;
+            if (climbAll) F.accA = nullptr;            // no pointer doubling after the one-launch climb: the receivers pass does not write its accumulator
             // three streams: the event lists of the solve (they need the receivers only) are built on a stream of their own beside the flow
             // accumulation (main) and the basin layout (side); the totals pass after the accumulation is a coalesced sweep, because the
             // receivers pass flags the few cells that have a late donor.  MEASURED, NOT FASTER, off by default (WO_FLOW_EVENTS_STREAM=1): with
             // three kernels at once the climb takes 274 us instead of 200, the events 261 instead of ~90, the layout's scatter 75 instead of
             // 27, and the setup starts at the same moment (profiles/r03bc_*): these "latency-bound" launches do fill the memory pipelines
             // when two of them already run side by side.  Default: k_flow_final after the accumulation.
+            // unchecked basin pass: its one launch tags what it produces with a number no earlier pass of this planet used
+            const bool passTagged = basin && !checkEveryPass && F.ev != nullptr && !p->opt.flowEventsStream && !graphRoute;      // (a replayed graph launches with the captured tag)
             const bool eventsStreamEnv = p->opt.flowEventsStream;
             const bool eventsStream = eventsStreamEnv && basin && basinOverlap && climbAll && F.ev;
             if (eventsStream) {
@@ -1061,7 +1065,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 Fields Ff = F;
                 if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
                 if (eventsStream) launch(p, FAM_FLOW_FINAL, k_flow_totals, gridL, WO_BLOCK, Ff, p->d_flowCnt);
-                else launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt, basin ? p->d_out : (SolveOut*)nullptr);
+                // the solve's outputs are cleared (tags 0) only for a pass whose result is checked on the spot (k_solve_patch / k_solve_final read
+                // the tags as launch numbers); the unchecked pass stamps them with a tag of its own instead (passTag below): 16 B per land cell less to write
+                else launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt, (basin && !passTagged) ? p->d_out : (SolveOut*)nullptr);
             }
             clk.end();
             clk.begin("solve");
@@ -1087,7 +1093,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             } else
                 launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
             if (p->patchVersion >= 0) {
-                const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared, !checkEveryPass);
+                int32_t passTag = 1;
+                if (passTagged) {
+                    if (p->solvePassSerial >= 0x3ff00000) { WO_HIP(hipMemsetAsync(p->d_out, 0, (size_t)N * sizeof(SolveOut), s)); p->solvePassSerial = 0; }
+                    passTag = (1 << 20) + (int32_t)(++p->solvePassSerial);
+                }
+                const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared, !checkEveryPass, passTag);
                 if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
             } else {
@@ -1269,6 +1280,10 @@ static bool check_planet(wo_planet* p, const char* fn) {
 static void erode_composite_checked(wo_planet* p, int32_t hIters, double K, double m, double dt, int32_t tIters, double talus,
                                     double kThermal, int32_t gIters, double gStrength) {
     if (hIters <= 0) { erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true); return; }
+    // With a flood exchange set (shares of one planet) every flood call of this rank is a pair of collectives with its peers: a rank that
+    // ran the call a second time would repeat them alone (its peers are past them and no longer hold that call's heights).  Such a call is
+    // therefore checked pass by pass from the start — pending tasks are finished where they arise and nothing is ever run again.
+    if (p->floodX.on) { erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true); return; }
     hipStream_t s = p->ctx->stream;
     if (!p->d_redoE) p->d_redoE = dalloc<float>((size_t)p->N);
     if (!p->d_pendingEver) p->d_pendingEver = dalloc<int32_t>(16);

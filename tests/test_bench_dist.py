@@ -69,7 +69,7 @@ def test_committed_pmc_file_covers_the_default_paths_kernels():
     and not the round's bench line."""
     import bench
     have = [k.replace("(anonymous namespace)::", "") for k, v in json.loads(bench.PMC_FILE.read_text()).items() if isinstance(v, dict)]
-    for fam in ("sort_radix", "sort_keys", "receivers", "flow_snap", "flow_final", "solve_setup", "solve_basin", "thermal_excess", "thermal_apply"):
+    for fam in ("sort_radix", "sort_keys", "receivers", "flow_climb", "flow_final", "solve_setup", "solve_basin", "thermal_excess", "thermal_apply"):
         if fam not in bench.FAMILY_KERNEL:
             continue
         names = bench.FAMILY_KERNEL[fam] if isinstance(bench.FAMILY_KERNEL[fam], tuple) else (bench.FAMILY_KERNEL[fam],)
