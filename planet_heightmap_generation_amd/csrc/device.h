@@ -56,7 +56,7 @@ enum Family : int {
     FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
     FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
     FAM_LEVEL_SORT, FAM_SOLVE_TAIL, FAM_SOLVE_PATCH, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_PLATE_GRID, FAM_PLATE_PROJECT, FAM_SMOOTH_FIELD,
-    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_CLIMATE, FAM_RIVER, FAM_BASIN, FAM_BASIN_SORT, FAM_SOLVE_BASIN, FAM_MISC, FAM_COUNT
+    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_CLIMATE, FAM_RIVER, FAM_BASIN, FAM_BASIN_SORT, FAM_SOLVE_BASIN, FAM_FLOW_TILES, FAM_MISC, FAM_COUNT
 };
 extern const char* const kFamilyNames[FAM_COUNT];
 
@@ -97,6 +97,7 @@ struct Options {
     bool noEventLists = false;         // WO_NO_EVENT_LISTS        solve setup by row scans
     int  flowClimbCap = 0x7fffffff;    // WO_FLOW_CLIMB=n          cap of a thread's climb (0: rake rounds + pointer doubling)
     bool flowEventsStream = false;     // WO_FLOW_EVENTS_STREAM=1  the solve's event lists on a third stream
+    bool flowClimbOnly = false;        // WO_FLOW=climb            flow accumulation by k_flow_climb alone (no tile-local level: kernels_impl.h, k_flow_tiles)
     bool iceRounds = false;            // WO_ICE_ROUNDS=1          synchronous ice accumulation rounds
     int  carveFlow = 2;                // WO_CARVE_FLOW            2 granules, 1 done words, 0 rounds
     long long carveFlowBudgetMs = 200; // WO_CARVE_FLOW_BUDGET_MS  spin budget of the one-launch carve
@@ -150,6 +151,7 @@ struct wo_planet {
     int32_t* d_flowCnt = nullptr; wo::TargetRank* d_tr = nullptr; wo::EventList* d_ev = nullptr; float* d_me = nullptr;
     int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; uint32_t* d_rs[2] = {nullptr, nullptr}; int rsFlip[2] = {0, 0};   /* radix.hip scratch: elevation sort, basin sort */ wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
     uint32_t *d_acc = nullptr, *d_snap = nullptr; unsigned long long* d_accCnt = nullptr;
+    int32_t *d_ftLr = nullptr, *d_ftParent = nullptr, *d_ftExtCnt = nullptr; uint32_t* d_ftInflow = nullptr; unsigned long long* d_ftRootAcc = nullptr;      // two-level flow accumulation (kernels_impl.h: FlowTiles)
     int32_t *d_jump = nullptr, *d_nj = nullptr;
     int32_t* d_doneAt = nullptr;
     double* d_totalExcess = nullptr;

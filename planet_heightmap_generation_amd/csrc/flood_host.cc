@@ -451,7 +451,8 @@ void flood_cell_noise(const FloodScratch& S, double* out) {
 
 namespace {
 struct FloodTimer {
-    bool on = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    bool on;
+    explicit FloodTimer(const FloodScratch& S) : on(S.hooks.timing) {}
     std::chrono::steady_clock::time_point tp = std::chrono::steady_clock::now();
     void lap(const char* what) {
         if (!on) return;
@@ -462,8 +463,19 @@ struct FloodTimer {
 };
 }  // namespace
 
-// land elevations into the compact arrays + the start state of pass 1 (:107-113)
+void FloodHooks::read() {
+    auto num = [](const char* n, int32_t dflt) { const char* v = std::getenv(n); return v ? (int32_t)std::atoi(v) : dflt; };
+    ringMin = num("WO_FLOOD_RING_MIN", 4096);
+    chainsMin = num("WO_FLOOD_CHAINS_MIN", 2048);
+    forceDirty = num("WO_FLOOD_FORCE_DIRTY", -1);
+    const char* rs = std::getenv("WO_FLOOD_REPLAY_STOP");
+    hasReplayStop = rs != nullptr; replayStop = rs ? (float)std::atof(rs) : 0.0f;
+    timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
+}
+
+// land elevations into the compact arrays + the start state of pass 1 (:107-113); every flood call starts here: the hooks are read
 void flood_gather(const float* e, FloodScratch& S) {
+    S.hooks.read();
     const int32_t L = S.L;
     const bool landOrder = S.landOrder;             // e holds the land heights only, in land-index order (FloodScratch::landOrder)
     const int32_t* landCell = S.landCell.data();
@@ -480,7 +492,7 @@ void flood_gather(const float* e, FloodScratch& S) {
 // pass 1 (:118-147): the serial heap walk — the reference's order including its heap's tie mechanics
 void flood_pass1_host(FloodScratch& S) {
     const double EPS = 1e-7;
-    FloodTimer T;
+    FloodTimer T(S);
     const int32_t* landCell = S.landCell.data();
     const int32_t* offL = S.offL.data();
     const int32_t* adjL = S.adjL.data();
@@ -646,16 +658,16 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
         }
     }
 }
-// landmasses of at least WO_FLOOD_RING_MIN cells (default 4096; read per call: the tests run both queues) walk on the ring queue
-inline bool walk_on_ring(int32_t nCells) { const char* v = std::getenv("WO_FLOOD_RING_MIN"); return nCells >= (v ? std::atoi(v) : 4096); }
+// landmasses of at least WO_FLOOD_RING_MIN cells (default 4096; FloodHooks: the tests run both queues) walk on the ring queue
+inline bool walk_on_ring(const FloodScratch& S, int32_t nCells) { return nCells >= S.hooks.ringMin; }
 void walk_landmass_with_stats(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
                               std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats& ws) {
-    if (walk_on_ring(nCells)) walk_landmass_h<RingQueue, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
+    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
     else walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
 }
 void walk_landmass_resume(FloodScratch& S, const std::vector<FloodHeapItem>& frontier, int32_t nCells, hvec<FloodHeapItem>& store,
                           std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
-    if (walk_on_ring(nCells)) walk_landmass_h<RingQueue>(S, nullptr, 0, store, contests, nGroups, nNested, nullptr, frontier.data(), frontier.size());
+    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue>(S, nullptr, 0, store, contests, nGroups, nNested, nullptr, frontier.data(), frontier.size());
     else walk_landmass_h<KeyHeap4>(S, nullptr, 0, store, contests, nGroups, nNested, nullptr, frontier.data(), frontier.size());
 }
 void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
@@ -672,7 +684,7 @@ void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_
     // the ring — exact (device keys and ranks == the host's arithmetic on every cell, fields == oracle), 8.7 against 20 ms on the queue-only replay
     // with ranks per landmass, but with ranks over the whole planet (a landmass's bits are sparse in it) the first flood's walk went 27.6-28.8 ->
     // 25-26 ms and the second flood's, whose keys are mostly raised, 34 -> 41-50 ms: a loss per step.
-    if (walk_on_ring(nCells)) walk_landmass_h<RingQueue>(S, seeds, nSeeds, store, contests, nGroups, nNested);
+    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue>(S, seeds, nSeeds, store, contests, nGroups, nNested);
     else walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
 }
 int flood_workers(int64_t items) {
@@ -683,7 +695,7 @@ int flood_workers(int64_t items) {
 
 bool flood_pass1_landmasses(FloodScratch& S, FloodTieReport& rep) {
     const double EPS = 1e-7;
-    FloodTimer T;
+    FloodTimer T(S);
     const int32_t nComp = (int32_t)S.compSize.size();
     rep = FloodTieReport{};
     rep.landmasses = nComp;
@@ -762,7 +774,6 @@ struct TreeCtx { const FloodCell* st; float* eL; const float* surface; double ca
 // (kernel sum accumulated in path order, weight = term / sum, float store, clamp at 0).  Returns false (nothing changed) if the
 // tree is not a single rooted tree of claimed cells — the caller then takes the plain form.
 // trees of at least this many cells take the chain form (WO_FLOOD_CHAINS_MIN, read per call: the tests run both forms; 0 = never)
-inline int32_t flood_chains_min() { const char* v = std::getenv("WO_FLOOD_CHAINS_MIN"); return v ? std::atoi(v) : 2048; }
 struct ChainScratch {
     std::vector<int32_t> par, kids, kidStart, order, sz, heavy, posOf, headPos, jump, cellAt;
     std::vector<float> E;
@@ -938,7 +949,7 @@ void tree_pass23(const TreeCtx& X, int32_t* cells, int32_t n, std::vector<int32_
 
 // passes 2 and 3 (:152-214) on the state pass 1 left, then the land elevations back into e
 bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const std::vector<std::pair<int32_t, int32_t>>* openAlt) {
-    FloodTimer T;
+    FloodTimer T(S);
     // Cells whose parent pass 1 left open (equal keys, same surface under either parent).  The elevations do not depend
     // on the choice when (i) no carve path runs through the cell — a path exists only below a deficit cell, so then the
     // cell keeps its height through pass 2 and both parents see the same carves — and (ii) pass 3 leaves the cell alone
@@ -1025,7 +1036,7 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
     };
     T.lap("group2");
     std::atomic<int64_t> nDeficit{0}, totLen{0};
-    const TreeCtx ctx{st, eL, surface, carveStrength, onPath, S.localIdx.data(), flood_chains_min()};
+    const TreeCtx ctx{st, eL, surface, carveStrength, onPath, S.localIdx.data(), S.hooks.chainsMin};
     for_trees(cnt2, [&](int32_t tree) {
         static thread_local std::vector<int32_t> path;
         int64_t myLen = 0, myDef = 0;
@@ -1064,7 +1075,7 @@ namespace {
 bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e, float stopLevel,
                              std::vector<std::vector<FloodHeapItem>>* frontier) {
     const double EPS = 1e-7;
-    FloodTimer T;
+    FloodTimer T(S);
     const int32_t L = S.L;
     const int32_t* landCell = S.landCell.data();
     const int32_t* offL = S.offL.data();
@@ -1178,7 +1189,7 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
 // On return e holds the reference's result; FloodScratch is consumed (the caller gathers again before another call).
 bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, FloodTieReport& rep, int64_t& pathRedo, bool replayAllowed) {
     const double EPS = 1e-7;
-    FloodTimer T;
+    FloodTimer T(S);
     const int32_t nComp = (int32_t)S.compSize.size();
     const int32_t L = S.L;
     rep = FloodTieReport{};
@@ -1193,7 +1204,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     float* eL = S.eL.data();
     int32_t* list2 = S.list2.data();
     constexpr int32_t BIG = 32768, CHUNK = 4096;
-    const int32_t chainsMin = flood_chains_min();
+    const int32_t chainsMin = S.hooks.chainsMin;
     struct BigJob {
         int32_t k = -1; std::vector<int32_t> cnt, chunkStart, chunkOrder; bool track = false;
         std::atomic<int> ready{0}; std::atomic<size_t> nextChunk{0}, doneChunks{0};
@@ -1201,7 +1212,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     struct Local { std::vector<Contest> contests; std::vector<std::pair<int32_t, int32_t>> alt; std::vector<int32_t> altComp; int64_t groups = 0, nested = 0, contested = 0, unresolved = 0; float maxLevel = -INFINITY; bool noLevel = false; };
     std::vector<Local> loc(nt);
     std::vector<uint8_t> dirty(std::max(nComp, 1), 0);
-    const int forceDirty = [] { const char* v = std::getenv("WO_FLOOD_FORCE_DIRTY"); return v ? std::atoi(v) : -1; }();     // test hook (read per call): treat this landmass (by rank in size) as undecided
+    const int forceDirty = S.hooks.forceDirty;     // test hook: treat this landmass (by rank in size) as undecided
     // One round over a list of landmasses.  walked: pass 1 of these landmasses is already there (the replay's).
     const auto tRound0 = std::chrono::steady_clock::now();
     auto run_round = [&](const std::vector<int32_t>& list, bool walked) {
@@ -1373,7 +1384,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         bool toTheEnd = forceDirty >= 0;                     // (the test hook has no level: its landmass is replayed in full)
         for (const Local& l : loc) { if (l.noLevel) toTheEnd = true; if (l.maxLevel > stopLevel) stopLevel = l.maxLevel; }
         if (toTheEnd) stopLevel = INFINITY;
-        if (const char* v = std::getenv("WO_FLOOD_REPLAY_STOP")) stopLevel = (float)std::atof(v);      // test hook (read per call)
+        if (S.hooks.hasReplayStop) stopLevel = S.hooks.replayStop;      // test hook
         std::vector<std::vector<FloodHeapItem>> frontier(nComp);
         if (replay_dirty_landmasses(S, dirty, e, stopLevel, &frontier)) {
             std::atomic<int> contestedAgain{0};

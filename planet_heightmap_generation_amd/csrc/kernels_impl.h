@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
         if (F.accA) F.accA[r] = a;                           // (the pointer doubling's accumulator: nullptr on the default route, where k_flow_climb retires every cell)
         F.jumpA[r] = j; F.accCnt[r] = 1ull;
-        if (j >= 0) atomicAdd(&donorCnt[j], 1);              // donorCnt is all zero on entry (k_flow_final leaves it so)
+        if (j >= 0 && donorCnt) atomicAdd(&donorCnt[j], 1);  // donorCnt is all zero on entry (k_flow_final leaves it so); nullptr: the tile route counts a cell's donors itself (k_flow_tiles)
         if (F.lateDonor && t >= 0 && !F.ocean[t] && !(F.rank[r] < F.rank[t])) F.lateDonor[t] = 1;      // r's total is added to t's flow by the totals pass, not forwarded
         if (F.basinJ) {                                      // start state of the drainage-component search (basin.hip: k_basin_init's job, one launch less on the layout's chain)
             const bool landT = t >= 0 && !F.ocean[t];
@@ -317,6 +317,165 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_climb(Fields F, const int32_t
         }
     }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Flow accumulation in two levels (default under the land-first mirror; WO_FLOW=climb: k_flow_climb alone).
+// k_flow_climb pays one returning device-scope atomic — a round trip to the memory side, ~0.5 us under load — per cell of the longest
+// flow path (a few hundred cells at 10 M: ~200 us per launch with the chip idle).  The land cells are numbered in Morton order, so a TILE
+// of FT_CELLS consecutive ids is a compact patch and ~95 % of the forward edges stay inside one.  Hence:
+//   1. k_flow_tiles<false>  one workgroup per tile: the forest restricted to the tile's own edges, in LDS — child counts, the local root
+//                           of every cell (pointer jumping), and the same last-arriver climb as k_flow_climb on LDS atomics (~0.1 us per
+//                           hop).  Out: lr[c] = local root of c, acc[R] = cells of R's local tree for every local root R.
+//   2. k_flow_root_links    a local root whose receiver lies in another tile is a child of THAT cell's local root: arrival counts.
+//   3. k_flow_root_climb    k_flow_climb on the forest of local roots (its depth is the number of tiles a river crosses: tens, not
+//                           hundreds); every root's total W is also added to inflow[x] of the cell x it drains into.
+//   4. k_flow_tiles<true>   the local climb again with the weight 1 + inflow[c] per cell: the forward total of EVERY cell (-> accCnt).
+// Integer sums over the same forest: any order of the additions is exact (test_flow_accumulation_routes_agree).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef WO_FT_CELLS
+#define WO_FT_CELLS 1024
+#endif
+#ifndef WO_FT_THREADS
+#define WO_FT_THREADS 256
+#endif
+constexpr int FT_CELLS = WO_FT_CELLS, FT_THREADS = WO_FT_THREADS, FT_PER = FT_CELLS / FT_THREADS;
+static_assert(FT_CELLS % FT_THREADS == 0 && FT_CELLS < 0xffff, "tile cells are 16-bit indices");
+struct FlowTiles {
+    int32_t* lr;                    // [L] local root of a land cell
+    unsigned long long* rootAcc;    // [L] per local root: {arrived children roots, running total}
+    uint32_t* inflow;               // [L] totals of the roots of other tiles that drain into this cell (zero between passes)
+    int32_t* extCnt;                // [L] per local root: roots of other tiles that drain into its tree (zero between passes)
+    int32_t* parent;                // [L] per local root: the local root of the cell it drains into, -1: none
+    int32_t* basinJ;                // nullable: start state of the basin layout's component search (basin.hip), shortened in place by k_flow_tiles<false>
+};
+template <bool FINAL>
+__global__ __launch_bounds__(FT_THREADS) void k_flow_tiles(Fields F, FlowTiles T) {
+    __shared__ uint32_t s_pc[FT_CELLS];                // low 16 bits: parent inside the tile (0xffff: none / another tile), high 16: children inside the tile
+    __shared__ unsigned long long s_acc[FT_CELLS];     // {arrived children, running total} as in k_flow_climb
+    __shared__ uint16_t s_lr[FINAL ? 1 : FT_CELLS];
+    __shared__ uint16_t s_b[FINAL ? 1 : FT_CELLS];       // basin layout: receiver of the cell inside the tile (any receiver edge, not only forward ones), or the cell itself
+    __shared__ int32_t s_bext[FINAL ? 1 : FT_CELLS];     //    and what J held for the cell
+    const int tid = threadIdx.x;
+    const int32_t base = (int32_t)blockIdx.x * FT_CELLS;
+    const int32_t n = min((int32_t)FT_CELLS, F.L - base);
+#pragma unroll
+    for (int q = 0; q < FT_PER; ++q) {
+        const int i = tid + q * FT_THREADS;
+        if (i >= n) continue;
+        const int32_t j = F.jumpA[base + i];
+        const bool local = j >= base && j < base + n;
+        s_pc[i] = local ? (uint32_t)(j - base) : 0xffffu;
+        uint32_t w = 1u;
+        if (FINAL) { w += T.inflow[base + i]; T.inflow[base + i] = 0u; T.extCnt[base + i] = 0; }
+        s_acc[i] = (unsigned long long)w;
+        if (!FINAL) s_lr[i] = local ? (uint16_t)(j - base) : (uint16_t)i;
+        if (!FINAL && T.basinJ) {
+            const int32_t jb = T.basinJ[base + i];
+            s_b[i] = (jb >= base && jb < base + n) ? (uint16_t)(jb - base) : (uint16_t)i;
+            s_bext[i] = jb;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FT_PER; ++q) {
+        const int i = tid + q * FT_THREADS;
+        if (i >= n) continue;
+        const uint32_t p = s_pc[i] & 0xffffu;
+        if (p != 0xffffu) atomicAdd(&s_pc[p], 1u << 16);
+    }
+    __syncthreads();
+    // the climb: a cell without children hands its total to its parent; whoever completes a parent carries on with it
+#pragma unroll
+    for (int q = 0; q < FT_PER; ++q) {
+        const int i = tid + q * FT_THREADS;
+        if (i >= n) continue;
+        const uint32_t pc0 = s_pc[i];
+        if ((pc0 >> 16) != 0u || (pc0 & 0xffffu) == 0xffffu) continue;
+        uint32_t p = pc0 & 0xffffu;
+        uint32_t v = (uint32_t)s_acc[i];
+        for (;;) {
+            const uint32_t pcp = s_pc[p];                         // fixed since the barrier above
+            const unsigned long long old = atomicAdd(&s_acc[p], (1ull << 32) | (unsigned long long)v);
+            if ((uint32_t)(old >> 32) + 1u != (pcp >> 16)) break; // other children of p are still out
+            v += (uint32_t)old;
+            p = pcp & 0xffffu;
+            if (p == 0xffffu) break;                              // p was a local root
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < FT_PER; ++q) {
+        const int i = tid + q * FT_THREADS;
+        if (i >= n) continue;
+        const uint32_t total = (uint32_t)s_acc[i];
+        if (FINAL) F.accCnt[base + i] = (unsigned long long)total;
+        else {
+            // local root: asynchronous pointer jumping in place, no barrier (whatever a thread reads in s_lr is an ancestor of the cell it
+            // stands on, so concurrent chases only shorten each other's paths; a local forest has no cycle: forward edges follow the ranks)
+            uint16_t r = s_lr[i];
+            for (int it = 0; it < FT_CELLS; ++it) {
+                const uint16_t rr = s_lr[r];
+                if (rr == r) break;
+                s_lr[i] = rr;                                    // (16-bit LDS stores: a reader sees the old or the new ancestor)
+                r = rr;
+            }
+            T.lr[base + i] = base + (int32_t)r;
+            if ((s_pc[i] & 0xffffu) == 0xffffu) T.rootAcc[base + i] = (unsigned long long)total;
+            if (T.basinJ) {
+                // The layout's component search (basin.hip: basin_root) accepts in J[x] ANY ancestor of x and chases from there.  Every forward
+                // edge is an edge of the layout's forest too, so x's path there runs through its local root r found above; what r points at
+                // decides: a cell of another tile (or r itself: a root) -> J[x] <- that.  If r's receiver lies inside the tile (an edge that
+                // is not a forward one: a donor ranked after its receiver, ~1 %) the walk goes on READ-ONLY (halving the pointers in place
+                // would split a ring of four cells draining into each other — they occur on flats — into two rings of two) until it
+                // leaves the tile; a walk that comes back to r (a ring) or is not over after 64 steps ends at r: J[x] <- r, and r keeps its own.
+                const uint16_t b0 = s_b[r];
+                int32_t out = s_bext[r];
+                if (b0 != r) {
+                    int32_t res = -1;
+                    uint16_t c = b0;
+                    for (int it = 0; it < 64; ++it) {
+                        const uint16_t cc = s_b[c];
+                        if (cc == c) { res = s_bext[c]; break; }
+                        if (cc == r) break;
+                        c = cc;
+                    }
+                    out = res >= 0 ? res : ((uint16_t)i == r ? s_bext[i] : base + (int32_t)r);
+                }
+                T.basinJ[base + i] = out;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_root_links(Fields F, FlowTiles T) {
+    WO_GRID_STRIDE(i, F.L) {
+        if (T.lr[i] != i) continue;
+        const int32_t x = F.jumpA[i];
+        int32_t P = -1;
+        if (x >= 0) { P = T.lr[x]; atomicAdd(&T.extCnt[P], 1); }
+        T.parent[i] = P;                                          // the local root this root's tree drains into (-1: none)
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_flow_root_climb(Fields F, FlowTiles T) {
+    WO_GRID_STRIDE(i, F.L) {
+        if (T.lr[i] != i || T.extCnt[i] != 0) continue;
+        int32_t P = T.parent[i];
+        if (P < 0) continue;
+        int32_t x = F.jumpA[i];
+        uint32_t v = (uint32_t)T.rootAcc[i];
+        for (;;) {
+            // one round trip per hop, as in k_flow_climb: everything the NEXT hop needs of P (fixed since k_flow_root_links) goes out with the hand-over
+            const int32_t need = T.extCnt[P];
+            const int32_t PP = T.parent[P];
+            const int32_t xx = F.jumpA[P];
+            atomicAdd(&T.inflow[x], v);
+            const unsigned long long old = atomicAdd(&T.rootAcc[P], (1ull << 32) | (unsigned long long)v);
+            if ((int32_t)(old >> 32) + 1 != need) break;
+            if (PP < 0) break;
+            v += (uint32_t)old;
+            P = PP; x = xx;
+        }
+    }
+}
+
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount, int32_t fromClimb) {
     const int32_t groups = (L + 3) / 4;
     WO_BLOCK_STRIDE(g, valid, groups) {
@@ -375,13 +534,13 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_events(Fields F, SolveOut* cl
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_totals(Fields F, int32_t* donorCnt) {
     WO_XCD_LAND(i, c) {
-        donorCnt[c] = 0;                                    // for the next iteration's receivers pass
+        if (donorCnt) donorCnt[c] = 0;                      // for the next iteration's receivers pass
         flow_totals_cell(F, c);
     }
 }
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt, SolveOut* clearOut) {
     WO_XCD_LAND(i, c) {
-        donorCnt[c] = 0;                                    // for the next iteration's receivers pass (only land cells are counted into)
+        if (donorCnt) donorCnt[c] = 0;                      // for the next iteration's receivers pass (only land cells are counted into)
         if (clearOut) { SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0; clearOut[i] = z; }      // the solve's output tags of this pass (store index i: one coalesced sweep, was a memset launch)
         flow_final_cell(F, c);                              // + the event list of c for the solve
     }

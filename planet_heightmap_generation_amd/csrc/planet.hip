@@ -26,7 +26,7 @@ const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
     "ocean_from_elevation", "sort_keys", "sort_radix", "rank_scatter", "receivers", "flow_init", "flow_climb",
     "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort", "solve_basin", "misc"};
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort", "solve_basin", "flow_tiles", "misc"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
@@ -689,6 +689,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     ensure_scratch(p);
     hipStream_t s = p->ctx->stream;
     if (hIters > 0) WO_HIP(hipMemsetAsync(p->d_flowCnt, 0, (size_t)p->N * sizeof(int32_t), s));   // k_flow_final keeps it zero between iterations; a call that was cut short may not have
+    if (hIters > 0 && p->d_ftInflow) { WO_HIP(hipMemsetAsync(p->d_ftInflow, 0, (size_t)p->N * 4, s)); WO_HIP(hipMemsetAsync(p->d_ftExtCnt, 0, (size_t)p->N * 4, s)); }   // (k_flow_tiles<true> keeps them zero)
     const int32_t N = p->N;
     const int gridN = xcd_grid(N);
     StageClock clk(p);
@@ -980,6 +981,18 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             const int climbCap = p->opt.flowClimbCap;
             const bool climbAll = climbCap == 0x7fffffff;
             if (climbAll) F.accA = nullptr;            // no pointer doubling after the one-launch climb: the receivers pass does not write its accumulator
+            // two-level accumulation (k_flow_tiles): needs the land cells to be the ids 0 .. L-1 in Morton order (land-first mirror)
+            const bool flowTiles = climbAll && p->landIdentity && !p->opt.flowClimbOnly;
+            FlowTiles FT{};
+            if (flowTiles) {
+                if (!p->d_ftLr) {
+                    p->d_ftLr = dalloc<int32_t>((size_t)N); p->d_ftParent = dalloc<int32_t>((size_t)N); p->d_ftExtCnt = dalloc<int32_t>((size_t)N); p->d_ftInflow = dalloc<uint32_t>((size_t)N); p->d_ftRootAcc = dalloc<unsigned long long>((size_t)N);
+                    WO_HIP(hipMemsetAsync(p->d_ftInflow, 0, (size_t)N * 4, s)); WO_HIP(hipMemsetAsync(p->d_ftExtCnt, 0, (size_t)N * 4, s));
+                }
+                FT.lr = p->d_ftLr; FT.parent = p->d_ftParent; FT.rootAcc = p->d_ftRootAcc; FT.inflow = p->d_ftInflow; FT.extCnt = p->d_ftExtCnt;
+            }
+            int32_t* const donorCnt = flowTiles ? (int32_t*)nullptr : p->d_flowCnt;
+            bool tilesFirstDone = false, linksDone = false;
             // three streams: the event lists of the solve (they need the receivers only) are built on a stream of their own beside the flow
             // accumulation (main) and the basin layout (side); the totals pass after the accumulation is a coalesced sweep, because the
             // receivers pass flags the few cells that have a late donor.  MEASURED, NOT FASTER, off by default (WO_FLOW_EVENTS_STREAM=1): with
@@ -987,7 +1000,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             // 27, and the setup starts at the same moment (profiles/r03bc_*): these "latency-bound" launches do fill the memory pipelines
             // when two of them already run side by side.  Default: k_flow_final after the accumulation.
             // unchecked basin pass: its one launch tags what it produces with a number no earlier pass of this planet used
-            const bool passTagged = basin && !checkEveryPass && F.ev != nullptr && !p->opt.flowEventsStream && !graphRoute;      // (a replayed graph launches with the captured tag)
+            const bool passTagged = basin && !checkEveryPass && F.ev != nullptr && !graphRoute;      // (a replayed graph launches with the captured tag)
             const bool eventsStreamEnv = p->opt.flowEventsStream;
             const bool eventsStream = eventsStreamEnv && basin && basinOverlap && climbAll && F.ev;
             if (eventsStream) {
@@ -995,7 +1008,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 F.lateDonor = p->d_lateDonor;
             }
             clk.begin("receivers");
-            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, p->d_flowCnt);        // + flow start state and donor counts
+            launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, donorCnt);        // + flow start state and donor counts
             clk.end();
             F.basinJ = nullptr;
             // basin-local solve (basin.hip): this pass's store order groups every drainage component with everything it depends on.
@@ -1011,6 +1024,15 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prGreatest));
                     WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
                 }
+                // two-level flow accumulation: its first kernel also shortens the layout's start state inside every tile (k_flow_tiles<false>:
+                // J[c] <- an ancestor at most a tile away), so the layout's component search starts after it, from chains of tiles instead of cells
+                const bool tilesFeedLayout = flowTiles && basinJFromReceivers && slotIdentity;
+                if (tilesFeedLayout) {
+                    FT.basinJ = p->d_basinJ;
+                    launch(p, FAM_FLOW_TILES, k_flow_tiles<false>, (int)(((int64_t)L + FT_CELLS - 1) / FT_CELLS), FT_THREADS, F, FT);
+                    tilesFirstDone = true;
+                    if (std::getenv("WO_X_FORK_AFTER_LINKS")) { launch(p, FAM_FLOW_TILES, k_flow_root_links, blocks_for(L, 4096), WO_BLOCK, F, FT); linksDone = true; }      // EXPERIMENT (session r05h)
+                }
                 WO_HIP(hipEventRecord(p->evFork, s));
                 WO_HIP(hipStreamWaitEvent(p->side, p->evFork, 0));
                 p->onSide = true;
@@ -1021,7 +1043,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     if (!p->side2) { WO_HIP(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking)); WO_HIP(hipEventCreateWithFlags(&p->evJoin2, hipEventDisableTiming)); }
                     WO_HIP(hipStreamWaitEvent(p->side2, p->evFork, 0));
                     hipStream_t keep = p->side; p->side = p->side2; p->onSide = true;          // launch() follows cur_stream(): the planet's side stream slot
-                    try { launch(p, FAM_FLOW_FINAL, k_flow_events, gridL, WO_BLOCK, F, p->d_out); } catch (...) { p->side = keep; p->onSide = false; throw; }
+                    try { launch(p, FAM_FLOW_FINAL, k_flow_events, gridL, WO_BLOCK, F, passTagged ? (SolveOut*)nullptr : p->d_out); } catch (...) { p->side = keep; p->onSide = false; throw; }
                     p->side = keep; p->onSide = false;
                     WO_HIP(hipEventRecord(p->evJoin2, p->side2));
                 }
@@ -1035,6 +1057,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             //                    very long unbranched chains, where one thread's walk would bound the launch)
             //  WO_FLOW_CLIMB=0   the synchronous rake rounds + pointer doubling of earlier builds
             // 10 M cells, flow stage per step: rake rounds 108 ms, cap 12: 69, cap 128: 60, cap 256: 59, no cap: 45 (profiles/r02r_*).
+            if (flowTiles) {
+                const int tiles = (int)(((int64_t)L + FT_CELLS - 1) / FT_CELLS);
+                if (!tilesFirstDone) launch(p, FAM_FLOW_TILES, k_flow_tiles<false>, tiles, FT_THREADS, F, FT);
+                if (!linksDone) launch(p, FAM_FLOW_TILES, k_flow_root_links, blocks_for(L, 4096), WO_BLOCK, F, FT);
+                launch(p, FAM_FLOW_TILES, k_flow_root_climb, blocks_for(L, 4096), WO_BLOCK, F, FT);
+                launch(p, FAM_FLOW_TILES, k_flow_tiles<true>, tiles, FT_THREADS, F, FT);
+            } else
             if (climbCap > 0) launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, (const int32_t*)p->d_flowCnt, (int32_t)climbCap);
             if (!climbAll) {
                 {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
@@ -1064,10 +1093,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             {
                 Fields Ff = F;
                 if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
-                if (eventsStream) launch(p, FAM_FLOW_FINAL, k_flow_totals, gridL, WO_BLOCK, Ff, p->d_flowCnt);
+                if (eventsStream) launch(p, FAM_FLOW_FINAL, k_flow_totals, gridL, WO_BLOCK, Ff, donorCnt);
                 // the solve's outputs are cleared (tags 0) only for a pass whose result is checked on the spot (k_solve_patch / k_solve_final read
                 // the tags as launch numbers); the unchecked pass stamps them with a tag of its own instead (passTag below): 16 B per land cell less to write
-                else launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, p->d_flowCnt, (basin && !passTagged) ? p->d_out : (SolveOut*)nullptr);
+                else launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, donorCnt, (basin && !passTagged) ? p->d_out : (SolveOut*)nullptr);
             }
             clk.end();
             clk.begin("solve");
@@ -1148,7 +1177,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
-                     {"flow_rounds_total", (double)flowRounds}, {"ice_rounds_total", (double)iceRounds},
+                     {"flow_rounds_total", (double)flowRounds}, {"flow_two_level", (p->d_ftLr && p->landIdentity && !p->opt.flowClimbOnly && p->opt.flowClimbCap == 0x7fffffff && hIters > 0) ? 1.0 : 0.0}, {"ice_rounds_total", (double)iceRounds},
                      {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"carve_flow_launches_with_leftovers", (double)carveFlowLeft}, {"solve_check_every_pass", checkEveryPass ? 1.0 : 0.0}, {"calls_run_again_with_checks", (double)p->redoCalls}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
                      {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
@@ -1251,6 +1280,7 @@ Options Options::from_env() {
     o.noEventLists = set("WO_NO_EVENT_LISTS");
     if (set("WO_FLOW_CLIMB")) o.flowClimbCap = std::max(0, std::atoi(std::getenv("WO_FLOW_CLIMB")));
     o.flowEventsStream = on("WO_FLOW_EVENTS_STREAM");
+    o.flowClimbOnly = str("WO_FLOW") == "climb";
     o.iceRounds = on("WO_ICE_ROUNDS");
     if (set("WO_CARVE_FLOW")) o.carveFlow = std::atoi(std::getenv("WO_CARVE_FLOW"));
     if (set("WO_CARVE_FLOW_BUDGET_MS")) o.carveFlowBudgetMs = std::atoll(std::getenv("WO_CARVE_FLOW_BUDGET_MS"));
@@ -1413,7 +1443,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

@@ -34,7 +34,17 @@ WO_FLOOD_HD inline double flood_cell_noise_of(int32_t r) {
 }
 struct FloodHeapItem { float key; int32_t cell; };
 struct FloodCell { float e; int32_t drain; float surface; int32_t root; };   // one 16-byte record per land cell: a pop touches one line for all four
+// Test hooks and diagnostics of the host flood, read from the environment ONCE per flood call (flood_gather) — never inside a walk.
+struct FloodHooks {
+    int32_t ringMin = 4096;        // WO_FLOOD_RING_MIN     landmasses of at least this many cells walk on the ring of key buckets
+    int32_t chainsMin = 2048;      // WO_FLOOD_CHAINS_MIN   drainage trees of at least this many cells carve on the chain-ordered copy
+    int32_t forceDirty = -1;       // WO_FLOOD_FORCE_DIRTY  treat this landmass (by rank in size) as undecided
+    bool hasReplayStop = false; float replayStop = 0.0f;     // WO_FLOOD_REPLAY_STOP  the level at which the replay of the single heap stops
+    bool timing = false;           // WO_FLOOD_TIMING       laps -> stderr
+    void read();
+};
 struct FloodScratch {
+    FloodHooks hooks;
     // static per (mesh, positions, ocean mask)
     bool staticValid = false; int32_t staticN = -1; int32_t L = 0; int64_t staticVersion = 0;
     hvec<int32_t> landCell, landIndex, offL, adjL, seedCell, landByR;   // landByR: land indices in ascending original id

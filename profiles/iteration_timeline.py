@@ -24,5 +24,5 @@ for r in rows[a:b]:
     q = r.get("Queue_Id", "0")
     gap = (s - last_end[q]) / 1000 if q in last_end else 0.0
     last_end[q] = e
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:70]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:70]
     print(f"{(s - t0) / 1000:9.1f} {(e - s) / 1000:8.1f} {gap:7.1f} {q:>6}  {name}")

@@ -37,7 +37,7 @@ def test_bench_line_schema_helpers():
     kernels = {k for p in bench.PASSES.values() for k in p["kernels"]}
     assert kernels >= {"solve_basin", "solve_setup", "thermal_apply", "receivers", "sort_radix"}
     assert sum(p["budget"][0] for p in bench.PASSES.values()) == 243.0 and sum(p["budget"][1] for p in bench.PASSES.values()) == 12.0
-    alt = {"solve_patch", "solve_round"}                      # alternatives of solve_basin: only one of the three runs in a pass
+    alt = set(bench.ALTERNATIVES)                             # alternatives of solve_basin / flow_tiles: only one of them runs in a pass
     for name, p in bench.PASSES.items():
         assert sum(v[0] for k, v in p["kernels"].items() if k not in alt) == p["budget"][0], name
 
@@ -69,7 +69,7 @@ def test_committed_pmc_file_covers_the_default_paths_kernels():
     and not the round's bench line."""
     import bench
     have = [k.replace("(anonymous namespace)::", "") for k, v in json.loads(bench.PMC_FILE.read_text()).items() if isinstance(v, dict)]
-    for fam in ("sort_radix", "sort_keys", "receivers", "flow_climb", "flow_final", "solve_setup", "solve_basin", "thermal_excess", "thermal_apply"):
+    for fam in ("sort_radix", "sort_keys", "receivers", "flow_final", "solve_setup", "solve_basin", "thermal_excess", "thermal_apply"):
         if fam not in bench.FAMILY_KERNEL:
             continue
         names = bench.FAMILY_KERNEL[fam] if isinstance(bench.FAMILY_KERNEL[fam], tuple) else (bench.FAMILY_KERNEL[fam],)

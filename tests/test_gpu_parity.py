@@ -366,7 +366,9 @@ def test_mirror_layout_is_invisible(TP, oracle, monkeypatch):
 
 
 def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
-    """Flow accumulation (js/terrain-post.js:604-611) = subtree sizes of the drainage forest.  Default: one launch in which the
+    """Flow accumulation (js/terrain-post.js:604-611) = subtree sizes of the drainage forest.  Default: two levels — the same
+    last-arriver climb inside every tile of 1 024 cells on LDS atomics, a climb over the tiles' local roots, and the tile sums
+    again with the inflows (k_flow_tiles); WO_FLOW=climb: one launch over all cells in which the
     thread that completes a receiver carries on with it (k_flow_climb); WO_FLOW_CLIMB=n caps a thread's walk and leaves the rest
     to the pointer doubling; WO_FLOW_CLIMB=0 is the synchronous rake + pointer doubling.  Integer sums: all routes must give the
     oracle's field bit for bit, on ordinary and on quantised (flat-heavy: long unbranched chains) terrain."""
@@ -381,10 +383,14 @@ def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
     for field in (e0, eq):
         oc = (field <= 0).astype(np.uint8)
         ref = oracle.erode_composite(om, field, xyz, oc, *args, nd)
-        for route in (None, "3", "40", "0", "events"):
+        for route in (None, "climb", "3", "40", "0", "events"):
             monkeypatch.delenv("WO_FLOW_EVENTS_STREAM", raising=False)
-            if route is None:
+            monkeypatch.delenv("WO_FLOW", raising=False)
+            if route is None:                           # two levels: tile-local climbs in LDS + a climb over the tiles' local roots (k_flow_tiles)
                 monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+            elif route == "climb":                      # the one-launch climb over all cells
+                monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
+                monkeypatch.setenv("WO_FLOW", "climb")
             elif route == "events":                     # the solve's event lists on a third stream beside the accumulation, totals pass with late-donor flags
                 monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
                 monkeypatch.setenv("WO_FLOW_EVENTS_STREAM", "1")
@@ -394,12 +400,14 @@ def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
             pl.erode_composite(got, oc, *args)
             st = pl.last_erode_stats()
             assert np.array_equal(got, ref), (route, int((got != ref).sum()))
-            if route in (None, "events"):
+            assert st["flow_two_level"] == (1.0 if route in (None, "events") else 0.0), (route, st["flow_two_level"])
+            if route in (None, "climb", "events"):
                 assert st["flow_rounds_total"] == 0, st["flow_rounds_total"]          # nothing left for the pointer doubling
             elif route in ("3", "0"):
                 assert st["flow_rounds_total"] > 0, (route, st["flow_rounds_total"])  # the doubling really ran
     monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
     monkeypatch.delenv("WO_FLOW_EVENTS_STREAM", raising=False)
+    monkeypatch.delenv("WO_FLOW", raising=False)
     pl.close()
 
 
@@ -513,10 +521,12 @@ def test_config3_checksum_of_the_benched_field(TP):
     pl.warp_terrain_resident(1, 0.75)
     pl.ocean_from_elevation()
     pl.erode_composite_resident(200, 3e-4, 0.5, 1.0, 200, 1.16, 0.015, 10, 0.5)
+    stats = pl.last_erode_stats()
     pl.apply_soil_creep_resident(3, 0.1125)
     out = pl.download()
     assert abs(float(out.astype(np.float64).sum()) - gold["sum"]) < 1e-5 * out.size      # RMS-scale guard before the exact check
     assert int(zlib.crc32(out.tobytes())) == gold["crc32"], "field differs from the oracle's"
+    assert stats["calls_run_again_with_checks"] == 0 and stats["flow_two_level"] == 1.0, stats
     pl.close()
 
 
@@ -543,6 +553,7 @@ def _checksum_case(TP, key, cells, seed, iters, g):
     pl.close()
     assert abs(float(out.astype(np.float64).sum()) - gold["sum"]) < 1e-5 * out.size      # RMS-scale guard before the exact check
     assert int(zlib.crc32(out.tobytes())) == gold["crc32"], "field differs from the oracle's"
+    assert stats["calls_run_again_with_checks"] == 0, "a basin-solve launch left tasks pending (the layout split a drainage component?)"
     return stats
 
 
@@ -554,6 +565,15 @@ def test_config4_size_checksum_on_one_gpu(TP):
     print({k: v for k, v in stats.items() if k.startswith("flood_host")})
     assert stats["flood_host_serial_pass1"] == 0
     assert stats["solve_basin_passes_with_leftovers"] == 0
+
+
+def test_config4_full_length_checksum_on_one_gpu(TP):
+    """BASELINE config 4's planet at its OWN iteration count: 40 M cells, 200 composite iterations (10 glacial), one GPU.  The oracle's
+    CRC (53 minutes of one core, oracle/ref_harness/make_crc_config3.py 40000000 1 200) is the one bench.py's one-planet leg checks
+    its timed steps against."""
+    stats = _checksum_case(TP, "40000000_iters200", 40_000_000, 1, 200, 10)
+    print({k: v for k, v in stats.items() if k.startswith("flood_host") or k == "flood_stage_ms"})
+    assert stats["flood_host_serial_pass1"] == 0 and stats["solve_basin_passes_with_leftovers"] == 0
 
 
 def test_config4_decomposed_8_shares_checksum(TP):
@@ -582,6 +602,29 @@ def test_config4_decomposed_8_shares_checksum(TP):
     assert sum(st["flood_exchange_whole_planet_floods"] for st in stats) >= 1            # the exchange was needed (else the test has no power)
     assert all(st["flood_host_serial_pass1"] == 0 for st in stats)
     assert int(zlib.crc32(merged.tobytes())) == gold["crc32"], "merged field differs from the oracle's"
+
+
+def test_config4_two_processes_over_gloo(TP, tmp_path):
+    """BASELINE config 4's planet (40 M cells, 20 iterations) as two PROCESSES sharing this GPU, the flood exchange and the merge over
+    torch.distributed (gloo): the multi-process path at a size where flood calls ARE undecided (the thread form of the same plan:
+    test_config4_decomposed_8_shares_checksum).  Every rank must end on the oracle's field.  The RCCL form of the exchange
+    (csrc/comm.hip: flood_link_exchange) still has never had a peer: RCCL refuses two ranks on one device, and this pool has one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import GOLDEN, REPO
+    gold = json.loads((GOLDEN / "crc_config3.json").read_text())["40000000"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", WO_FLOOD_THREADS="12", WO_HOST_THREADS="32")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29741",
+                    str(REPO / "tests" / "config4_worker.py"), str(tmp_path), str(gold["cells"]), str(gold["seed"]), str(gold["iterations"]), str(gold["gIters"])],
+                   check=True, env=env, timeout=1500)
+    res = json.loads((tmp_path / "result.json").read_text())
+    print(res)
+    assert len(res) == 2 and sum(r["land_cells"] for r in res) == gold["land_cells"]
+    assert sum(r["whole_planet_floods"] for r in res) >= 1 and res[0]["gathers"] >= 1          # the exchange was needed: the test has power
+    assert all(r["serial_pass1"] == 0 for r in res)
+    assert all(r["crc32"] == gold["crc32"] for r in res), [r["crc32"] for r in res]
 
 
 def test_decomposed_shares_with_flood_exchange_small(TP, oracle):
