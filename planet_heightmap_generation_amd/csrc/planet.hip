@@ -786,7 +786,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     FloodRun floodRun;
     auto leftovers_so_far = [&]() {
         if (checkEveryPass || !p->d_pendingEver) return;
-        if (read_count(p, p->d_pendingEver) != 0) throw RedoWithChecks{};
+        if (read_count(p, p->d_pendingEver) != 0) {
+            if (p->opt.floodTiming) {          // (diagnostic runs only) which of the two reasons: a splitter-sort bucket that did not fit, or a basin launch with leftovers
+                int32_t h[8] = {0};
+                WO_HIP(hipMemcpy(h, p->d_pendingEver, sizeof(h), hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[erode] call runs again with checks: %d basin-solve tasks were left pending\n", h[0]);
+            }
+            throw RedoWithChecks{};
+        }
     };
     auto flood = [&](double cs) {
         leftovers_so_far();                    // the host is about to read the field
@@ -1031,7 +1038,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     FT.basinJ = p->d_basinJ;
                     launch(p, FAM_FLOW_TILES, k_flow_tiles<false>, (int)(((int64_t)L + FT_CELLS - 1) / FT_CELLS), FT_THREADS, F, FT);
                     tilesFirstDone = true;
-                    if (std::getenv("WO_X_FORK_AFTER_LINKS")) { launch(p, FAM_FLOW_TILES, k_flow_root_links, blocks_for(L, 4096), WO_BLOCK, F, FT); linksDone = true; }      // EXPERIMENT (session r05h)
+                    // (the root links too before the fork: beside the layout's first kernel — high-priority stream — they took 33 us instead of 15; flow stage 45.9 -> 43.8 ms per step, profiles/r05h_*)
+                    launch(p, FAM_FLOW_TILES, k_flow_root_links, blocks_for(L, 4096), WO_BLOCK, F, FT);
+                    linksDone = true;
                 }
                 WO_HIP(hipEventRecord(p->evFork, s));
                 WO_HIP(hipStreamWaitEvent(p->side, p->evFork, 0));

@@ -645,11 +645,20 @@ def test_decomposed_shares_with_flood_exchange_small(TP, oracle):
     assert stats[0]["flood_exchange_calls"] == 2
 
 
-@pytest.mark.parametrize("seed", [2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("seed", list(range(2, 17)))
 def test_config5_seeds_checksum(TP, seed):
-    """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 .. 9, 20 composite iterations (1 glacial),
-    CRC == the oracle's (seed 1 at the full 200 iterations: test_config3_checksum_of_the_benched_field)."""
+    """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 .. 16, 20 composite iterations (1 glacial),
+    CRC == the oracle's (seed 1 at the full 200 iterations: test_config3_checksum_of_the_benched_field; seeds 2 and 3 at the full
+    200 iterations: test_config5_seeds_full_length_checksum)."""
     stats = _checksum_case(TP, f"10000000_seed{seed}_iters20", 10_000_000, seed, 20, 1)
+    assert stats["flood_host_serial_pass1"] == 0
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_config5_seeds_full_length_checksum(TP, seed):
+    """Two more planets of BASELINE config 5 at the full 200 iterations (10 glacial): CRC == the oracle's (10-12 minutes of one core each,
+    oracle/ref_harness/make_crc_config3.py 10000000 <seed> 200)."""
+    stats = _checksum_case(TP, f"10000000_seed{seed}_iters200", 10_000_000, seed, 200, 10)
     assert stats["flood_host_serial_pass1"] == 0
 
 
@@ -818,6 +827,14 @@ def test_sort_routes_agree_under_ties(TP, oracle, monkeypatch):
     monkeypatch.setenv("WO_SORT", "hipcub")
     got = eq.copy(); pl.erode_composite(got, oc, *args)
     assert np.array_equal(got, ref), int((got != ref).sum())
+    monkeypatch.delenv("WO_SORT")
+    # so few distinct heights that a single key holds a fifth of the land
+    e4 = (np.round(e0 * 4) / 4).astype(np.float32)
+    oc4 = (e4 <= 0).astype(np.uint8)
+    args4 = (4, 3e-4, 0.5, 1.0, 4, 1.16, 0.015, 0, 0.0)
+    ref4 = oracle.erode_composite(om, e4, xyz, oc4, *args4, nd)
+    got = e4.copy(); pl.erode_composite(got, oc4, *args4)
+    assert np.array_equal(got, ref4), int((got != ref4).sum())
     pl.close()
 
 
