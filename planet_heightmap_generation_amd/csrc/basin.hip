@@ -324,10 +324,6 @@ __global__ __launch_bounds__(64 * NW, (NW <= 4 ? 4 : 2)) void k_solve_flowing(Fi
     static_assert(LOOKBACK + LAG + 1 <= RCHUNKS, "ring too small for the lag");
     __shared__ unsigned long long s_ring[2 * RING];
     __shared__ int32_t s_prog[NW];                     // super-chunks each wave has finished
-#ifdef WO_X_SOLVE_LDS_PAD
-    __shared__ unsigned long long s_pad[WO_X_SOLVE_LDS_PAD / 8];      // EXPERIMENT: fewer workgroups per CU
-    if (threadIdx.x == 0 && launchTag == -12345) s_pad[0] = 1;
-#endif
     __shared__ int32_t s_level[STATS ? RING : 1];      // WO_BASIN_STATS (diagnostic): depth of every task in the dependency DAG
     __shared__ int32_t s_maxLevel;
     __shared__ unsigned long long s_passes[STATS ? NW : 1], s_readyPasses[STATS ? NW : 1], s_clk[4];
