@@ -477,9 +477,26 @@ def relaxed_mode_leg(pl, seed, params, exact_field, cells, ks=(4, 32, 1000000)):
                             rms_vs_exact=float(np.sqrt((d * d).mean())), max_abs_vs_exact=float(np.abs(d).max()), cells_differing=int((f != exact_field).sum())))
     finally:
         os.environ.pop("WO_RELAXED_SORT_EVERY", None)
+    # SURVEY 7.3's whole relaxed mode (WO_RELAXED=full): one sort per flood, the implicit solve as an affine recurrence composed by pointer jumping with the
+    # deposition applied afterwards, the glacial carve from a snapshot (csrc/kernels_impl.h: k_affine_*, k_carve_jacobi); the flood and the thermal pass as they are
+    full = None
+    try:
+        os.environ["WO_RELAXED"] = "full"
+        one_step(pl, seed, params); pl.sync()
+        t0 = time.perf_counter()
+        one_step(pl, seed, params); pl.sync()
+        ms = (time.perf_counter() - t0) * 1e3
+        f = pl.download()
+        d = f.astype(np.float64) - exact_field.astype(np.float64)
+        full = dict(mode="relaxed", what="one sort per flood + affine pointer-jumping solve with deferred deposition + Jacobi glacial carve", ms_per_step=round(ms, 1),
+                    value=round(cells * iters / (ms / 1e3) / 1e6, 1), rms_vs_exact=float(np.sqrt((d * d).mean())), max_abs_vs_exact=float(np.abs(d).max()),
+                    cells_differing=int((f != exact_field).sum()), stage_ms={k: round(v, 2) for k, v in pl.last_stage_timing().items()})
+    finally:
+        os.environ.pop("WO_RELAXED", None)
     return dict(note="RELAXED MODE, not parity: landCells re-sorted every K-th iteration only (stale visiting order in between); north_star's bound is RMS < 1e-5; "
-                     "everything else (flood, dependency-ordered solve / carve / thermal replay) is unchanged, so this isolates what the order itself costs",
-                runs=out)
+                     "everything else (flood, dependency-ordered solve / carve / thermal replay) is unchanged, so this isolates what the order itself costs.  `full`: "
+                     "every order-defined pass of the iteration replaced by an order-free one (SURVEY 7.3's roofline mode)",
+                runs=out, full=full)
 
 
 def one_planet_leg(TP, args, rank, world, dist, local_rank):

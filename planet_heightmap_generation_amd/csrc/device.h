@@ -108,6 +108,7 @@ struct Options {
     bool stageTimingAll = false;       // WO_STAGE_TIMING=all      bracket every iteration
     bool graphs = false;               // WO_GRAPH=1               hipGraph replay of the steady composite iteration (measured slower: planet.hip)
     int  relaxedSortEvery = 1;         // WO_RELAXED_SORT_EVERY=K  RELAXED MODE (not parity): re-sort landCells every K-th iteration only
+    bool relaxedFull = false;          // WO_RELAXED=full          RELAXED MODE (not parity): one sort per flood, affine pointer-jumping solve with deferred deposition, Jacobi carve (kernels_impl.h)
     static Options from_env();
 };
 }  // namespace wo
@@ -161,7 +162,7 @@ struct wo_planet {
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
     hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; bool onSide = false;
     hipStream_t side2 = nullptr; hipEvent_t evJoin2 = nullptr; uint8_t* d_lateDonor = nullptr;        // third stream: the solve's event lists beside the flow accumulation and the layout; late-donor flags of the receivers pass   // second stream of the planet: the basin layout runs beside the flow accumulation (planet.hip)
-    uint32_t* d_basinKey = nullptr; int32_t* d_basinVals[2] = {nullptr, nullptr}; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; uint8_t* d_basinLong = nullptr; int64_t basinLaunches = 0; int64_t solvePassSerial = 0;   /* unchecked basin passes so far (their output tag: planet.hip, passTag) */   // basin.hip: component roots (Morton slot space), group-major store order of the pass
+    uint32_t* d_basinKey = nullptr; int32_t* d_basinVals[2] = {nullptr, nullptr}; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; uint8_t* d_basinLong = nullptr; int64_t basinLaunches = 0; wo::Affine* d_affine[2] = {nullptr, nullptr};   /* relaxed mode: the affine recurrence, ping-pong */ int64_t solvePassSerial = 0;   /* unchecked basin passes so far (their output tag: planet.hip, passTag) */   // basin.hip: component roots (Morton slot space), group-major store order of the pass
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
     int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
     void* d_sortTemp = nullptr; size_t sortTempBytes = 0;

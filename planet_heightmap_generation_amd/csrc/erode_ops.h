@@ -79,6 +79,7 @@ struct alignas(8) TargetRank { int32_t target; int32_t rank; };
 constexpr int WO_EVENTS = WO_EVENTS_N;
 struct alignas(16) EventList { int32_t cell[WO_EVENTS]; int32_t rank[WO_EVENTS]; };     // unused slots: rank -1; overflow: rank[0] == -2
 constexpr int WO_CARVE_DEPS = 24;       // dependency slots per active carve task (a task with more takes the scanning form, and a round lasts as long as its slowest task)
+struct alignas(16) Affine { float a, b; int32_t j; int32_t pad; };       // relaxed mode (kernels_impl.h): h'(r) = a + b * h'(j); j < 0: h'(r) = a
 struct Fields {
     int32_t N;                 // numRegions
     int32_t xcdTile;           // blocks per XCD tile for index-order kernels (device.h: xcd_tile)

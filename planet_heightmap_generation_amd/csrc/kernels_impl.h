@@ -1410,6 +1410,89 @@ __global__ __launch_bounds__(WO_BLOCK) void k_moraine_fjord(Fields F, double gDe
     WO_XCD_CELLS(r, F.N) moraine_fjord_cell(F, r, gDep, gFjord);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// RELAXED MODE (WO_RELAXED=full; SURVEY 7.3's "roofline mode") — NOT the reference's semantics, never used for parity or for `value`.
+// The order-defined parts of an iteration are replaced by order-free ones: landCells is sorted once per flood (the passes keep comparing
+// the stale ranks pairwise), the implicit solve becomes an affine recurrence composed by pointer jumping with the deposition applied
+// afterwards from the old slopes, the glacial carve reads a snapshot (Jacobi).  bench.py reports its time and its distance from the
+// exact field as `relaxed_mode`.
+// ---------------------------------------------------------------------------------------------------------------------
+// js/terrain-post.js:614-627 without the order: h' = (h + f * hr) / (1 + f) with hr = max(h'(t), 0) is affine in h'(t) along a forward edge that
+// descends; an ocean receiver, a late edge (the receiver's turn comes later: it still has its old height) and a cell without a receiver are
+// final at once; a forward edge that does not descend gives h' = max(.., hr) = hr
+__global__ __launch_bounds__(WO_BLOCK) void k_affine_init(Fields F, Affine* X) {
+    WO_XCD_LAND(i, r) {
+        const TargetRank trr = F.tr[r];
+        const int32_t t = trr.target;
+        const double h = F.e[r];
+        Affine A; A.pad = 0; A.j = -1; A.b = 0.0f;
+        if (t < 0) A.a = (float)h;
+        else {
+            const double f = solve_factor_of(F.flow[r], F.cellDist[r], F.solveK, F.solveM, F.solveDt);
+            const TargetRank trt = F.tr[t];
+            const double et = F.e[t];
+            const bool forward = trt.rank >= 0 && trr.rank < trt.rank;            // (ocean cells carry rank -1)
+            if (!forward) {
+                const double hr = et > 0 ? et : 0;
+                double hn = (h + f * hr) / (1 + f);
+                hn = hn < hr ? hr : hn; hn = hn < 0 ? 0 : hn;
+                A.a = (float)hn;
+            } else if (et >= h) { A.a = 0.0f; A.b = 1.0f; A.j = t; }
+            else { A.a = (float)(h / (1 + f)); A.b = (float)(f / (1 + f)); A.j = t; }
+        }
+        X[r] = A;
+    }
+}
+__global__ __launch_bounds__(WO_BLOCK) void k_affine_jump(Fields F, const Affine* __restrict__ in, Affine* __restrict__ out) {
+    WO_XCD_LAND(i, r) {
+        Affine A = in[r];
+        if (A.j >= 0) { const Affine B = in[A.j]; A.a = (float)((double)A.a + (double)A.b * (double)B.a); A.b = (float)((double)A.b * (double)B.b); A.j = B.j; }
+        out[r] = A;
+    }
+}
+// the new height of every land cell: its solved height plus what its donors deposit on it (js/terrain-post.js:628-640, deposits taken from the OLD slope of the cell
+// and applied in one sum; the cap of a deposit at the donor's new height is dropped with the order)
+__global__ __launch_bounds__(WO_BLOCK) void k_affine_apply(Fields F, const Affine* __restrict__ X, float* __restrict__ out) {
+    WO_XCD_LAND(i, c) {
+        double hc = X[c].a; if (hc < 0) hc = 0;
+        const TargetRank trc = F.tr[c];
+        double slope = 0;
+        if (trc.target >= 0) { const float cd = F.cellDist[c]; if (cd > 0) slope = fabs((double)F.e[c] - (double)F.e[trc.target]) / (double)cd; }
+        const double frac = 0.5 / (1 + slope * 50);
+        double dep = 0;
+        for (int32_t jn = F.off[c]; jn < F.off[c + 1]; ++jn) {
+            const int32_t d = F.adj[jn];
+            if (F.tr[d].target != c) continue;                                   // (ocean cells carry target -1)
+            double hd = X[d].a; if (hd < 0) hd = 0;
+            const double eroded = (double)F.e[d] - hd;
+            if (eroded > 0) dep += eroded * frac;
+        }
+        const float v = (float)(hc + dep);
+        out[c] = v; F.me[c] = v;
+    }
+}
+// the glacial carve from a snapshot (js/terrain-post.js:506-526 as a Jacobi pass): every active cell's own deepening and convergence bonus, and the widening every
+// active neighbour would apply to this cell, all from the heights before the pass
+__global__ __launch_bounds__(WO_BLOCK) void k_carve_jacobi(Fields F, const float* __restrict__ in, float* __restrict__ out, double gCarveRate, double gConvergenceBonus, double glacialStrength) {
+    WO_XCD_LAND(i, c) {
+        const double h = in[c];
+        double e = h;
+        const double flc = F.iceFlow[c];
+        if (flc > 0.1) { e -= gCarveRate * pow(flc, 0.6) * glacialStrength; if (F.iceUp[c] >= 2) e -= gConvergenceBonus * pow(flc, 0.4); }
+        for (int32_t jn = F.off[c]; jn < F.off[c + 1]; ++jn) {
+            const int32_t nb = F.adj[jn];
+            if (F.ocean[nb]) continue;
+            const double fl = F.iceFlow[nb];
+            if (!(fl > 0.1)) continue;
+            const double deep = gCarveRate * pow(fl, 0.6) * glacialStrength;
+            const double slope = fabs(((double)in[nb] - deep) - h) / nd_or_eps(F.dist[jn]);
+            const double w = 1 - slope;
+            if (w > 0) e -= deep * 0.4 * w;
+        }
+        out[c] = (float)e;
+    }
+}
+
 // ---- patch-major mirror of the mesh for erodeComposite (planet.hip: Mirror).  perm: mirror id -> cell id, inv: the inverse ----
 __global__ __launch_bounds__(WO_BLOCK) void k_mirror_gather_f32(const float* src, const int32_t* perm, float* dst, int32_t n) { WO_GRID_STRIDE(i, n) dst[i] = src[perm[i]]; }
 __global__ __launch_bounds__(WO_BLOCK) void k_mirror_scatter_f32(const float* src, const int32_t* perm, float* dst, int32_t n) { WO_GRID_STRIDE(i, n) dst[perm[i]] = src[i]; }

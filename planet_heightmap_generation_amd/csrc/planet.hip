@@ -842,9 +842,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const bool graphRoute = O.graphs && !p->profiling && !checkEveryPass && basinSolve && p->patchVersion >= 0 && O.flowClimbCap == 0x7fffffff && !O.flowEventsStream &&
                             !O.noEventLists && !O.basinStats && !O.sortLibrary && O.relaxedSortEvery <= 1 && p->maxDeg <= 16 && total > 16;
     int64_t graphReplays = 0;
+    bool sortAfterFlood = false;
     for (int32_t iter = 0; iter < total; ++iter) {
         clk.on = true;
-        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); }
+        if (!midDone && iter >= midIter) { midDone = true; flood(0.85); sortAfterFlood = true; }
         clk.on = stageAll || p->profiling || total <= 16 || iter % 8 == 0;
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
         const bool graphable = graphRoute && !clk.on && !gNow && hNow && iter < tIters && iter >= 2 && p->side != nullptr;
@@ -862,7 +863,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         // WO_RELAXED_SORT_EVERY=K (relaxed mode, NOT the reference's semantics: SURVEY 7.3): landCells is re-sorted only every K-th
         // iteration; in between the passes run with a stale visiting order (still a consistent order: every pass compares ranks
         // pairwise, so the dataflow is well defined, it is just not the reference's).  Measured, never reported as parity.
-        const bool sortNow = p->opt.relaxedSortEvery <= 1 || iter % p->opt.relaxedSortEvery == 0;
+        const bool relaxedFull = p->opt.relaxedFull;           // RELAXED MODE, not parity (kernels_impl.h): one sort per flood, affine solve, Jacobi carve
+        const bool sortNow = relaxedFull ? (iter == 0 || sortAfterFlood) : (p->opt.relaxedSortEvery <= 1 || iter % p->opt.relaxedSortEvery == 0);
+        if ((gNow || hNow) && sortNow) sortAfterFlood = false;
         if ((gNow || hNow) && sortNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
 
         if (gNow) {
@@ -877,6 +880,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
                     launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
                 });
+            if (relaxedFull) {          // RELAXED: the carve from a snapshot of the heights, one sweep
+                launch(p, FAM_CARVE_ROUND, k_carve_jacobi, gridL, WO_BLOCK, F, (const float*)p->d_e, p->d_e2, gCarve, gConv, gStrength);
+                swap_elev(p);
+                launch(p, FAM_MORAINE, k_moraine_fjord, gridN, WO_BLOCK, p->fields(), gDep, gFjord);
+                clk.end();
+            } else {
             // WO_CARVE_FLOW=0: no one-launch carve (k_carve_flow), activation list in arrival order as in earlier builds
             const int carveFlowMode = p->opt.carveFlow;      // 2: heights as granules (k_carve_granules), 1: done words (k_carve_flow), 0: rounds
             const bool carveFlow = carveFlowMode != 0;
@@ -973,13 +982,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             }
             launch(p, FAM_MORAINE, k_moraine_fjord, gridN, WO_BLOCK, F, gDep, gFjord);
             clk.end();
+            }
         }
 
         if (hNow) {
             if (gNow && sortNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             F.solveK = K; F.solveM = m; F.solveDt = dt;
-            const bool basin = basinSolve && p->patchVersion >= 0;
+            const bool basin = basinSolve && p->patchVersion >= 0 && !relaxedFull;
             // the receivers pass also leaves the start state of the layout's component search
             const bool basinJFromReceivers = basin;
             const bool slotIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;          // land-first mirror: a land cell's Morton slot is its id
@@ -1102,6 +1112,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             {
                 Fields Ff = F;
                 if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
+                if (relaxedFull) Ff.ev = nullptr;                // (no event lists: the relaxed solve has no order)
                 if (eventsStream) launch(p, FAM_FLOW_FINAL, k_flow_totals, gridL, WO_BLOCK, Ff, donorCnt);
                 // the solve's outputs are cleared (tags 0) only for a pass whose result is checked on the spot (k_solve_patch / k_solve_final read
                 // the tags as launch numbers); the unchecked pass stamps them with a tag of its own instead (passTag below): 16 B per land cell less to write
@@ -1109,6 +1120,16 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             }
             clk.end();
             clk.begin("solve");
+            if (relaxedFull) {
+                // RELAXED: h' = a + b h'(receiver) composed by pointer jumping (12 doublings cover chains of 4 096 cells), then heights + deposits in one sweep
+                if (!p->d_affine[0]) { p->d_affine[0] = dalloc<Affine>((size_t)N); p->d_affine[1] = dalloc<Affine>((size_t)N); }
+                launch(p, FAM_SOLVE_SETUP, k_affine_init, gridL, WO_BLOCK, F, p->d_affine[0]);
+                int cur = 0;
+                for (int q = 0; q < 12; ++q, cur ^= 1) launch(p, FAM_SOLVE_ROUND, k_affine_jump, gridL, WO_BLOCK, F, (const Affine*)p->d_affine[cur], p->d_affine[cur ^ 1]);
+                launch(p, FAM_SOLVE_FINAL, k_affine_apply, gridL, WO_BLOCK, F, (const Affine*)p->d_affine[cur], p->d_e2);
+                swap_elev(p);
+                clk.end();
+            } else {
             if (basin) {
                 if (basinOverlap && eventsStream) WO_HIP(hipStreamWaitEvent(s, p->evJoin2, 0));
                 WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0));
@@ -1146,6 +1167,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (!solveFinals) launch(p, FAM_SOLVE_FINAL, k_solve_final, gridL, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
             swap_elev(p);
             clk.end();
+            }
         }
 
         if (iter < tIters) {
@@ -1196,7 +1218,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
                      {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_replays", (double)floodRun.host.replays}, {"flood_host_replayed_landmasses", (double)floodRun.host.replayedLandmasses}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
                      {"flood_host_pass23_ms", floodRun.host.pass23Ms},
-                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"iterations_replayed_from_graph", (double)graphReplays}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}};
+                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"relaxed_full", p->opt.relaxedFull ? 1.0 : 0.0}, {"iterations_replayed_from_graph", (double)graphReplays}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
@@ -1300,6 +1322,7 @@ Options Options::from_env() {
     o.stageTimingAll = str("WO_STAGE_TIMING") == "all";
     if (set("WO_GRAPH")) o.graphs = std::atoi(std::getenv("WO_GRAPH")) != 0;
     if (set("WO_RELAXED_SORT_EVERY")) o.relaxedSortEvery = std::max(1, std::atoi(std::getenv("WO_RELAXED_SORT_EVERY")));
+    o.relaxedFull = str("WO_RELAXED") == "full";
     return o;
 }
 
@@ -1452,7 +1475,7 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_affine[0]); dfree(p->d_affine[1]); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);

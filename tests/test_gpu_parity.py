@@ -867,6 +867,34 @@ def test_solve_kernel_and_tile_staging_routes_agree(TP, oracle, monkeypatch):
     pl.close()
 
 
+def test_relaxed_mode_runs_and_is_not_the_parity_path(TP, oracle, monkeypatch):
+    """WO_RELAXED=full (SURVEY 7.3's roofline mode: one sort per flood, affine pointer-jumping solve with deferred deposition, Jacobi glacial
+    carve) is a MEASUREMENT mode: it must run, say so in the stats, stay in the neighbourhood of the exact field — and differ from it (the
+    default path is the exact one and equals the oracle; nothing relaxed is ever reported as parity)."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(200000, 0.75, 4)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(4)
+    e0, oc = pl.download(), pl.download_ocean()
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    args = (12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 3, 0.5)
+    ref = oracle.erode_composite(om, e0, xyz, oc, *args, nd)
+    exact = e0.copy(); pl.erode_composite(exact, oc, *args)
+    assert pl.last_erode_stats()["relaxed_full"] == 0.0 and rms(exact, ref) < RMS_TOL
+    monkeypatch.setenv("WO_RELAXED", "full")
+    relaxed = e0.copy(); pl.erode_composite(relaxed, oc, *args)
+    st = pl.last_erode_stats()
+    monkeypatch.delenv("WO_RELAXED")
+    assert st["relaxed_full"] == 1.0 and st["sorts"] <= 3
+    assert np.isfinite(relaxed).all() and np.array_equal(relaxed[oc != 0], e0[oc != 0])          # ocean cells untouched
+    d = rms(relaxed, exact)
+    print(f"relaxed vs exact: rms {d:.2e}, cells differing {int((relaxed != exact).sum())}")
+    assert 0 < d < 0.05
+    again = e0.copy(); pl.erode_composite(again, oc, *args)                                          # and the exact path is what it was
+    assert np.array_equal(again, exact)
+    pl.close()
+
+
 def test_land_count_shrinks_and_grows_on_one_planet(TP, oracle):
     """Masks of very different land counts on ONE planet (what a rank of the landmass decomposition sees when plans change): a
     large land mass, then a few cells of land, then the large one again.  The in-tree radix sort keeps per-planet scratch whose
