@@ -198,19 +198,24 @@ int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t*
     const int tiles = rs_tiles(n), groups = rs_groups(n);
     const size_t gtWords = (size_t)rs_groups(nMax) * RS_DIGITS;
     uint32_t* counts = scratch + 2 * gtWords;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+    // profiled runs bracket every kernel on its own (as wo::launch does): a family's time is then the sum of its kernels' durations, comparable
+    // with a rocprofv3 kernel trace, and not the length of the whole sort with the gaps a side stream waits in
+    auto bracketed = [&](auto&& launchIt) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
+        launchIt();
+        if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({family, a, b}); if (p->pending.size() >= 4096) profile_resolve(p); }
+    };
     int cur = 0;
     for (int q = 0; q < passes; ++q, ++flip) {
         uint32_t* gt = scratch + (size_t)(flip & 1) * gtWords;
         uint32_t* gtOther = scratch + (size_t)((flip + 1) & 1) * gtWords;
-        hipLaunchKernelGGL(k_rs_count, dim3(tiles), dim3(RS_THREADS), 0, s, (const uint32_t*)keys[cur], n, beginBit + 8 * q, counts, gt);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(tiles), dim3(RS_THREADS), 0, s, (const uint32_t*)keys[cur], (const int32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
-                           beginBit + 8 * q, (const uint32_t*)counts, (const uint32_t*)gt, (int32_t)groups, gtOther, (q == passes - 1) ? posOut : (int32_t*)nullptr);
+        bracketed([&] { hipLaunchKernelGGL(k_rs_count, dim3(tiles), dim3(RS_THREADS), 0, s, (const uint32_t*)keys[cur], n, beginBit + 8 * q, counts, gt); });
+        bracketed([&] { hipLaunchKernelGGL(k_rs_scatter, dim3(tiles), dim3(RS_THREADS), 0, s, (const uint32_t*)keys[cur], (const int32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
+                           beginBit + 8 * q, (const uint32_t*)counts, (const uint32_t*)gt, (int32_t)groups, gtOther, (q == passes - 1) ? posOut : (int32_t*)nullptr); });
         cur ^= 1;
     }
     WO_HIP(hipGetLastError());
-    if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({family, a, b}); }
     return cur;
 }
 
