@@ -48,8 +48,6 @@ struct KeyHeap {
     hvec<HeapItem>& d;
     size_t n = 0;
     explicit KeyHeap(hvec<HeapItem>& storage) : d(storage) {}
-    const HeapItem& top(size_t q) const { return d.data()[q]; }            // q < n: the q-th entry of the array (the first ones pop soon)
-    template <class Fn> void for_each(Fn&& fn) const { const HeapItem* h = d.data(); for (size_t q = 0; q < n; ++q) fn(h[q]); }
     void push(int32_t c, float kc) {
         size_t i = n++;
         if (d.size() < n + 2) d.resize(d.size() * 2 + 1024);
@@ -88,78 +86,6 @@ struct KeyHeap {
         }
         return top;
     }
-};
-
-// The same logical heap — the reference's array and sift rules, index for index — on a cache-blocked PHYSICAL layout, for the replay of the
-// single heap (replay_dirty_landmasses), whose heap holds millions of entries (40 MB at 40 M cells: a pop sinks ~22 levels and every level
-// below the cached top is a miss).  Three levels of the logical tree (7 nodes) share one 64-byte block: logical node m (1-based) lives in
-// block B at local position l (1 = the block's top, 2-3, 4-7), B and l following m's path from the root three bits at a time; the eight
-// child blocks of a block are contiguous.  A root-to-leaf path touches one line per three levels instead of one per level.  Which entry sits
-// at which LOGICAL index is exactly the reference's at every moment, so its choices between equal keys are the reference's.
-struct KeyHeapBlocked {
-    hvec<HeapItem>& d;      // 8 items per block, slot 0 of every block unused
-    size_t n = 0;           // logical size
-    explicit KeyHeapBlocked(hvec<HeapItem>& storage) : d(storage) {}
-    static inline size_t phys(size_t m) {                    // m >= 1
-        const int D = 63 - __builtin_clzll((unsigned long long)m);
-        size_t B = 0;
-        int rem = D;
-        while (rem >= 3) { rem -= 3; B = 8 * B + 1 + ((m >> rem) & 7u); }
-        return 8 * B + ((size_t(1) << rem) | (m & ((size_t(1) << rem) - 1)));
-    }
-    static inline size_t blocks_for_depth(int D) { size_t b = 1, tot = 1; for (int q = 0; q < D / 3; ++q) { b *= 8; tot += b; } return tot; }
-    const HeapItem& top(size_t q) const { return d.data()[q + 1]; }        // q < 7: the logical top three levels are block 0
-    void reserve_for(size_t m) {
-        const int D = 63 - __builtin_clzll((unsigned long long)m);
-        const size_t need = 8 * blocks_for_depth(D) + 8;
-        if (d.size() < need) d.resize(need);
-    }
-    void push(int32_t c, float kc) {
-        size_t m = ++n;
-        if ((m & (m - 1)) == 0 || d.size() < 16) reserve_for(m);           // a new level: room for all its blocks
-        HeapItem* h = d.data();
-        size_t pm = phys(m);
-        while (m > 1) {
-            const size_t par = m >> 1;
-            // parent's place: inside the block when the node is not the block's top, else the leaf of the parent block it hangs under
-            const size_t l = pm & 7u, B = pm >> 3;
-            const size_t pp = l > 1 ? 8 * B + (l >> 1) : 8 * ((B - 1) >> 3) + 4 + (((B - 1) & 7u) >> 1);
-            if (kc >= h[pp].key) break;
-            h[pm] = h[pp];
-            pm = pp; m = par;
-        }
-        h[pm] = HeapItem{kc, c};
-    }
-    int32_t pop() {
-        HeapItem* h = d.data();
-        const int32_t topCell = h[1].cell;
-        const HeapItem last = h[phys(n)];
-        --n;
-        if (n > 0) {
-            const float kc = last.key;
-            size_t m = 1, pm = 1;
-            for (;;) {
-                const size_t lm = 2 * m;
-                if (lm > n) break;
-                const size_t l = pm & 7u, B = pm >> 3;
-                size_t pl, pr;
-                if (l < 4) { pl = 8 * B + 2 * l; pr = pl + 1; }
-                else { const size_t cb = 8 * B + 1 + 2 * (l - 4); pl = 8 * cb + 1; pr = pl + 8; }
-                size_t s = lm, ps = pl;
-                if (lm + 1 <= n && h[pr].key < h[pl].key) { s = lm + 1; ps = pr; }
-                if (!(h[ps].key < kc)) break;
-                h[pm] = h[ps];
-                m = s; pm = ps;
-                if ((pm & 7u) == 1) {          // a new block: its three levels are one line; ask for the eight blocks below it (one contiguous 512-byte stretch) now
-                    const size_t cb0 = 8 * (pm >> 3) + 1;
-                    if (8 * cb0 < d.size()) for (int q = 0; q < 8; ++q) __builtin_prefetch(&h[8 * (cb0 + q)]);
-                }
-            }
-            h[pm] = last;
-        }
-        return topCell;
-    }
-    template <class Fn> void for_each(Fn&& fn) const { const HeapItem* h = d.data(); for (size_t m = 1; m <= n; ++m) fn(h[phys(m)]); }
 };
 
 // The landmass walks never rely on how their queue orders EQUAL keys (that is what the tie groups are for), so they need the
@@ -341,26 +267,6 @@ constexpr int32_t UNVISITED = -2, TO_OCEAN = -3, NO_TARGET = -1;
 
 }  // namespace
 int64_t flood_queues_differ(int64_t ops, uint64_t seed) { return queues_differ(ops, seed); }
-// Test support: the blocked heap against the reference-layout heap on a random operation sequence FULL of equal keys; returns the number of pops whose
-// CELL differs (the choice between equal keys is what the replay is for).
-int64_t flood_blocked_heap_differs(int64_t ops, uint64_t seed) {
-    hvec<HeapItem> sa(1024), sb(1024);
-    KeyHeap a(sa); KeyHeapBlocked b(sb);
-    uint64_t x = seed * 0x9E3779B97F4A7C15ull + 11;
-    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
-    int64_t bad = 0; int32_t id = 0;
-    bool draining = false;
-    for (int64_t op = 0; op < ops; ++op) {
-        if (a.n == 0) draining = false;
-        if (!draining && rnd() % 8192 == 0) draining = true;
-        const bool doPop = a.n > 0 && (draining || rnd() % 100 < 48);
-        if (doPop) { const int32_t ca = a.pop(), cb = b.pop(); if (ca != cb) ++bad; }
-        else { const float k = (float)(rnd() % 64) * 0.125f; a.push(id, k); b.push(id, k); ++id; }          // 64 distinct keys: ties everywhere
-        if (a.n != b.n) return -1;
-    }
-    while (a.n > 0) { const int32_t ca = a.pop(), cb = b.pop(); if (ca != cb) ++bad; }
-    return bad + (b.n != 0);
-}
 
 // Everything that depends only on (mesh, positions, r_isOcean): Morton order, compact land numbering and CSR, the
 // open-ocean component (largest, first wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose
@@ -565,8 +471,6 @@ void FloodHooks::read() {
     const char* rs = std::getenv("WO_FLOOD_REPLAY_STOP");
     hasReplayStop = rs != nullptr; replayStop = rs ? (float)std::atof(rs) : 0.0f;
     timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
-    const char* rh = std::getenv("WO_FLOOD_REPLAY_HEAP");
-    replayPlainHeap = rh && std::string(rh) == "plain";
 }
 
 // land elevations into the compact arrays + the start state of pass 1 (:107-113); every flood call starts here: the hooks are read
@@ -1168,9 +1072,8 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
 namespace {
 // stopLevel: the replay ends as soon as the heap's smallest key exceeds it (+inf: runs to the end); then `frontier[k]` receives the
 // entries the heap still holds for dirty landmass k, in array order, and true is returned.  See flood_landmass_pipeline.
-template <class Heap>
-bool replay_dirty_landmasses_h(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e, float stopLevel,
-                               std::vector<std::vector<FloodHeapItem>>* frontier) {
+bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e, float stopLevel,
+                             std::vector<std::vector<FloodHeapItem>>* frontier) {
     const double EPS = 1e-7;
     FloodTimer T(S);
     const int32_t L = S.L;
@@ -1229,7 +1132,7 @@ bool replay_dirty_landmasses_h(FloodScratch& S, const std::vector<uint8_t>& dirt
     });
     T.lap("replay prep");
     if (S.heapStore.size() < 4096) S.heapStore.resize(4096);
-    Heap heap(S.heapStore);
+    KeyHeap heap(S.heapStore);
     for (size_t s = 0; s < S.seedCell.size(); ++s) {        // :118-128, ascending r: every seed of the planet
         const int32_t i = S.seedCell[s];
         if (dirty[i]) { st[i].drain = TO_OCEAN; st[i].root = (int32_t)s; }
@@ -1238,13 +1141,14 @@ bool replay_dirty_landmasses_h(FloodScratch& S, const std::vector<uint8_t>& dirt
     int64_t realPops = 0, pops = 0;
     bool stopped = false;
     while (heap.n > 0) {
-        if (heap.top(0).key > stopLevel) { stopped = true; break; }
+        if (S.heapStore.data()[0].key > stopLevel) { stopped = true; break; }
         const int32_t c = heap.pop();
         ++pops;
         {
+            const FloodHeapItem* hp = S.heapStore.data();
             const size_t lim2 = heap.n < 7 ? heap.n : 7;
-            for (size_t q = 0; q < lim2; ++q) { const int32_t cc = heap.top(q).cell; __builtin_prefetch(&cs[cc]); __builtin_prefetch(&dirty[cc]); }
-            if (heap.n > 0) __builtin_prefetch(&ci[cs[heap.top(0).cell]]);
+            for (size_t q = 0; q < lim2; ++q) { const int32_t cc = hp[q].cell; __builtin_prefetch(&cs[cc]); __builtin_prefetch(&dirty[cc]); }
+            if (heap.n > 0) __builtin_prefetch(&ci[cs[hp[0].cell]]);
         }
         if (!dirty[c]) {
             for (int32_t j = cs[c]; j < cs[c + 1]; ++j) heap.push(ci[j].cell, ci[j].key);
@@ -1265,17 +1169,14 @@ bool replay_dirty_landmasses_h(FloodScratch& S, const std::vector<uint8_t>& dirt
             heap.push(nb, k);
         }
     }
-    if (stopped && frontier) heap.for_each([&](const FloodHeapItem& it) { if (dirty[it.cell]) (*frontier)[S.localIdx[it.cell]].push_back(it); });
+    if (stopped && frontier) {
+        const FloodHeapItem* hp = S.heapStore.data();
+        for (size_t q = 0; q < heap.n; ++q) if (dirty[hp[q].cell]) (*frontier)[S.localIdx[hp[q].cell]].push_back(hp[q]);
+    }
     T.lap("replay");
     if (T.on) std::fprintf(stderr, "[flood] replay: %lld cells walked for real of %d; %s after %lld pops (level %.9g), %zu entries left in the heap\n", (long long)realPops, L,
                            stopped ? "stopped" : "ran to the end", (long long)pops, (double)stopLevel, heap.n);
     return stopped;
-}
-// the replay's heap: the reference's logical heap on the cache-blocked layout (KeyHeapBlocked); WO_FLOOD_REPLAY_HEAP=plain: on the plain array (cross-check)
-bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e, float stopLevel,
-                             std::vector<std::vector<FloodHeapItem>>* frontier) {
-    if (S.hooks.replayPlainHeap) return replay_dirty_landmasses_h<KeyHeap>(S, dirtyComp, e, stopLevel, frontier);
-    return replay_dirty_landmasses_h<KeyHeapBlocked>(S, dirtyComp, e, stopLevel, frontier);
 }
 }  // namespace
 

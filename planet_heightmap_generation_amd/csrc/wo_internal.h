@@ -41,7 +41,6 @@ struct FloodHooks {
     int32_t forceDirty = -1;       // WO_FLOOD_FORCE_DIRTY  treat this landmass (by rank in size) as undecided
     bool hasReplayStop = false; float replayStop = 0.0f;     // WO_FLOOD_REPLAY_STOP  the level at which the replay of the single heap stops
     bool timing = false;           // WO_FLOOD_TIMING       laps -> stderr
-    bool replayPlainHeap = false;  // WO_FLOOD_REPLAY_HEAP=plain  the replay of the single heap on the plain array instead of the cache-blocked layout (same logical heap)
     void read();
 };
 struct FloodScratch {
@@ -89,7 +88,6 @@ void priority_flood_carve_host(int32_t N, const int32_t* off, const int32_t* adj
                                const uint8_t* ocean, double carveStrength, FloodScratch& S);
 // the pieces of the call above, used by the device flood (pass 1 on the GPU, passes 2/3 per drainage tree on the host)
 int64_t flood_queues_differ(int64_t ops, uint64_t seed);            // test support: RingQueue against the 4-ary heap on a random operation sequence
-int64_t flood_blocked_heap_differs(int64_t ops, uint64_t seed);     // test support: the cache-blocked layout of the reference's heap against the plain one, pop for pop (cells), with equal keys everywhere
 void flood_cell_noise(const FloodScratch& S, double* out);            // cellNoise per land cell, compact order
 void flood_gather(const float* e, FloodScratch& S);                   // land elevations -> compact arrays, pass-1 start state
 void flood_pass1_host(FloodScratch& S);                               // serial heap walk (reference order incl. heap tie mechanics)

@@ -657,4 +657,3 @@ extern "C" int64_t emu_solve_turn_forms_differ(int64_t n, uint64_t seed) {
 }
 
 extern "C" int64_t emu_flood_queues_differ(int64_t ops, uint64_t seed) { return flood_queues_differ(ops, seed); }
-extern "C" int64_t emu_flood_blocked_heap_differs(int64_t ops, uint64_t seed) { return flood_blocked_heap_differs(ops, seed); }
