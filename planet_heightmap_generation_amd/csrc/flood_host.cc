@@ -470,6 +470,8 @@ void FloodHooks::read() {
     forceDirty = num("WO_FLOOD_FORCE_DIRTY", -1);
     const char* rs = std::getenv("WO_FLOOD_REPLAY_STOP");
     hasReplayStop = rs != nullptr; replayStop = rs ? (float)std::atof(rs) : 0.0f;
+    replayPrefix = num("WO_FLOOD_PREFIX", 1) != 0;
+    forcePrefixPermille = std::min(1000, std::max(0, num("WO_FLOOD_FORCE_PREFIX", 0)));
     timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
 }
 
@@ -571,11 +573,17 @@ namespace {
 struct TieGroup { float level; int32_t firstFam, fam; };
 struct Contest { int32_t cell, other; float level; };
 
+// The pops of a walk up to the first tie group that holds a contested cell (of either kind), in order.  `prefix` = the pops before the
+// OUTERMOST group open at that moment opened: up to there every equal-key decision was without consequence, so any min-first walk of the
+// landmass — the single heap's included — has popped exactly these cells, each claiming exactly the children it claimed here, when its
+// smallest key first reaches that group's level (between top-level groups the smallest key is unique; an uncontested top-level group ends
+// in the same state whatever the order inside it).  The replay of the single heap treats them like cells of a decided landmass.
+struct PopLog { std::vector<int32_t> cells; int32_t n = 0, outerOpen = 0, prefix = -1; };
 struct WalkStats { int64_t pops = 0, descending = 0, raised = 0, heapSum = 0, heapMax = 0; };     // WO_FLOOD_TIMING: the largest landmass's walk
 template <class Heap, bool STATS = false>
 void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec<FloodHeapItem>& store,
                    std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats* ws = nullptr,
-                   const FloodHeapItem* resume = nullptr, size_t nResume = 0) {
+                   const FloodHeapItem* resume = nullptr, size_t nResume = 0, PopLog* log = nullptr) {
     const double EPS = 1e-7;
     const int32_t* landCell = S.landCell.data();
     const int32_t* offL = S.offL.data();
@@ -603,6 +611,8 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
     int32_t famCounter = 0;
     TieGroup groups[64]; int nOpen = 0;
     float highest = -INFINITY;
+    int32_t* logCells = nullptr;
+    if (log) { log->n = 0; log->outerOpen = 0; log->prefix = -1; logCells = log->cells.data(); }
     while (heap.n > 0) {
         const float kc = heap.front()[0].key;
         if (STATS) { ++ws->pops; ws->heapSum += (int64_t)heap.n; if ((int64_t)heap.n > ws->heapMax) ws->heapMax = (int64_t)heap.n; if (kc < highest) ++ws->descending; else highest = kc; }
@@ -610,12 +620,13 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
         const FloodHeapItem* hp = heap.front();
         const size_t nFront = heap.front_count();
         const bool tieTop = nFront > 0 && hp[0].key == kc;
+        if (logCells) logCells[log->n++] = c;
         if (tieTop || nOpen) {
             while (nOpen && kc > groups[nOpen - 1].level) --nOpen;
             if (nOpen && kc == groups[nOpen - 1].level) groups[nOpen - 1].fam = ++famCounter;       // the next tied cell: a new family
             else if (tieTop) {
-                if (nOpen == 64) { contests.push_back(Contest{c, -1, kc}); }                        // cannot happen in practice: reported as unresolved
-                else { if (nOpen) ++nNested; ++nGroups; ++famCounter; groups[nOpen++] = TieGroup{kc, famCounter, famCounter}; }
+                if (nOpen == 64) { contests.push_back(Contest{c, -1, kc}); if (logCells) { log->prefix = log->outerOpen; logCells = nullptr; } }     // cannot happen in practice: reported as unresolved
+                else { if (nOpen) ++nNested; else if (logCells) log->outerOpen = log->n - 1; ++nGroups; ++famCounter; groups[nOpen++] = TieGroup{kc, famCounter, famCounter}; }
             }
         }
         {
@@ -636,7 +647,11 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
                 if (curFam) {
                     const int32_t sv = stamp[nb];
                     if (sv) for (int g = 0; g < nOpen; ++g)
-                        if (sv >= groups[g].firstFam && sv < groups[g].fam) { contests.push_back(Contest{nb, c, groups[g].level}); break; }
+                        if (sv >= groups[g].firstFam && sv < groups[g].fam) {
+                            contests.push_back(Contest{nb, c, groups[g].level});
+                            if (logCells) { log->prefix = log->outerOpen; logCells = nullptr; }
+                            break;
+                        }
                 }
                 continue;
             }
@@ -657,13 +672,15 @@ void walk_landmass_h(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, hvec
             heap.push(nb, k);
         }
     }
+    if (logCells) log->prefix = log->n;                     // no contested cell at all
 }
 // landmasses of at least WO_FLOOD_RING_MIN cells (default 4096; FloodHooks: the tests run both queues) walk on the ring queue
 inline bool walk_on_ring(const FloodScratch& S, int32_t nCells) { return nCells >= S.hooks.ringMin; }
 void walk_landmass_with_stats(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
-                              std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats& ws) {
-    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
-    else walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws);
+                              std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, WalkStats& ws, PopLog* log = nullptr) {
+    if (log && (int32_t)log->cells.size() < nCells) log->cells.resize(nCells);
+    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws, nullptr, 0, log);
+    else walk_landmass_h<KeyHeap4, true>(S, seeds, nSeeds, store, contests, nGroups, nNested, &ws, nullptr, 0, log);
 }
 void walk_landmass_resume(FloodScratch& S, const std::vector<FloodHeapItem>& frontier, int32_t nCells, hvec<FloodHeapItem>& store,
                           std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
@@ -671,7 +688,7 @@ void walk_landmass_resume(FloodScratch& S, const std::vector<FloodHeapItem>& fro
     else walk_landmass_h<KeyHeap4>(S, nullptr, 0, store, contests, nGroups, nNested, nullptr, frontier.data(), frontier.size());
 }
 void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_t nCells, hvec<FloodHeapItem>& store,
-                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested) {
+                   std::vector<Contest>& contests, int64_t& nGroups, int64_t& nNested, PopLog* log = nullptr) {
     // Where a walk's time goes (round 4, the 402 k-cell landmass of the bench planet; research/flood_walk_bench.py replays the walk's op log
     // on the queue alone and the recorded pop order on the expansion alone).  FIRST flood of a step (fresh terrain): heap 11 600 entries on
     // average, 88 % of the pops in ascending order, 86 % of the pushes carry the cell's own key (height + noise); queue 20-24 ms and
@@ -684,8 +701,9 @@ void walk_landmass(FloodScratch& S, const int32_t* seeds, int32_t nSeeds, int32_
     // the ring — exact (device keys and ranks == the host's arithmetic on every cell, fields == oracle), 8.7 against 20 ms on the queue-only replay
     // with ranks per landmass, but with ranks over the whole planet (a landmass's bits are sparse in it) the first flood's walk went 27.6-28.8 ->
     // 25-26 ms and the second flood's, whose keys are mostly raised, 34 -> 41-50 ms: a loss per step.
-    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue>(S, seeds, nSeeds, store, contests, nGroups, nNested);
-    else walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested);
+    if (log && (int32_t)log->cells.size() < nCells) log->cells.resize(nCells);
+    if (walk_on_ring(S, nCells)) walk_landmass_h<RingQueue>(S, seeds, nSeeds, store, contests, nGroups, nNested, nullptr, nullptr, 0, log);
+    else walk_landmass_h<KeyHeap4>(S, seeds, nSeeds, store, contests, nGroups, nNested, nullptr, nullptr, 0, log);
 }
 int flood_workers(int64_t items) {
     static const int capThreads = [] { const char* e = std::getenv("WO_FLOOD_THREADS"); const int v = e ? std::atoi(e) : 0; return v >= 1 ? v : 24; }();
@@ -1072,8 +1090,10 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
 namespace {
 // stopLevel: the replay ends as soon as the heap's smallest key exceeds it (+inf: runs to the end); then `frontier[k]` receives the
 // entries the heap still holds for dirty landmass k, in array order, and true is returned.  See flood_landmass_pipeline.
+// prefix[k]: the cells of dirty landmass k that its own walk popped before its first tie group with a contested cell (PopLog) — they, and
+// the claims they made, are kept and they push like clean cells (dirty == 2); only the rest of the landmass is walked for real (dirty == 1).
 bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyComp, const float* e, float stopLevel,
-                             std::vector<std::vector<FloodHeapItem>>* frontier) {
+                             std::vector<std::vector<FloodHeapItem>>* frontier, const std::vector<std::vector<int32_t>>* prefix) {
     const double EPS = 1e-7;
     FloodTimer T(S);
     const int32_t L = S.L;
@@ -1086,17 +1106,26 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
     uint8_t* dirty = S.replayDirty.data();
     parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(dirty + b, 0, (size_t)(en - b)); });
     const int32_t nComp = (int32_t)S.compSize.size();
+    int64_t prefixLeft = 0;
     for (int32_t k = 0; k < nComp; ++k) {
         if (!dirtyComp[k]) continue;
         const int32_t* cells = S.compCells.data() + S.compCellStart[k];
         const int32_t n = S.compCellStart[k + 1] - S.compCellStart[k];
+        parallel_ranges(n, [&](int64_t b, int64_t en, int) { for (int64_t q = b; q < en; ++q) dirty[cells[q]] = 1; });
+        if (prefix) {
+            const std::vector<int32_t>& pre = (*prefix)[k];
+            parallel_ranges((int64_t)pre.size(), [&](int64_t b, int64_t en, int) { for (int64_t q = b; q < en; ++q) dirty[pre[q]] = 2; });
+            prefixLeft += (int64_t)pre.size();
+        }
         parallel_ranges(n, [&](int64_t b, int64_t en, int) {
-            for (int64_t q = b; q < en; ++q) {                       // back to the start state of pass 1 (flood_gather)
+            for (int64_t q = b; q < en; ++q) {                       // back to the start state of pass 1 (flood_gather) ...
                 const int32_t i = cells[q];
-                dirty[i] = 1;
                 S.localIdx[i] = k;                                   // (scratch of the carve pass, free until round 2: which landmass a frontier entry belongs to)
                 const float v = S.landOrder ? e[i] : e[landCell[i]];
-                eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1;
+                eL[i] = v; st[i].e = v;
+                const int32_t par = st[i].drain;                     // ... except what the prefix popped or claimed (a claimant is a neighbour: same landmass)
+                if (dirty[i] == 2 || (par >= 0 && dirty[par] == 2)) continue;
+                st[i].surface = v; st[i].drain = UNVISITED; st[i].root = -1;
             }
         });
     }
@@ -1106,7 +1135,7 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
     parallel_ranges(L, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; ++i) {
             int32_t c = 0;
-            if (!dirty[i] && st[i].drain != UNVISITED) for (int32_t j = offL[i]; j < offL[i + 1]; ++j) c += st[adjL[j]].drain == (int32_t)i ? 1 : 0;
+            if (dirty[i] != 1 && st[i].drain != UNVISITED) for (int32_t j = offL[i]; j < offL[i + 1]; ++j) c += st[adjL[j]].drain == (int32_t)i ? 1 : 0;
             cs[i + 1] = c;
         }
     });
@@ -1120,13 +1149,16 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
     }
     S.childItem.resize((size_t)cs[L] + 1);
     FloodHeapItem* ci = S.childItem.data();
+    // An entry of this heap carries "walked for real" in the top bit of its cell (the heap compares keys only): the loop below never has
+    // to look the popped cell up to know which of the two kinds it is, nor to decide what to pull in for the cells about to pop.
+    constexpr int32_t REAL = INT32_MIN, CELL = INT32_MAX;
     parallel_ranges(L, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; ++i) {
             if (cs[i + 1] == cs[i]) continue;
             int32_t o = cs[i];
             for (int32_t j = offL[i]; j < offL[i + 1]; ++j) {
                 const int32_t nb = adjL[j];
-                if (st[nb].drain == (int32_t)i) ci[o++] = FloodHeapItem{(float)((double)st[nb].surface + cell_noise(landCell[nb])), nb};
+                if (st[nb].drain == (int32_t)i) ci[o++] = FloodHeapItem{(float)((double)st[nb].surface + cell_noise(landCell[nb])), dirty[nb] == 1 ? (nb | REAL) : nb};
             }
         }
     });
@@ -1135,23 +1167,35 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
     KeyHeap heap(S.heapStore);
     for (size_t s = 0; s < S.seedCell.size(); ++s) {        // :118-128, ascending r: every seed of the planet
         const int32_t i = S.seedCell[s];
-        if (dirty[i]) { st[i].drain = TO_OCEAN; st[i].root = (int32_t)s; }
-        heap.push(i, (float)((double)st[i].e + cell_noise(landCell[i])));    // a seed's surface is its height at the start of the call (state copy: eL of a clean landmass is carved by now)
+        if (dirty[i] == 1) { st[i].drain = TO_OCEAN; st[i].root = (int32_t)s; }
+        heap.push(dirty[i] == 1 ? (i | REAL) : i, (float)((double)st[i].e + cell_noise(landCell[i])));    // a seed's surface is its height at the start of the call (state copy: eL of a clean landmass is carved by now)
     }
     int64_t realPops = 0, pops = 0;
     bool stopped = false;
     while (heap.n > 0) {
-        if (S.heapStore.data()[0].key > stopLevel) { stopped = true; break; }
-        const int32_t c = heap.pop();
+        if (S.heapStore.data()[0].key > stopLevel && prefixLeft == 0) { stopped = true; break; }     // (a prefix cell left in the heap — test hook levels only — has children that are claimed and not yet pushed)
+        const int32_t popped = heap.pop();
+        const int32_t c = popped & CELL;
         ++pops;
-        {
+        {   // what the next pops will touch (the first heap levels hold them): child lists of the bare cells; rows, records and — for the
+            // very next one — the neighbours' records of the cells walked for real, as in flood_pass1_host
             const FloodHeapItem* hp = S.heapStore.data();
             const size_t lim2 = heap.n < 7 ? heap.n : 7;
-            for (size_t q = 0; q < lim2; ++q) { const int32_t cc = hp[q].cell; __builtin_prefetch(&cs[cc]); __builtin_prefetch(&dirty[cc]); }
-            if (heap.n > 0) __builtin_prefetch(&ci[cs[hp[0].cell]]);
+            for (size_t q = 0; q < lim2; ++q) {
+                const int32_t raw = hp[q].cell, cc = raw & CELL;
+                if (raw < 0) { __builtin_prefetch(&offL[cc]); __builtin_prefetch(&st[cc]); }
+                else __builtin_prefetch(&cs[cc]);
+            }
+            if (heap.n > 0) {
+                const int32_t raw = hp[0].cell, c0 = raw & CELL;
+                if (raw < 0) for (int32_t j = offL[c0]; j < offL[c0 + 1]; ++j) __builtin_prefetch(&st[adjL[j]]);
+                else __builtin_prefetch(&ci[cs[c0]]);
+            }
+            for (size_t q = 1; q < lim2 && q < 3; ++q) if (hp[q].cell < 0) __builtin_prefetch(&adjL[offL[hp[q].cell & CELL]]);
         }
-        if (!dirty[c]) {
+        if (popped >= 0) {
             for (int32_t j = cs[c]; j < cs[c + 1]; ++j) heap.push(ci[j].cell, ci[j].key);
+            if (prefixLeft) prefixLeft -= dirty[c] >> 1;
             continue;
         }
         ++realPops;
@@ -1166,12 +1210,15 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
             float k;
             if ((double)sn.e < lim) { sn.surface = (float)lim; k = (float)((double)sn.surface + cell_noise(landCell[nb])); }
             else k = (float)((double)sn.e + cell_noise(landCell[nb]));
-            heap.push(nb, k);
+            heap.push(nb | REAL, k);
         }
     }
     if (stopped && frontier) {
         const FloodHeapItem* hp = S.heapStore.data();
-        for (size_t q = 0; q < heap.n; ++q) if (dirty[hp[q].cell]) (*frontier)[S.localIdx[hp[q].cell]].push_back(hp[q]);
+        for (size_t q = 0; q < heap.n; ++q) {
+            const int32_t cc = hp[q].cell & CELL;
+            if (dirty[cc]) (*frontier)[S.localIdx[cc]].push_back(FloodHeapItem{hp[q].key, cc});
+        }
     }
     T.lap("replay");
     if (T.on) std::fprintf(stderr, "[flood] replay: %lld cells walked for real of %d; %s after %lld pops (level %.9g), %zu entries left in the heap\n", (long long)realPops, L,
@@ -1213,6 +1260,8 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     std::vector<Local> loc(nt);
     std::vector<uint8_t> dirty(std::max(nComp, 1), 0);
     const int forceDirty = S.hooks.forceDirty;     // test hook: treat this landmass (by rank in size) as undecided
+    // the pops of a landmass with a contested cell up to its first such tie group (PopLog): bare pushes in the replay, like a decided landmass
+    std::vector<std::vector<int32_t>> prefix(S.hooks.replayPrefix ? std::max(nComp, 1) : 0);
     // One round over a list of landmasses.  walked: pass 1 of these landmasses is already there (the replay's).
     const auto tRound0 = std::chrono::steady_clock::now();
     auto run_round = [&](const std::vector<int32_t>& list, bool walked) {
@@ -1249,6 +1298,8 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         auto worker = [&](int w) {
             Local& me = loc[w];
             std::vector<int32_t> path, cnt;
+            static thread_local PopLog popLog;
+            PopLog* const log = prefix.empty() ? nullptr : &popLog;
             for (;;) {
                 const int32_t q = next.fetch_add(1);
                 if (q >= nList) break;
@@ -1259,8 +1310,14 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                     me.contests.clear();
                     const auto tw0 = std::chrono::steady_clock::now();
                     WalkStats ws;
-                    if (T.on && q == 0) walk_landmass_with_stats(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], me.contests, me.groups, me.nested, ws);
-                    else walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], me.contests, me.groups, me.nested);
+                    if (T.on && q == 0) walk_landmass_with_stats(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], me.contests, me.groups, me.nested, ws, log);
+                    else walk_landmass(S, S.compSeeds.data() + S.compSeedStart[k], S.compSeedStart[k + 1] - S.compSeedStart[k], S.compSize[k], S.workerHeaps[w], me.contests, me.groups, me.nested, log);
+                    if (log && (!me.contests.empty() || q == forceDirty)) {
+                        // (the test hook's landmass has no contested cell: every cut of its pops is as good as any; WO_FLOOD_FORCE_PREFIX permille of them)
+                        const int32_t len = q == forceDirty && me.contests.empty() ? (int32_t)((int64_t)log->n * S.hooks.forcePrefixPermille / 1000) : log->prefix;
+                        prefix[k].assign(log->cells.begin(), log->cells.begin() + len);
+                        if (T.on) std::fprintf(stderr, "[flood] landmass %d (%d cells): %d pops before its first tie group with a contested cell\n", k, S.compSize[k], len);
+                    }
                     // (measured and dropped in round 3: a bucket queue — 2^16 buckets of width 2^-14 behind a two-level bitmap — instead of the
                     // binary heap for the walks, which do not depend on the order of equal keys: 83-130 ms against 45-60 ms for this landmass in
                     // the build container; the heap of one landmass stays in cache, the buckets' vectors do not)
@@ -1386,7 +1443,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         if (toTheEnd) stopLevel = INFINITY;
         if (S.hooks.hasReplayStop) stopLevel = S.hooks.replayStop;      // test hook
         std::vector<std::vector<FloodHeapItem>> frontier(nComp);
-        if (replay_dirty_landmasses(S, dirty, e, stopLevel, &frontier)) {
+        if (replay_dirty_landmasses(S, dirty, e, stopLevel, &frontier, prefix.empty() ? nullptr : &prefix)) {
             std::atomic<int> contestedAgain{0};
             uint8_t* seen = S.seen.data();
             int32_t* stamp = S.stamp.data();
@@ -1404,7 +1461,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
             }, 1);
             T.lap("resumed");
             if (T.on) std::fprintf(stderr, "[flood] %zu landmasses resumed on their own queues above level %.9g%s\n", redo.size(), (double)stopLevel, contestedAgain.load() ? "; a contested cell turned up: full replay" : "");
-            if (contestedAgain.load()) replay_dirty_landmasses(S, dirty, e, INFINITY, nullptr);
+            if (contestedAgain.load()) replay_dirty_landmasses(S, dirty, e, INFINITY, nullptr, prefix.empty() ? nullptr : &prefix);
         }
         run_round(redo, true);
         T.lap("round 2");

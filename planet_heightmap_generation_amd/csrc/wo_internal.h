@@ -40,6 +40,8 @@ struct FloodHooks {
     int32_t chainsMin = 2048;      // WO_FLOOD_CHAINS_MIN   drainage trees of at least this many cells carve on the chain-ordered copy
     int32_t forceDirty = -1;       // WO_FLOOD_FORCE_DIRTY  treat this landmass (by rank in size) as undecided
     bool hasReplayStop = false; float replayStop = 0.0f;     // WO_FLOOD_REPLAY_STOP  the level at which the replay of the single heap stops
+    bool replayPrefix = true;      // WO_FLOOD_PREFIX=0     the replay walks undecided landmasses from their seeds (not from their first contested tie group)
+    int32_t forcePrefixPermille = 0;   // WO_FLOOD_FORCE_PREFIX  how much of the forced landmass's pops counts as its decided prefix
     bool timing = false;           // WO_FLOOD_TIMING       laps -> stderr
     void read();
 };

@@ -347,6 +347,71 @@ def test_replay_stopped_at_a_level_and_resumed_per_landmass(emu, oracle, monkeyp
             assert st["serialPass1"] == 0 and st["replays"] == 1, st
 
 
+@pytest.mark.parametrize("permille", [0, 250, 600, 1000])
+def test_replay_keeps_the_decided_prefix_of_an_undecided_landmass(emu, oracle, monkeypatch, permille):
+    """Inside the replay of the single heap an undecided landmass is walked for real only from its first tie group that holds a contested
+    cell; the cells its own walk popped before that (flood_host.cc: PopLog) keep their claims and push like cells of a decided landmass.
+    For a landmass that is only FORCED to be undecided every cut of its pops must do (WO_FLOOD_FORCE_PREFIX, in permille of the pops; 1000 =
+    nothing is walked for real), with and without a stop level in the middle of the prefix, on ordinary and on quantised terrain."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(80000, 0.75, 6)
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    base = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, 6), xyz, 6, 0.75)
+    oc = (base <= 0).astype(np.uint8)
+    quant = np.where(oc == 1, base, np.maximum(np.floor(base * 2048) / 2048, 1.0 / 2048)).astype(np.float32)
+    monkeypatch.setenv("WO_FLOOD_FORCE_PREFIX", str(permille))
+    for e0 in (base, quant):
+        ref = oracle.priority_flood_carve(om, e0, oc, 0.85)
+        for k, stop in ((0, None), (0, 0.05), (2, 0.1), (7, None)):
+            monkeypatch.setenv("WO_FLOOD_FORCE_DIRTY", str(k))
+            if stop is None:
+                monkeypatch.delenv("WO_FLOOD_REPLAY_STOP", raising=False)
+            else:
+                monkeypatch.setenv("WO_FLOOD_REPLAY_STOP", str(stop))
+            e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, 0.85, 1)
+            assert np.array_equal(e, ref), (permille, k, stop, int((e != ref).sum()), st)
+            assert st["serialPass1"] == 0 and st["replays"] == 1, st
+
+
+def test_prefix_of_a_really_undecided_landmass(emu, oracle, monkeypatch, capfd):
+    """Equal keys that matter (lowlands of one key, see the next test): the undecided landmasses have a first contested tie group of their
+    own, their pops before it are kept (the log names them), and the elevations are the oracle's with the prefix rule on and off."""
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    import re
+    monkeypatch.setenv("WO_FLOOD_TIMING", "1")
+    mesh, xyz, nd = S.build_sphere(60000, 0.75, 2)
+    N = mesh.numRegions
+    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
+    base = oracle.warp_terrain(om, oracle.synthetic_terrain(xyz, 2), xyz, 2, 0.75)
+    noise = _cell_noise(np.arange(N)).astype(np.float32)
+    oc = (base <= 0).astype(np.uint8)
+    kept, rows = 0, []
+    for lo, cut in ((0.05, 0.08), (0.10, 0.12), (0.0, 0.06)):
+        band = (base > lo) & (base < cut)
+        e0 = np.where(band, np.float32(cut) - noise, base).astype(np.float32)
+        e0 = np.where((base > 0) & (e0 <= 0), np.float32(1e-3), e0).astype(np.float32)
+        ref = oracle.priority_flood_carve(om, e0, oc, 0.5)
+        for on in ("1", "0"):
+            monkeypatch.setenv("WO_FLOOD_PREFIX", on)
+            capfd.readouterr()
+            e, st = flood(emu, mesh.adjOffset, mesh.adjList, xyz, e0, oc, 0.5, 1)
+            log = capfd.readouterr().err
+            assert np.array_equal(e, ref), (lo, cut, on, int((e != ref).sum()), st)
+            assert st["replays"] == 1 and st["unresolved"] > 0 and st["serialPass1"] == 0, st
+            lens = [int(x) for x in re.findall(r"(\d+) pops before its first tie group", log)]
+            assert (len(lens) > 0) == (on == "1"), log[-400:]
+            real = [int(x) for x in re.findall(r"replay: (\d+) cells walked for real", log)]
+            rows.append((lo, cut, on, "prefix pops", sum(lens), "of", st["replayedLandmasses"], "landmasses; walked for real", real))
+            if on == "1":
+                kept += sum(lens)
+                real_on = real[0]
+            else:
+                assert real_on <= real[0] and (sum(lens_on) == 0 or real_on < real[0]), (real_on, real[0], lens_on)
+            lens_on = lens
+    print(*rows, sep="\n")
+    assert kept > 0, "no undecided landmass had a decided prefix"
+
+
 def test_replay_stops_after_the_last_tie_that_matters(emu, oracle, monkeypatch, capfd):
     """Equal keys that matter, all of them LOW: the land below a cut gets the height cut - noise(cell) (one key for whole lowlands: hundreds
     of undecided contested cells), the rest keeps its ordinary terrain.  The replay of the single heap must stop at the cut and the ~30
