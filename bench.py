@@ -543,6 +543,7 @@ def one_planet_leg(TP, args, rank, world, dist, local_rank):
     busy = [None] * world
     dist.all_gather_object(busy, dict(rank=rank, land_cells=int(stats.get("land_cells", 0)), flood_stage_ms=round(stats.get("flood_stage_ms", 0.0), 1),
                                       whole_planet_floods=int(stats.get("flood_exchange_whole_planet_floods", 0)), exchange_gathers=int(stats.get("flood_exchange_gathers", 0)),
+                                      floods_received=int(stats.get("flood_exchange_received", 0)),
                                       erode_ms=round(sum(stages.values()), 1)))
     out = None
     if rank == 0:

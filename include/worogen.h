@@ -196,14 +196,19 @@ int wo_planet_exchange_neighbors(wo_planet* planet, wo_comm* comm, int32_t nToPr
  * their current heights included.  A rank's flood proves for each of its landmasses that no equal-key decision matters, or
  * reports it undecided (csrc/flood_host.cc).  With an exchange set, every flood call of erodeComposite then (phase 0) agrees
  * with the other ranks whether any rank is undecided and, if so, (phase 1) pools the heights of all land cells at that call;
- * an undecided rank floods the whole planet on the true mask exactly as the unpartitioned run does and keeps its own cells.
- * Never needed at 10 M cells; at 40 M cells in every call.  All ranks make the same calls.
+ * ONE undecided rank (the flag is a bid: INT32_MAX - its lowest land cell id, 0 when decided; the maximum names it) floods the
+ * whole planet on the true mask exactly as the unpartitioned run does and (phases 2 / 3) hands the land heights back; the
+ * undecided ranks keep their own cells of them.  Never needed at 10 M cells; at 40 M cells in every call.
+ * All ranks make the same sequence of calls (0; then 1 and one of 2 / 3 when the maximum is not 0).
  *   fn(user, 0, int32_t flag[1], 1)        flag := max over the ranks
  *   fn(user, 1, float field[numRegions], numRegions)   in: the rank's own land cells hold their heights; out: every land cell does
+ *   fn(user, 2, float land[n], n)          this rank flooded: it SENDS land (the planet's land cells in ascending id) to every rank
+ *   fn(user, 3, float land[n], n)          every other rank: land := what the one rank in phase 2 sent
  * fn returns 0 on success; a non-zero status fails the erodeComposite call.  r_isOcean_true: the planet's real mask (the
  * resident mask is the rank's: other ranks' landmasses are ocean).  fn == NULL switches the exchange off.
  * wo_planet_set_flood_exchange_comm: the same over RCCL — counts[j] land cells of rank j, their region ids concatenated in
- * rank order in cellsByRank (ncclAllReduce of the flag, ncclAllGather of the heights). */
+ * rank order in cellsByRank (ncclAllReduce of the flag, ncclAllGather of the heights, ncclBroadcast of the flooded heights).
+ * The comm must outlive the exchange: switch it off (fn == NULL) or destroy the planet before wo_comm_destroy. */
 typedef int (*wo_flood_exchange_fn)(void* user, int32_t phase, void* buf, int64_t n);
 int wo_planet_set_flood_exchange(wo_planet* planet, const uint8_t* r_isOcean_true, wo_flood_exchange_fn fn, void* user);
 int wo_planet_set_flood_exchange_comm(wo_planet* planet, const uint8_t* r_isOcean_true, wo_comm* comm, const int32_t* counts,

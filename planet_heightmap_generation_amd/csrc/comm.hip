@@ -42,6 +42,7 @@ bool nccl_ok(ncclResult_t r, const char* what) {
 // every exchange entry point: the planet's device current, and the communicator living on that device
 bool comm_ready(wo_planet* p, wo_comm* c, const char* fn) {
     if (!p || !c || !p->ctx) { wo::set_error(std::string(fn) + ": bad arguments"); return false; }
+    if (!c->comm) { wo::set_error(std::string(fn) + ": the communicator is closed (an earlier collective failed and aborted it)"); return false; }
     if (c->device != p->ctx->device) { wo::set_error(std::string(fn) + ": the communicator was created on another device than the planet's"); return false; }
     const hipError_t e = hipSetDevice(p->ctx->device);
     if (e != hipSuccess) { wo::set_error(std::string(fn) + ": hipSetDevice failed: " + hipGetErrorString(e)); return false; }
@@ -63,6 +64,7 @@ struct FloodLink {
     int32_t maxCount = 1;
     int32_t* d_flag = nullptr; int32_t* h_flag = nullptr;
     float *d_send = nullptr, *d_all = nullptr, *h_send = nullptr, *h_all = nullptr;
+    float* d_land = nullptr; size_t landCap = 0;     // the flooded land heights on their way through ncclBroadcast
 };
 void flood_link_free(void* v) {
     FloodLink* k = (FloodLink*)v;
@@ -71,6 +73,7 @@ void flood_link_free(void* v) {
     if (k->h_flag) (void)hipHostFree(k->h_flag);
     if (k->d_send) (void)hipFree(k->d_send);
     if (k->d_all) (void)hipFree(k->d_all);
+    if (k->d_land) (void)hipFree(k->d_land);
     if (k->h_send) (void)hipHostFree(k->h_send);
     if (k->h_all) (void)hipHostFree(k->h_all);
     delete k;
@@ -78,6 +81,7 @@ void flood_link_free(void* v) {
 int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
     FloodLink* k = (FloodLink*)user;
     wo_comm* c = k->comm;
+    if (!c || !c->comm) { wo::set_error("flood exchange: the communicator is closed"); return 1; }
     hipStream_t s = k->planet->ctx->stream;
     try {
         if (hipSetDevice(k->planet->ctx->device) != hipSuccess) { wo::set_error("flood exchange: hipSetDevice failed"); return 1; }
@@ -88,6 +92,29 @@ int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
             WO_HIP(hipMemcpyAsync(k->h_flag, k->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             WO_HIP(hipStreamSynchronize(s));
             *(int32_t*)buf = *k->h_flag;
+            return 0;
+        }
+        if (phase >= 2) {
+            // the one rank that flooded the whole planet (phase 2) sends the planet's land heights: who it is, then the heights
+            const bool sender = phase == 2;
+            *k->h_flag = sender ? c->rank : -1;
+            WO_HIP(hipMemcpyAsync(k->d_flag, k->h_flag, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            if (!nccl_ok(ncclAllReduce(k->d_flag, k->d_flag, 1, ncclInt32, ncclMax, c->comm, s), "ncclAllReduce")) return 1;
+            WO_HIP(hipMemcpyAsync(k->h_flag, k->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            WO_HIP(hipStreamSynchronize(s));
+            const int32_t root = *k->h_flag;
+            if (root < 0 || root >= c->nranks) { wo::set_error("flood exchange: no rank sent the flooded heights"); return 1; }
+            const size_t need = (size_t)std::max<int64_t>(n, 1);
+            if (need > k->landCap) {
+                if (k->d_land) (void)hipFree(k->d_land);
+                k->d_land = nullptr; k->landCap = 0;
+                WO_HIP(hipMalloc((void**)&k->d_land, need * sizeof(float)));
+                k->landCap = need;
+            }
+            if (sender) WO_HIP(hipMemcpyAsync(k->d_land, buf, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+            if (!nccl_ok(ncclBroadcast(k->d_land, k->d_land, (size_t)n, ncclFloat, root, c->comm, s), "ncclBroadcast")) return 1;
+            if (!sender) WO_HIP(hipMemcpyAsync(buf, k->d_land, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
+            WO_HIP(hipStreamSynchronize(s));
             return 0;
         }
         float* field = (float*)buf;

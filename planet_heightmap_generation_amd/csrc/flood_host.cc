@@ -1538,24 +1538,51 @@ int flood_host_passes_exchange(int32_t N, const int32_t* off, const int32_t* adj
         st.tieGroups += rep.groups; st.contested += rep.contested; st.openParents += rep.openParents; st.unresolved += rep.unresolved;
         flag = done ? 0 : 1;
     }
-    const int32_t mine = flag;
+    // Who floods the whole planet when a call is undecided: ONE rank — the undecided one that owns the land cell with the smallest id (the
+    // ranks' cells are disjoint, so "INT32_MAX - that id" under the max picks it and every rank can tell whether it is the one).  It hands
+    // the planet's land heights back (phase 2: it sends; phase 3: the others receive) and the other undecided ranks keep their own cells.
+    const bool mine = flag != 0;
+    if (S.L > 0 && (X.posVersion != S.staticVersion || X.ownPos.size() != (size_t)S.L)) {
+        X.ownPos.resize((size_t)S.L);
+        const uint8_t* toc = X.trueOcean.data();
+        const int32_t* li = S.landIndex.data();
+        int32_t cnt = 0, lowest = -1;
+        for (int32_t r = 0; r < N; ++r) if (!toc[r]) { if (li[r] >= 0) { X.ownPos[(size_t)li[r]] = cnt; if (lowest < 0) lowest = r; } ++cnt; }
+        X.landTotal = cnt; X.minOwnCell = lowest; X.posVersion = S.staticVersion;
+    }
+    const int32_t bid = mine ? INT32_MAX - X.minOwnCell : 0;
+    flag = bid;
     if (int rc = X.fn(X.user, 0, &flag, 1)) return rc;
     if (!flag) return 0;
     ++X.gathers;
     if (int rc = X.fn(X.user, 1, snap, N)) return rc;
-    if (!mine) return 0;
-    // undecided here: the whole planet, as the unpartitioned run floods it
-    ++X.globalFloods;
-    FloodScratch& G = X.global;
-    if (!G.staticValid || G.staticN != N) flood_build_static(N, off, adj, xyz, X.trueOcean.data(), G);
-    flood_gather(snap, G);
-    FloodTieReport rep;
-    auto t0 = clock::now();
-    flood_landmass_pipeline(snap, carveStrength, G, rep, st.pathRedo, true);
-    st.pass1Ms += ms(t0, clock::now());
-    if (rep.replayed) { ++st.replays; st.replayedLandmasses += rep.replayed; }
-    const int32_t* landCell = S.landCell.data();
-    parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = snap[landCell[i]]; });
+    if (X.landTotal < 0) { int64_t cnt = 0; for (int32_t r = 0; r < N; ++r) cnt += X.trueOcean[r] ? 0 : 1; X.landTotal = cnt; }      // (a rank without land)
+    X.landPack.resize((size_t)std::max<int64_t>(X.landTotal, 1));
+    float* pack = X.landPack.data();
+    if (mine && flag == bid) {
+        // undecided, and the one to do it: the whole planet, as the unpartitioned run floods it
+        ++X.globalFloods;
+        FloodScratch& G = X.global;
+        if (!G.staticValid || G.staticN != N) flood_build_static(N, off, adj, xyz, X.trueOcean.data(), G);
+        flood_gather(snap, G);
+        FloodTieReport rep;
+        auto t0 = clock::now();
+        flood_landmass_pipeline(snap, carveStrength, G, rep, st.pathRedo, true);
+        st.pass1Ms += ms(t0, clock::now());
+        if (rep.replayed) { ++st.replays; st.replayedLandmasses += rep.replayed; }
+        const int32_t* gCell = G.landCell.data();
+        const int32_t* byR = G.landByR.data();
+        parallel_ranges(G.L, [&](int64_t b, int64_t en, int) { for (int64_t q = b; q < en; ++q) pack[q] = snap[gCell[byR[q]]]; });
+        if (int rc = X.fn(X.user, 2, pack, X.landTotal)) return rc;
+    } else {
+        if (int rc = X.fn(X.user, 3, pack, X.landTotal)) return rc;
+        if (mine) ++X.received;
+    }
+    if (mine) {
+        const int32_t* landCell = S.landCell.data();
+        const int32_t* pos = X.ownPos.data();
+        parallel_ranges(S.L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = pack[pos[i]]; });
+    }
     return 0;
 }
 

@@ -684,7 +684,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     if (gStrength != gStrength) gStrength = 0;
     const int32_t total = std::max(hIters, std::max(tIters, gIters));
     p->stageTiming.clear(); p->erodeStats.clear();
-    p->floodX.calls = 0; p->floodX.gathers = 0; p->floodX.globalFloods = 0;       // per call (the stats of a step, not of the planet's life)
+    p->floodX.calls = 0; p->floodX.gathers = 0; p->floodX.globalFloods = 0; p->floodX.received = 0;       // per call (the stats of a step, not of the planet's life)
     if (total <= 0) return;
     ensure_scratch(p);
     hipStream_t s = p->ctx->stream;
@@ -1218,7 +1218,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
                      {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_replays", (double)floodRun.host.replays}, {"flood_host_replayed_landmasses", (double)floodRun.host.replayedLandmasses}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
                      {"flood_host_pass23_ms", floodRun.host.pass23Ms},
-                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"relaxed_full", p->opt.relaxedFull ? 1.0 : 0.0}, {"iterations_replayed_from_graph", (double)graphReplays}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}};
+                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"relaxed_full", p->opt.relaxedFull ? 1.0 : 0.0}, {"iterations_replayed_from_graph", (double)graphReplays}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}, {"flood_exchange_received", (double)p->floodX.received}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
@@ -1542,7 +1542,7 @@ int wo_planet_set_flood_exchange(wo_planet* p, const uint8_t* trueOcean, wo_floo
         const bool same = X.trueOcean.size() == (size_t)p->N && std::memcmp(X.trueOcean.data(), trueOcean, (size_t)p->N) == 0;
         if (!same) { X.trueOcean.assign(trueOcean, trueOcean + p->N); X.global.staticValid = false; }
         X.fn = fn; X.user = user; X.on = true;
-        X.calls = X.gathers = X.globalFloods = 0;
+        X.calls = X.gathers = X.globalFloods = X.received = 0; X.posVersion = -1; X.landTotal = -1;
         return 0;
     WO_CATCH("wo_planet_set_flood_exchange")
 }

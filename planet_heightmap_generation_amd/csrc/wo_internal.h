@@ -122,8 +122,10 @@ struct FloodExchange {
     FloodExchangeFn fn = nullptr; void* user = nullptr;
     hvec<uint8_t> trueOcean;
     hvec<float> snapshot;
-    FloodScratch global;                     // tables of the true mask, built when first needed
-    int64_t calls = 0, gathers = 0, globalFloods = 0;
+    FloodScratch global;                     // tables of the true mask, built when first needed (on a rank that floods the whole planet)
+    // the planet's land cells in ascending id (true mask) are what the flooding rank hands back: positions of this rank's cells in that list
+    hvec<int32_t> ownPos; hvec<float> landPack; int64_t landTotal = -1, posVersion = -1; int32_t minOwnCell = -1;
+    int64_t calls = 0, gathers = 0, globalFloods = 0, received = 0;
 };
 // returns 0, or the non-zero status of fn
 int flood_host_passes_exchange(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, float* e, double carveStrength,

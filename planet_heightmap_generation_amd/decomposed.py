@@ -212,6 +212,23 @@ class TorchFloodExchange:
                 field[plan.cells[j]] = host[j * n_max: j * n_max + plan.cells[j].size]
 
 
+    def broadcast(self, land: np.ndarray, sender: bool) -> None:
+        """The land heights of the one rank that flooded the whole planet (it calls with sender=True), to every rank, in place."""
+        import torch
+        t = torch.tensor([self.rank if sender else -1], dtype=torch.int32, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        src = int(t.item())
+        if src < 0:
+            raise RuntimeError("flood exchange: no rank sent the flooded heights")
+        if self.device is None:
+            self.dist.broadcast(torch.from_numpy(land), src)          # gloo: in place on the host buffer
+            return
+        buf = torch.from_numpy(land).to(self.device) if sender else torch.empty(land.size, dtype=torch.float32, device=self.device)
+        self.dist.broadcast(buf, src)
+        if not sender:
+            land[:] = buf.cpu().numpy()
+
+
 class ThreadFloodExchange:
     """The same between the shares of ONE process (one host thread, context and planet per share: the partitioned code path
     rehearsed on a single GPU).  One instance per share from ThreadFloodExchange.group(plan)."""
@@ -222,6 +239,7 @@ class ThreadFloodExchange:
             self.barrier = threading.Barrier(world)
             self.flags = [0] * world
             self.fields = [None] * world
+            self.sent = None
 
     def __init__(self, plan: LandmassPlan, rank: int, shared):
         self.plan, self.rank, self.shared = plan, rank, shared
@@ -249,6 +267,16 @@ class ThreadFloodExchange:
         for j in range(self.plan.world):
             if j != self.rank and self.plan.cells[j].size:
                 field[self.plan.cells[j]] = sh.fields[j][self.plan.cells[j]]
+        sh.barrier.wait()
+
+
+    def broadcast(self, land: np.ndarray, sender: bool) -> None:
+        sh = self.shared
+        if sender:
+            sh.sent = land
+        sh.barrier.wait()
+        if not sender:
+            land[:] = sh.sent
         sh.barrier.wait()
 
 

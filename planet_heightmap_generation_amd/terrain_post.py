@@ -170,9 +170,12 @@ class Planet:
     def set_flood_exchange(self, true_ocean, exchange=None, comm: "Comm | None" = None, counts=None, cells_by_rank=None) -> None:
         """The flood exchange of the landmass decomposition (include/worogen.h: wo_planet_set_flood_exchange): every flood call of
         erodeComposite agrees with the other ranks whether any of them met an equal-key decision that matters and, if so, pools the
-        heights of all land cells so that an undecided rank can flood the whole planet like the unpartitioned run does.
-        exchange: an object with allreduce_max(flag: int) -> int and allgather(field: np.ndarray[numRegions]) -> None (in place;
-        own land cells valid on entry, every land cell on return) — decomposed.TorchFloodExchange / ThreadFloodExchange; or
+        heights of all land cells so that ONE undecided rank floods the whole planet like the unpartitioned run does and hands the
+        result back.
+        exchange: an object with allreduce_max(flag: int) -> int, allgather(field: np.ndarray[numRegions]) -> None (in place;
+        own land cells valid on entry, every land cell on return) and broadcast(land: np.ndarray, sender: bool) -> None (in place:
+        the one rank that flooded the whole planet sends its land heights, the others receive them) —
+        decomposed.TorchFloodExchange / ThreadFloodExchange; or
         comm + counts + cells_by_rank: the same over RCCL behind the C ABI.  true_ocean None: off."""
         import ctypes as C
         L = capi.lib()
@@ -199,9 +202,12 @@ class Planet:
                 if phase == 0:
                     flag = C.cast(buf, C.POINTER(C.c_int32))
                     flag[0] = int(exchange.allreduce_max(int(flag[0])))
-                else:
+                elif phase == 1:
                     field = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(int(n),))
                     exchange.allgather(field)
+                else:                       # 2: this rank flooded the whole planet and sends the land heights; 3: it receives them
+                    land = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(int(n),))
+                    exchange.broadcast(land, phase == 2)
                 return 0
             except Exception as e:          # never let an exception cross the C boundary
                 errors.append(e)

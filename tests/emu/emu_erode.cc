@@ -325,7 +325,7 @@ struct ShareBarrier {
     explicit ShareBarrier(int n_) : n(n_) {}
     void wait() { std::unique_lock<std::mutex> l(m); const long g = gen; if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); } else cv.wait(l, [&] { return gen != g; }); }
 };
-struct ShareGroup { ShareBarrier bar; std::vector<int32_t> flags; std::vector<float*> fields; const int32_t* owner; int32_t N; explicit ShareGroup(int n) : bar(n), flags(n, 0), fields(n, nullptr) {} };
+struct ShareGroup { ShareBarrier bar; std::vector<int32_t> flags; std::vector<float*> fields; const float* sent = nullptr; const int32_t* owner; int32_t N; explicit ShareGroup(int n) : bar(n), flags(n, 0), fields(n, nullptr) {} };
 struct ShareCtx { ShareGroup* g; int rank; };
 int share_exchange(void* user, int32_t phase, void* buf, int64_t n) {
     ShareCtx* c = (ShareCtx*)user; ShareGroup& G = *c->g;
@@ -338,6 +338,13 @@ int share_exchange(void* user, int32_t phase, void* buf, int64_t n) {
         return 0;
     }
     float* field = (float*)buf;
+    if (phase >= 2) {                                  // the flooding share's land heights: 2 sends, 3 receives
+        if (phase == 2) G.sent = field;
+        G.bar.wait();
+        if (phase == 3) std::memcpy(field, G.sent, sizeof(float) * (size_t)n);
+        G.bar.wait();
+        return 0;
+    }
     G.fields[c->rank] = field;
     G.bar.wait();
     for (int64_t r = 0; r < n; ++r) { const int32_t o = G.owner[r]; if (o >= 0 && o != c->rank) field[r] = G.fields[o][r]; }
@@ -364,10 +371,10 @@ extern "C" void emu_flood_shares(int32_t N, const int32_t* off, const int32_t* a
         flood_host_passes_exchange(N, off, adj, xyz, field[k].data(), cs, S, &hs[k], X[k]);
     });
     for (auto& t : th) t.join();
-    double gathers = 0, globals = 0, replays = 0;
-    for (int k = 0; k < nShares; ++k) { gathers += (double)X[k].gathers; globals += (double)X[k].globalFloods; replays += (double)hs[k].replays; }
+    double gathers = 0, globals = 0, replays = 0, received = 0;
+    for (int k = 0; k < nShares; ++k) { gathers += (double)X[k].gathers; globals += (double)X[k].globalFloods; replays += (double)hs[k].replays; received += (double)X[k].received; }
     for (int32_t r = 0; r < N; ++r) if (owner[r] >= 0) e[r] = field[owner[r]][r];
-    if (stats) { stats[0] = gathers; stats[1] = globals; stats[2] = replays; }
+    if (stats) { stats[0] = gathers; stats[1] = globals; stats[2] = replays; stats[3] = received; }
 }
 
 extern "C" void emu_flood(int32_t N, const int32_t* off, const int32_t* adj, float* e, const uint8_t* ocean, double cs) {

@@ -600,6 +600,8 @@ def test_config4_decomposed_8_shares_checksum(TP):
     print("share seconds", [round(v, 2) for v in secs], "whole-planet floods per share", [st["flood_exchange_whole_planet_floods"] for st in stats],
           "gathers", stats[0]["flood_exchange_gathers"])
     assert sum(st["flood_exchange_whole_planet_floods"] for st in stats) >= 1            # the exchange was needed (else the test has no power)
+    # ONE share floods the whole planet per undecided call and hands the land heights back to the others
+    assert sum(st["flood_exchange_whole_planet_floods"] for st in stats) == stats[0]["flood_exchange_gathers"]
     assert all(st["flood_host_serial_pass1"] == 0 for st in stats)
     assert int(zlib.crc32(merged.tobytes())) == gold["crc32"], "merged field differs from the oracle's"
 
@@ -623,6 +625,7 @@ def test_config4_two_processes_over_gloo(TP, tmp_path):
     print(res)
     assert len(res) == 2 and sum(r["land_cells"] for r in res) == gold["land_cells"]
     assert sum(r["whole_planet_floods"] for r in res) >= 1 and res[0]["gathers"] >= 1          # the exchange was needed: the test has power
+    assert sum(r["whole_planet_floods"] for r in res) == res[0]["gathers"]                      # one rank floods per undecided call, the others receive
     assert all(r["serial_pass1"] == 0 for r in res)
     assert all(r["crc32"] == gold["crc32"] for r in res), [r["crc32"] for r in res]
 
