@@ -109,6 +109,26 @@ def plan_landmasses(mesh, r_isOcean, world: int) -> LandmassPlan:
     return LandmassPlan(world, owner, cells, load, largest, n)
 
 
+def plan_largest_apart(mesh, r_isOcean) -> LandmassPlan:
+    """A two-share plan that is not balanced on purpose: share 0 is the largest landmass alone, share 1 everything else.  The walk
+    of the largest landmass is the critical path of a flood call on the host: with this plan the rest of the
+    planet can start iterating while that walk is still running (research/ab/r05_two_shares_flood_overlap.py)."""
+    base = plan_landmasses(mesh, r_isOcean, 1)
+    oc = np.ascontiguousarray(r_isOcean, np.uint8)
+    label = land_components(mesh, open_ocean(mesh, oc).astype(np.uint8))
+    label = np.where(oc != 0, -1, label).astype(np.int32)
+    land = np.flatnonzero(label >= 0).astype(np.int32)
+    owner = np.full(label.size, -1, np.int32)
+    load = np.zeros(2, np.int64)
+    if land.size:
+        labs, counts = np.unique(label[land], return_counts=True)
+        big = labs[np.flatnonzero(counts == counts.max())[0]]
+        owner[land] = np.where(label[land] == big, 0, 1)
+        load[0], load[1] = int(counts.max()), int(land.size - counts.max())
+    cells = [np.ascontiguousarray(land[owner[land] == k], np.int32) for k in range(2)]
+    return LandmassPlan(2, owner, cells, load, base.largest, base.num_landmasses)
+
+
 def merge_land(plan: LandmassPlan, rank: int, field: np.ndarray, dist) -> None:
     """Host-array form of the exchange: every rank contributes the elevations of its own land cells, every rank ends up
     with the complete field (in place).  `dist` is the initialised torch.distributed module (None: single rank)."""
@@ -281,17 +301,22 @@ class ThreadFloodExchange:
 
 
 def erode_shares_concurrently(TP, mesh, r_xyz, neighborDist, field, r_isOcean, shares: int, erode_args, creep_args=None, device: int = 0,
-                              planets=None):
+                              planets=None, plan: "LandmassPlan | None" = None, exchange: bool = True):
     """The S-rank landmass decomposition executed by S host threads of ONE process on ONE GPU (a context, stream and planet per
     share): every share erodes `field` with the other shares' landmasses masked as ocean — erodeComposite(*erode_args), then
     applySoilCreep(*creep_args) — with the flood exchange between the shares (ThreadFloodExchange), and the land elevations are
     merged.  This is the partitioned code path of an S-GPU run, flood exchange included; shares of one planet cannot run one after
     the other once a flood call needs the other shares' CURRENT heights.  Returns (merged field, per-share erode stats,
-    per-share wall seconds, plan).  planets: reuse a list of S planets of this mesh (else they are created and closed here)."""
+    per-share wall seconds, plan).  planets: reuse a list of S planets of this mesh (else they are created and closed here).
+    plan: a plan of `shares` shares other than plan_landmasses'.  exchange=False: no flood exchange — the shares never wait for
+    each other (only exact while no flood call is undecided: every share's erode stats must then show 0 replays)."""
     import threading
     import time
     oc = np.ascontiguousarray(r_isOcean, np.uint8)
-    plan = plan_landmasses(mesh, oc, shares)
+    if plan is None:
+        plan = plan_landmasses(mesh, oc, shares)
+    if plan.world != shares:
+        raise ValueError("the plan is for another number of shares")
     own = planets is None
     if own:
         planets = [TP.Planet(mesh, r_xyz, neighborDist, ctx=TP.Context(device)) for _ in range(shares)]
@@ -302,7 +327,8 @@ def erode_shares_concurrently(TP, mesh, r_xyz, neighborDist, field, r_isOcean, s
         try:
             pl = planets[k]
             pl.upload(field, plan.rank_mask(k, oc))
-            pl.set_flood_exchange(oc, links[k])
+            if exchange:
+                pl.set_flood_exchange(oc, links[k])
             pl.sync()
             t0 = time.perf_counter()
             pl.erode_composite_resident(*erode_args)
