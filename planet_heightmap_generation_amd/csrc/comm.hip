@@ -10,9 +10,12 @@
 //     list comes from them — the one-ring halo of a band decomposition (banded.py), ncclSend / ncclRecv in one group.
 // Pack and unpack are the kernels of wo_planet_pack_halo / unpack_halo; everything is enqueued on the planet's stream.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library itself is bound at the first multi-GPU call (below)
+
+#include <dlfcn.h>
 
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,9 +37,46 @@ __global__ __launch_bounds__(wo::WO_BLOCK) void k_comm_unpack(float* __restrict_
     for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) e[idx[i]] = in[i];
 }
 
+// librccl is NOT a link-time dependency of libworogen.so: a single-GPU host never maps it (hundreds of MB of kernels), and the
+// library loads on a machine without it.  The first entry point that needs a collective binds these by name.
+struct Rccl {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    std::string error;
+};
+const Rccl& rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { R.error = std::string("librccl could not be loaded: ") + dlerror(); return; }
+        auto bind = [&](auto& fp, const char* sym) { fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(h, sym)); if (!fp && R.error.empty()) R.error = std::string("librccl lacks ") + sym; };
+        bind(R.GetUniqueId, "ncclGetUniqueId"); bind(R.CommInitRank, "ncclCommInitRank"); bind(R.CommDestroy, "ncclCommDestroy"); bind(R.CommAbort, "ncclCommAbort");
+        bind(R.GetErrorString, "ncclGetErrorString"); bind(R.AllReduce, "ncclAllReduce"); bind(R.AllGather, "ncclAllGather"); bind(R.Broadcast, "ncclBroadcast");
+        bind(R.Send, "ncclSend"); bind(R.Recv, "ncclRecv"); bind(R.GroupStart, "ncclGroupStart"); bind(R.GroupEnd, "ncclGroupEnd");
+    });
+    return R;
+}
+bool rccl_ready(const char* fn) {
+    const Rccl& R = rccl();
+    if (R.error.empty()) return true;
+    wo::set_error(std::string(fn) + ": " + R.error);
+    return false;
+}
 bool nccl_ok(ncclResult_t r, const char* what) {
     if (r == ncclSuccess) return true;
-    wo::set_error(std::string(what) + ": " + ncclGetErrorString(r));
+    wo::set_error(std::string(what) + ": " + rccl().GetErrorString(r));
     return false;
 }
 // every exchange entry point: the planet's device current, and the communicator living on that device
@@ -51,9 +91,9 @@ bool comm_ready(wo_planet* p, wo_comm* c, const char* fn) {
 // ncclGroupStart is always answered by ncclGroupEnd, whatever happens in between
 struct GroupGuard {
     bool open = false;
-    bool start() { open = nccl_ok(ncclGroupStart(), "ncclGroupStart"); return open; }
-    bool end() { if (!open) return true; open = false; return nccl_ok(ncclGroupEnd(), "ncclGroupEnd"); }
-    ~GroupGuard() { if (open) (void)ncclGroupEnd(); }
+    bool start() { open = nccl_ok(rccl().GroupStart(), "ncclGroupStart"); return open; }
+    bool end() { if (!open) return true; open = false; return nccl_ok(rccl().GroupEnd(), "ncclGroupEnd"); }
+    ~GroupGuard() { if (open) (void)rccl().GroupEnd(); }
 };
 
 // RCCL form of the landmass decomposition's flood exchange (wo_planet_set_flood_exchange_comm)
@@ -88,7 +128,7 @@ int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
         if (phase == 0) {
             *k->h_flag = *(int32_t*)buf;
             WO_HIP(hipMemcpyAsync(k->d_flag, k->h_flag, sizeof(int32_t), hipMemcpyHostToDevice, s));
-            if (!nccl_ok(ncclAllReduce(k->d_flag, k->d_flag, 1, ncclInt32, ncclMax, c->comm, s), "ncclAllReduce")) return 1;
+            if (!nccl_ok(rccl().AllReduce(k->d_flag, k->d_flag, 1, ncclInt32, ncclMax, c->comm, s), "ncclAllReduce")) return 1;
             WO_HIP(hipMemcpyAsync(k->h_flag, k->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             WO_HIP(hipStreamSynchronize(s));
             *(int32_t*)buf = *k->h_flag;
@@ -99,7 +139,7 @@ int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
             const bool sender = phase == 2;
             *k->h_flag = sender ? c->rank : -1;
             WO_HIP(hipMemcpyAsync(k->d_flag, k->h_flag, sizeof(int32_t), hipMemcpyHostToDevice, s));
-            if (!nccl_ok(ncclAllReduce(k->d_flag, k->d_flag, 1, ncclInt32, ncclMax, c->comm, s), "ncclAllReduce")) return 1;
+            if (!nccl_ok(rccl().AllReduce(k->d_flag, k->d_flag, 1, ncclInt32, ncclMax, c->comm, s), "ncclAllReduce")) return 1;
             WO_HIP(hipMemcpyAsync(k->h_flag, k->d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             WO_HIP(hipStreamSynchronize(s));
             const int32_t root = *k->h_flag;
@@ -112,7 +152,7 @@ int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
                 k->landCap = need;
             }
             if (sender) WO_HIP(hipMemcpyAsync(k->d_land, buf, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
-            if (!nccl_ok(ncclBroadcast(k->d_land, k->d_land, (size_t)n, ncclFloat, root, c->comm, s), "ncclBroadcast")) return 1;
+            if (!nccl_ok(rccl().Broadcast(k->d_land, k->d_land, (size_t)n, ncclFloat, root, c->comm, s), "ncclBroadcast")) return 1;
             if (!sender) WO_HIP(hipMemcpyAsync(buf, k->d_land, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s));
             WO_HIP(hipStreamSynchronize(s));
             return 0;
@@ -130,7 +170,7 @@ int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
         for (int32_t i = 0; i < nMine; ++i) { if (mine[i] >= n) { wo::set_error("flood exchange: cell id out of range"); return 1; } k->h_send[i] = field[mine[i]]; }
         for (size_t i = (size_t)nMine; i < M; ++i) k->h_send[i] = 0.0f;
         WO_HIP(hipMemcpyAsync(k->d_send, k->h_send, M * sizeof(float), hipMemcpyHostToDevice, s));
-        if (!nccl_ok(ncclAllGather(k->d_send, k->d_all, M, ncclFloat, c->comm, s), "ncclAllGather")) return 1;
+        if (!nccl_ok(rccl().AllGather(k->d_send, k->d_all, M, ncclFloat, c->comm, s), "ncclAllGather")) return 1;
         WO_HIP(hipMemcpyAsync(k->h_all, k->d_all, M * (size_t)c->nranks * sizeof(float), hipMemcpyDeviceToHost, s));
         WO_HIP(hipStreamSynchronize(s));
         for (int32_t j = 0; j < c->nranks; ++j) {
@@ -156,20 +196,22 @@ extern "C" {
 int wo_comm_unique_id(uint8_t* id) {
     if (!id) { wo::set_error("wo_comm_unique_id: null output"); return 1; }
     static_assert(sizeof(ncclUniqueId) == WO_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    if (!rccl_ready("wo_comm_unique_id")) return 1;
     ncclUniqueId u;
-    if (!nccl_ok(ncclGetUniqueId(&u), "ncclGetUniqueId")) return 1;
+    if (!nccl_ok(rccl().GetUniqueId(&u), "ncclGetUniqueId")) return 1;
     std::memcpy(id, &u, sizeof(u));
     return 0;
 }
 
 int wo_comm_create(wo_ctx* ctx, const uint8_t* id, int32_t nranks, int32_t rank, wo_comm** out) {
     if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) { wo::set_error("wo_comm_create: bad arguments"); return 1; }
+    if (!rccl_ready("wo_comm_create")) return 1;
     if (hipSetDevice(ctx->device) != hipSuccess) { wo::set_error("wo_comm_create: cannot select the context's device"); return 1; }
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     wo_comm* c = new wo_comm;
     c->nranks = nranks; c->rank = rank; c->device = ctx->device;
-    if (!nccl_ok(ncclCommInitRank(&c->comm, nranks, u, rank), "ncclCommInitRank")) { delete c; return 1; }
+    if (!nccl_ok(rccl().CommInitRank(&c->comm, nranks, u, rank), "ncclCommInitRank")) { delete c; return 1; }
     *out = c;
     return 0;
 }
@@ -177,7 +219,7 @@ int wo_comm_create(wo_ctx* ctx, const uint8_t* id, int32_t nranks, int32_t rank,
 int wo_comm_destroy(wo_comm* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
     if (c->gather) (void)hipFree(c->gather);
     if (c->send) (void)hipFree(c->send);
     delete c;
@@ -202,7 +244,7 @@ int wo_planet_exchange_allgather(wo_planet* p, wo_comm* c, const int32_t* counts
         if (!c->send || !c->gather) { wo::set_error("wo_planet_exchange_allgather: out of device memory"); return 1; }
         if (p->nHaloSend > 0) wo::launch(p, wo::FAM_MISC, k_comm_pack, wo::blocks_for(p->nHaloSend), wo::WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_haloSend, p->nHaloSend, c->send);
         if (p->nHaloSend < maxCount) WO_HIP(hipMemsetAsync(c->send + p->nHaloSend, 0, (size_t)(maxCount - p->nHaloSend) * sizeof(float), s));
-        if (!nccl_ok(ncclAllGather(c->send, c->gather, (size_t)maxCount, ncclFloat, c->comm, s), "ncclAllGather")) return 1;
+        if (!nccl_ok(rccl().AllGather(c->send, c->gather, (size_t)maxCount, ncclFloat, c->comm, s), "ncclAllGather")) return 1;
         // the others' parts, compacted in rank order into the unpack buffer
         size_t at = 0;
         for (int32_t j = 0; j < c->nranks; ++j) {
@@ -233,11 +275,11 @@ int wo_planet_exchange_neighbors(wo_planet* p, wo_comm* c, int32_t nToPrev, int3
         GroupGuard group;
         if (!group.start()) return 1;
         bool ok = true;
-        if (hasPrev && nToPrev) ok = ok && nccl_ok(ncclSend(c->send, (size_t)nToPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclSend");
-        if (hasNext && nToNext) ok = ok && nccl_ok(ncclSend(c->send + nToPrev, (size_t)nToNext, ncclFloat, c->rank + 1, c->comm, s), "ncclSend");
-        if (hasPrev && nFromPrev) ok = ok && nccl_ok(ncclRecv(p->d_haloBuf, (size_t)nFromPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclRecv");
-        if (hasNext && nFromNext) ok = ok && nccl_ok(ncclRecv(p->d_haloBuf + nFromPrev, (size_t)nFromNext, ncclFloat, c->rank + 1, c->comm, s), "ncclRecv");
-        if (!group.end() || !ok) { (void)ncclCommAbort(c->comm); c->comm = nullptr; wo::set_error("wo_planet_exchange_neighbors: send / receive failed, the communicator was aborted"); return 1; }
+        if (hasPrev && nToPrev) ok = ok && nccl_ok(rccl().Send(c->send, (size_t)nToPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclSend");
+        if (hasNext && nToNext) ok = ok && nccl_ok(rccl().Send(c->send + nToPrev, (size_t)nToNext, ncclFloat, c->rank + 1, c->comm, s), "ncclSend");
+        if (hasPrev && nFromPrev) ok = ok && nccl_ok(rccl().Recv(p->d_haloBuf, (size_t)nFromPrev, ncclFloat, c->rank - 1, c->comm, s), "ncclRecv");
+        if (hasNext && nFromNext) ok = ok && nccl_ok(rccl().Recv(p->d_haloBuf + nFromPrev, (size_t)nFromNext, ncclFloat, c->rank + 1, c->comm, s), "ncclRecv");
+        if (!group.end() || !ok) { (void)rccl().CommAbort(c->comm); c->comm = nullptr; wo::set_error("wo_planet_exchange_neighbors: send / receive failed, the communicator was aborted"); return 1; }
         if (p->nHaloRecv > 0) wo::launch(p, wo::FAM_MISC, k_comm_unpack, wo::blocks_for(p->nHaloRecv), wo::WO_BLOCK, p->d_e, (const int32_t*)p->d_haloRecv, p->nHaloRecv, (const float*)p->d_haloBuf);
         WO_HIP(hipStreamSynchronize(s));
         return 0;

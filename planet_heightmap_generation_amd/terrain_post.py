@@ -128,11 +128,23 @@ class Planet:
         capi.check(capi.lib().wo_smooth_elevation(self.handle, capi.ptr(e), capi.ptr(_u8(r_isOcean, e.size)), int(iterations), float(strength)),
                    "smoothElevation")
 
+    def _check_erode(self, rc: int) -> None:
+        """capi.check for erodeComposite: a failure inside the flood-exchange callback (set_flood_exchange) is the cause, not just a status."""
+        try:
+            capi.check(rc, "erodeComposite")
+        except capi.WorogenError as err:
+            pending = getattr(self, "_flood_errors", None)
+            if pending:
+                cause = pending[-1]
+                del pending[:]
+                raise capi.WorogenError(f"{err} (flood exchange: {cause!r})") from cause
+            raise
+
     def erode_composite(self, r_elevation, r_isOcean, hIters, K, m, dt, tIters, talusSlope, kThermal, gIters=0, glacialStrength=0.0):
         e = _f32(r_elevation, self.numRegions)
-        capi.check(capi.lib().wo_erode_composite(self.handle, capi.ptr(e), capi.ptr(_u8(r_isOcean, e.size)), int(hIters), float(K), float(m),
-                                                 float(dt), int(tIters), float(talusSlope), float(kThermal), int(gIters or 0),
-                                                 float(glacialStrength or 0.0)), "erodeComposite")
+        self._check_erode(capi.lib().wo_erode_composite(self.handle, capi.ptr(e), capi.ptr(_u8(r_isOcean, e.size)), int(hIters), float(K), float(m),
+                                                        float(dt), int(tIters), float(talusSlope), float(kThermal), int(gIters or 0),
+                                                        float(glacialStrength or 0.0)))
 
     def sharpen_ridges(self, r_elevation, r_isOcean, iterations, strength):
         e = _f32(r_elevation, self.numRegions)
@@ -270,8 +282,8 @@ class Planet:
         capi.check(capi.lib().wo_smooth_elevation_resident(self.handle, int(iterations), float(strength)), "smoothElevation")
 
     def erode_composite_resident(self, hIters, K, m, dt, tIters, talusSlope, kThermal, gIters=0, glacialStrength=0.0):
-        capi.check(capi.lib().wo_erode_composite_resident(self.handle, int(hIters), float(K), float(m), float(dt), int(tIters), float(talusSlope),
-                                                          float(kThermal), int(gIters), float(glacialStrength)), "erodeComposite")
+        self._check_erode(capi.lib().wo_erode_composite_resident(self.handle, int(hIters), float(K), float(m), float(dt), int(tIters), float(talusSlope),
+                                                                 float(kThermal), int(gIters), float(glacialStrength)))
 
     def sharpen_ridges_resident(self, iterations, strength):
         capi.check(capi.lib().wo_sharpen_ridges_resident(self.handle, int(iterations), float(strength)), "sharpenRidges")

@@ -33,6 +33,14 @@ def test_no_cpu_fallback_without_device():
         terrain_post.Context(0)
 
 
+def test_rccl_is_not_a_load_time_dependency():
+    """Single-GPU hosts never map librccl: the collectives are bound by name at the first multi-GPU entry point (csrc/comm.hip)."""
+    import subprocess
+    from planet_heightmap_generation_amd import capi
+    needed = subprocess.run(["readelf", "-d", str(capi.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "libamdhip64" in needed and "rccl" not in needed, needed
+
+
 def test_product_does_not_reference_the_oracle():
     pkg = REPO / "planet_heightmap_generation_amd"
     for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.cc")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + list(pkg.rglob("*.js")) + list(pkg.rglob("*.mjs")):
