@@ -145,7 +145,8 @@ void sort_land_by_elevation(wo_planet* p) {
     const int32_t L = p->L;
     const int cur = p->landCur;
     // (measured in round 4: the keys made inside the first counting pass of the in-tree sort instead of by a launch of their own — sort stage 34.6 ms
-    // per step against 33.1: the counting pass's 679 workgroups gather the heights more slowly than this grid does)
+    // per step against 33.1: the counting pass's 679 workgroups gather the heights more slowly than this grid does.  Round 5: the keys written by the
+    // thermal step of the previous iteration, keys[rank[cell]] — sort 33.1 -> 28.3 ms per step, thermal 37.6 -> 44.2: profiles/r05z_*; removed)
     launch(p, FAM_SORT_KEYS, k_sort_keys, blocks_for(L, 4096), WO_BLOCK, (const float*)p->d_e, (const int32_t*)p->d_land[cur],
            p->d_keys[0], L);
     hipStream_t s = p->ctx->stream;
