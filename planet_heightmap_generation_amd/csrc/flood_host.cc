@@ -473,6 +473,7 @@ void FloodHooks::read() {
     replayPrefix = num("WO_FLOOD_PREFIX", 1) != 0;
     forcePrefixPermille = std::min(1000, std::max(0, num("WO_FLOOD_FORCE_PREFIX", 0)));
     timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
+    pin = num("WO_FLOOD_PIN", 1) != 0;
 }
 
 // land elevations into the compact arrays + the start state of pass 1 (:107-113); every flood call starts here: the hooks are read
@@ -1295,16 +1296,38 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
                 if (J.doneChunks.fetch_add(1) + 1 == nChunks) bigLeft.fetch_sub(1);
             }
         };
+        // The walk of the largest landmass is the critical path of the call, one thread for 27-40 ms, and its working set (~20 MB) lives in the
+        // last-level cache of the core it runs on.  That thread stays on the CPU it is on and every other worker of the round keeps off the
+        // CPUs that share its L3 (an EPYC CCD) until it is done (WO_FLOOD_PIN=0: nobody's affinity is touched).
+        const CpuGroups& cpus = CpuGroups::get();
+        const bool pinning = S.hooks.pin && !walked && nBig > 0 && !cpus.groups.empty() && nt > 1;
+        std::atomic<int> reservedGroup{-1};
         auto worker = [&](int w) {
             Local& me = loc[w];
             std::vector<int32_t> path, cnt;
             static thread_local PopLog popLog;
             PopLog* const log = prefix.empty() ? nullptr : &popLog;
+            AffinityScope affinity;
+            bool placed = false;
             for (;;) {
                 const int32_t q = next.fetch_add(1);
                 if (q >= nList) break;
                 const int32_t k = list[q];
                 bool track = false, undecided = false;
+                if (pinning && !placed) {
+                    if (q == 0) {
+                        const int cpu = sched_getcpu();
+                        const int g = cpu >= 0 && cpu < (int)cpus.groupOf.size() ? cpus.groupOf[cpu] : -1;
+                        if (g >= 0 && affinity.only(cpu)) reservedGroup.store(g, std::memory_order_release);
+                        else reservedGroup.store(-2, std::memory_order_release);
+                        if (T.on) std::fprintf(stderr, "[flood] the largest walk stays on cpu %d; the other workers keep off its L3 (group %d of %zu)\n", cpu, g, cpus.groups.size());
+                        placed = true;
+                    } else {
+                        const int g = reservedGroup.load(std::memory_order_acquire);
+                        if (g >= 0) { (void)affinity.all_but_group(cpus, g); placed = true; }
+                        else if (g == -2) placed = true;
+                    }
+                }
                 if (!walked) {
                     // --- pass 1 of landmass k
                     me.contests.clear();

@@ -7,7 +7,9 @@
 #include <mutex>
 #include <new>
 #include <pthread.h>
+#include <sched.h>
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
@@ -143,6 +145,60 @@ inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
     }
     for (auto& t : th) t.join();
 }
+
+// ---- where the host threads run (Linux) ----
+// The CPUs this process may use, grouped by the last-level cache they share (one CCD of an EPYC: 8 cores, 32 MB).  Read once from sysfs;
+// a machine where that fails, or whose mask holds a single group, has no groups and nothing is ever pinned.
+struct CpuGroups {
+    std::vector<std::vector<int>> groups;          // logical CPUs per L3
+    std::vector<int> groupOf;                      // by logical CPU number, -1: not ours
+    static const CpuGroups& get() {
+        static const CpuGroups* g = [] {
+            CpuGroups* G = new CpuGroups();
+            cpu_set_t mask;
+            CPU_ZERO(&mask);
+            if (sched_getaffinity(0, sizeof(mask), &mask) != 0) return G;
+            std::vector<int> l3ids;
+            G->groupOf.assign(CPU_SETSIZE, -1);
+            for (int c = 0; c < CPU_SETSIZE; ++c) {
+                if (!CPU_ISSET(c, &mask)) continue;
+                char path[128];
+                std::snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/id", c);
+                int id = -1;
+                if (FILE* f = std::fopen(path, "r")) { if (std::fscanf(f, "%d", &id) != 1) id = -1; std::fclose(f); }
+                if (id < 0) { G->groups.clear(); std::fill(G->groupOf.begin(), G->groupOf.end(), -1); return G; }
+                size_t k = 0;
+                while (k < l3ids.size() && l3ids[k] != id) ++k;
+                if (k == l3ids.size()) { l3ids.push_back(id); G->groups.emplace_back(); }
+                G->groups[k].push_back(c);
+                G->groupOf[c] = (int)k;
+            }
+            if (G->groups.size() < 2) { G->groups.clear(); std::fill(G->groupOf.begin(), G->groupOf.end(), -1); }
+            return G;
+        }();
+        return *g;
+    }
+};
+// The calling thread's affinity for the lifetime of the object (restored on destruction; a failed call changes nothing).
+struct AffinityScope {
+    cpu_set_t before; bool changed = false;
+    AffinityScope() { CPU_ZERO(&before); }
+    bool only(int cpu) { cpu_set_t m; CPU_ZERO(&m); CPU_SET(cpu, &m); return set(m); }
+    bool all_but_group(const CpuGroups& G, int group) {
+        cpu_set_t m; CPU_ZERO(&m);
+        int n = 0;
+        for (size_t g = 0; g < G.groups.size(); ++g) if ((int)g != group) for (int c : G.groups[g]) { CPU_SET(c, &m); ++n; }
+        return n > 0 && set(m);
+    }
+    ~AffinityScope() { if (changed) (void)pthread_setaffinity_np(pthread_self(), sizeof(before), &before); }
+private:
+    bool set(const cpu_set_t& m) {
+        if (!changed && pthread_getaffinity_np(pthread_self(), sizeof(before), &before) != 0) return false;
+        if (pthread_setaffinity_np(pthread_self(), sizeof(m), &m) != 0) return false;
+        changed = true;
+        return true;
+    }
+};
 
 // Connected components of the cells r with member(r), joined along mesh edges (r, nb) with joined(r, nb): a concurrent
 // union-find (link the larger root under the smaller with a CAS, path halving on the way up).  On return parent[r] is
