@@ -794,8 +794,8 @@ struct TreeCtx { const FloodCell* st; float* eL; const float* surface; double ca
 // tree is not a single rooted tree of claimed cells — the caller then takes the plain form.
 // trees of at least this many cells take the chain form (WO_FLOOD_CHAINS_MIN, read per call: the tests run both forms; 0 = never)
 struct ChainScratch {
-    std::vector<int32_t> par, kids, kidStart, order, sz, heavy, posOf, headPos, jump, cellAt;
-    std::vector<float> E;
+    std::vector<int32_t> par, kids, kidStart, order, sz, heavy, posOf, headPos, jump, cellAt, depth;
+    std::vector<float> E, S;
     std::vector<double> term;
 };
 bool tree_pass2_chains(const TreeCtx& X, const int32_t* cells, int32_t n, int64_t& lenSum, int64_t& nDeficit) {
@@ -828,7 +828,9 @@ bool tree_pass2_chains(const TreeCtx& X, const int32_t* cells, int32_t n, int64_
     C.sz.assign(n, 1); C.heavy.assign(n, -1);
     for (int32_t i = n - 1; i > 0; --i) { const int32_t v = C.order[i]; C.sz[C.par[v]] += C.sz[v]; }
     for (int32_t i = 1; i < n; ++i) { const int32_t v = C.order[i], p = C.par[v]; if (C.heavy[p] < 0 || C.sz[v] > C.sz[C.heavy[p]]) C.heavy[p] = v; }
-    C.posOf.resize(n); C.headPos.resize(n); C.jump.assign(n, -1); C.cellAt.resize(n); C.E.resize(n);
+    C.posOf.resize(n); C.headPos.resize(n); C.jump.assign(n, -1); C.cellAt.resize(n); C.E.resize(n); C.S.resize(n); C.depth.resize(n);
+    C.depth[rootQ] = 0;
+    for (int32_t i = 1; i < n; ++i) { const int32_t v = C.order[i]; C.depth[v] = C.depth[C.par[v]] + 1; }
     {   // chain by chain in breadth-first order of the chain heads: positions grow towards the sea inside a chain
         int32_t base = 0;
         for (int32_t i = 0; i < n; ++i) {
@@ -838,12 +840,13 @@ bool tree_pass2_chains(const TreeCtx& X, const int32_t* cells, int32_t n, int64_
             for (int32_t u = v; u >= 0; u = C.heavy[u]) ++m;
             const int32_t top = base + m - 1;
             int32_t at = top;
-            for (int32_t u = v; u >= 0; u = C.heavy[u], --at) { C.posOf[u] = at; C.headPos[at] = top; C.cellAt[at] = cells[u]; C.E[at] = eL[cells[u]]; }
+            for (int32_t u = v; u >= 0; u = C.heavy[u], --at) { C.posOf[u] = at; C.headPos[at] = top; C.cellAt[at] = cells[u]; C.E[at] = eL[cells[u]]; C.S[at] = surf(cells[u]); }
             C.jump[top] = C.par[v] >= 0 ? C.posOf[C.par[v]] : -1;        // the head's receiver: its chain was laid out earlier
             base += m;
         }
     }
     float* E = C.E.data();
+    const float* S = C.S.data();
     const int32_t* headPos = C.headPos.data();
     const int32_t* jump = C.jump.data();
     int32_t segA[64], segB[64], segK[64];
@@ -852,13 +855,33 @@ bool tree_pass2_chains(const TreeCtx& X, const int32_t* cells, int32_t n, int64_
         const double deficit = (double)surf(r) - (double)E[pr];      // against the CURRENT height (:154)
         if (deficit <= EPS) continue;
         ++nDeficit;
-        int nseg = 0; int32_t len = 0, peakIdx = -1;
+        // The path's length is the cell's depth in the tree; its peak (the FIRST maximum of the current heights, :160-165) is found without walking
+        // all of it: a height never exceeds its cell's flood surface (pass 2 lowers heights, and lifts the deficit cell by less than its deficit),
+        // and the surfaces do not increase towards the sea (pass 1: a claimed cell's surface is at least its claimant's), so once the surface of
+        // the next cell is no higher than the maximum in hand nothing further down can beat it.  The segments are then only followed as far as the
+        // carve window reaches.  (A tracked landmass marks every cell of the path: no shortcut there.)
+        const int32_t len = C.depth[q] + 1;
+        int nseg = 0; int32_t seen = 0, peakIdx = -1;
         float peakElev = -INFINITY;
-        for (int32_t a = pr; a >= 0;) {
+        bool scanning = true;
+        const bool whole = X.onPath != nullptr;
+        int32_t need = len;                                  // path cells the segment list has to cover (shrinks to the window's end when the scan stops)
+        for (int32_t a = pr; a >= 0 && seen < need;) {
             const int32_t b = headPos[a];
-            segA[nseg] = a; segB[nseg] = b; segK[nseg] = len; ++nseg;
-            for (int32_t p = a; p <= b; ++p) if (E[p] > peakElev) { peakElev = E[p]; peakIdx = len + (p - a); }
-            len += b - a + 1;
+            segA[nseg] = a; segB[nseg] = b; segK[nseg] = seen; ++nseg;
+            if (scanning) {
+                int32_t p = a;
+                for (; p <= b; ++p) {
+                    if (!whole && S[p] <= peakElev) { scanning = false; break; }
+                    if (E[p] > peakElev) { peakElev = E[p]; peakIdx = seen + (p - a); }
+                }
+                if (!scanning) {
+                    const double rcs = std::ceil((double)len * 0.3);
+                    const int32_t rad = rcs > 3.0 ? (int32_t)rcs : 3;
+                    need = peakIdx + rad + 1 < len ? peakIdx + rad + 1 : len;
+                }
+            }
+            seen += b - a + 1;
             a = jump[b];
         }
         if (X.onPath) for (int s = 0; s < nseg; ++s) for (int32_t p = segA[s]; p <= segB[s]; ++p) X.onPath[C.cellAt[p]] = 1;
