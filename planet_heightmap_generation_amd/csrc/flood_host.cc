@@ -1095,7 +1095,8 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
             if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) return false;
         }
     }
-    if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
+    if (S.landOrder && e == eL) {}                       // the caller handed eL itself over (pinned by the planet: the result is uploaded straight from it)
+    else if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
     else parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
@@ -1145,8 +1146,8 @@ bool replay_dirty_landmasses(FloodScratch& S, const std::vector<uint8_t>& dirtyC
             for (int64_t q = b; q < en; ++q) {                       // back to the start state of pass 1 (flood_gather) ...
                 const int32_t i = cells[q];
                 S.localIdx[i] = k;                                   // (scratch of the carve pass, free until round 2: which landmass a frontier entry belongs to)
-                const float v = S.landOrder ? e[i] : e[landCell[i]];
-                eL[i] = v; st[i].e = v;
+                const float v = st[i].e;                             // the height at the start of the call (flood_gather's copy: e may BE eL, which round 1 has carved)
+                eL[i] = v;
                 const int32_t par = st[i].drain;                     // ... except what the prefix popped or claimed (a claimant is a neighbour: same landmass)
                 if (dirty[i] == 2 || (par >= 0 && dirty[par] == 2)) continue;
                 st[i].surface = v; st[i].drain = UNVISITED; st[i].root = -1;
@@ -1513,7 +1514,8 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         T.lap("round 2");
     }
     const int32_t* landCell = S.landCell.data();
-    if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
+    if (S.landOrder && e == eL) {}                       // the caller handed eL itself over (pinned by the planet: the result is uploaded straight from it)
+    else if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
     else parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
