@@ -486,9 +486,15 @@ void flood_gather(const float* e, FloodScratch& S) {
     FloodCell* st = S.state.data();
     if ((int32_t)S.seen.size() < L) S.seen.resize(L);
     uint8_t* seen = S.seen.data();
+    // (the tie stamps and the path marks of the landmass pipeline are cleared in the same sweep: two dispatches of the worker pool less per call)
+    if ((int32_t)S.stamp.size() < L) S.stamp.resize(L);
+    if ((int32_t)S.onPath.size() < L) S.onPath.resize(L);
+    int32_t* stamp = S.stamp.data(); uint8_t* onPath = S.onPath.data();
     parallel_ranges(L, [&](int64_t b, int64_t en, int) {
         for (int64_t i = b; i < en; ++i) { const float v = landOrder ? e[i] : e[landCell[i]]; eL[i] = v; st[i].surface = v; st[i].e = v; st[i].drain = UNVISITED; st[i].root = -1; }
         std::memset(seen + b, 0, (size_t)(en - b));
+        std::memset(onPath + b, 0, (size_t)(en - b));
+        std::memset(stamp + b, 0, sizeof(int32_t) * (size_t)(en - b));
     });
 }
 
@@ -1266,9 +1272,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
     const int32_t L = S.L;
     rep = FloodTieReport{};
     rep.landmasses = nComp;
-    parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(S.stamp.data() + b, 0, sizeof(int32_t) * (size_t)(en - b)); });
-    S.onPath.resize(L);
-    parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memset(S.onPath.data() + b, 0, (size_t)(en - b)); });
+    // (stamp and onPath start at zero: flood_gather, which every caller runs first)
     const int nt = std::min(flood_workers(std::max(nComp, 1)), std::max(1, L / 16384));    // small planets: a thread costs more than it saves
     rep.workers = nt;
     if ((int)S.workerHeaps.size() < nt) S.workerHeaps.resize(nt);

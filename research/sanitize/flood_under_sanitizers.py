@@ -28,7 +28,7 @@ L = C.CDLL(str(lib)); p = C.c_void_p
 L.emu_flood_host.argtypes = [C.c_int32, p, p, p, p, p, C.c_double, C.c_int32, C.c_int32, p]
 L.emu_flood_shares.argtypes = [C.c_int32, p, p, p, p, p, p, C.c_int32, C.c_double, C.c_int32, p]
 P = lambda a: a.ctypes.data_as(p)                                                   # noqa: E731
-cells = 60000 if kind == "asan" else 300000
+cells = 60000 if kind == "asan" else 700000
 mesh, xyz, nd = S.build_sphere(cells, 0.75, 2)
 om = O.Mesh(mesh.adjOffset, mesh.adjList)
 base = O.warp_terrain(om, O.synthetic_terrain(xyz, 2), xyz, 2, 0.75)
