@@ -88,6 +88,7 @@ namespace wo {
 struct Options {
     bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror
     bool sortLibrary = false;          // WO_SORT=hipcub           the library's radix sort instead of radix.hip
+    bool noLandListCache = false;      // WO_NO_LAND_LIST_CACHE=1  the land lists are rebuilt by every erodeComposite call (default: kept while the ocean mask stays the same)
     bool floodNoDirect = false;        // WO_FLOOD_STAGING=copy    the flood stage copies the land heights through the planet's pinned buffer (default: straight into / out of the flood's own array)
     bool basinBarrierKernel = false;   // WO_BASIN_KERNEL=barrier  k_solve_coop (one barrier per super-chunk) instead of k_solve_flowing
     bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr (=2: without the depth bookkeeping, which doubles the kernel's time)
@@ -139,6 +140,7 @@ struct wo_planet {
     // resident fields
     float *d_e = nullptr, *d_e2 = nullptr, *d_hot = nullptr, *d_orig = nullptr;
     uint8_t *d_ocean = nullptr, *d_coast = nullptr;
+    uint8_t* d_oceanKnown = nullptr; int32_t* d_maskDiff = nullptr; bool oceanKnownValid = false;   // the mask h_ocean describes, on the device (refresh_host_ocean)
     bool hot_valid = false;
     float* d_savedE = nullptr; uint8_t* d_savedOcean = nullptr; bool saved = false;
     uint8_t* d_tables = nullptr;        // perm[512] + pm12[512]
@@ -148,6 +150,8 @@ struct wo_planet {
     int64_t floodPrefixMirror = -1, floodPrefixStatic = -1;      // (mirror version, flood static version) for which the mirror's first L ids were checked to be the flood's land order
     bool floodPrefixOk = false;
     int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
+    // the initial land list (ascending r, js/terrain-post.js:384-390) and the index-order list are functions of the ocean mask alone: kept while it stays
+    int32_t* d_landInit = nullptr; int64_t oceanVersion = 0, landListsOcean = -1; bool landListsMirror = false; int32_t landListsL = -1;
     uint32_t* d_keys[2] = {nullptr, nullptr};
     float *d_cellDist = nullptr, *d_flow = nullptr;
     wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; int32_t *d_haloSend = nullptr, *d_haloRecv = nullptr; float *d_haloBuf = nullptr, *h_haloBuf = nullptr; int32_t nHaloSend = 0, nHaloRecv = 0;   // banded Jacobi passes

@@ -92,17 +92,34 @@ static inline void swap_elev(wo_planet* p) { std::swap(p->d_e, p->d_e2); }
 // The device ocean mask changed (or may have): the host copy is refreshed lazily.  The flood's cached
 // open-ocean / seed data is only rebuilt when the mask really differs (a "reapply" with the same mask keeps it).
 static inline void ocean_changed(wo_planet* p) { p->h_ocean_valid = false; }
+__global__ __launch_bounds__(wo::WO_BLOCK) void k_mask_differs(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int32_t N, int32_t* flag) {
+    bool diff = false;
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) diff |= a[r] != b[r];
+    if (diff) atomicOr(flag, 1);
+}
+static int32_t read_count(wo_planet* p, const int32_t* d_ptr);
+// The host's copy of the ocean mask, brought up to date.  A mask written on the device (ocean_from_elevation, restore_state, synthetic_terrain) is
+// first compared ON the device with the mask the host copy describes (a copy of it kept there): a step that re-derives the same mask — every step of
+// the bench — then costs one 10 us kernel and one word instead of a 10 MB download and a 10 MB memcmp.
 static void refresh_host_ocean(wo_planet* p) {
     if (p->h_ocean_valid) return;
     hipStream_t s = p->ctx->stream;
+    if (p->d_oceanKnown && p->oceanKnownValid && p->h_ocean.size() == (size_t)p->N) {
+        WO_HIP(hipMemsetAsync(p->d_maskDiff, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_mask_differs, dim3(wo::blocks_for(p->N, 1 << 15)), dim3(wo::WO_BLOCK), 0, s, (const uint8_t*)p->d_ocean, (const uint8_t*)p->d_oceanKnown, p->N, p->d_maskDiff);
+        if (read_count(p, p->d_maskDiff) == 0) { p->h_ocean_valid = true; return; }
+    }
     hvec<uint8_t> tmp(p->N);
     WO_HIP(hipMemcpyAsync(tmp.data(), p->d_ocean, p->N, hipMemcpyDeviceToHost, s));
     WO_HIP(hipStreamSynchronize(s));
     if (tmp.size() != p->h_ocean.size() || std::memcmp(tmp.data(), p->h_ocean.data(), tmp.size()) != 0) {
         p->h_ocean.swap(tmp);
-        p->flood.staticValid = false;
+        p->flood.staticValid = false; ++p->oceanVersion;
     }
     p->h_ocean_valid = true;
+    if (!p->d_oceanKnown) { WO_HIP(hipMalloc((void**)&p->d_oceanKnown, (size_t)p->N)); WO_HIP(hipMalloc((void**)&p->d_maskDiff, sizeof(int32_t))); }
+    WO_HIP(hipMemcpyAsync(p->d_oceanKnown, p->d_ocean, (size_t)p->N, hipMemcpyDeviceToDevice, s));
+    p->oceanKnownValid = true;
 }
 
 // One device integer for the host, through a host-mapped word the host polls: ~10 us from the producing kernel's end to the next
@@ -134,7 +151,7 @@ static int32_t publish_and_wait(wo_planet* p, const int32_t* d_ptr) {
     return p->h_count[0];
 }
 
-static int32_t read_count(wo_planet* p, const int32_t* d_ptr) { return publish_and_wait(p, d_ptr); }
+int32_t read_count(wo_planet* p, const int32_t* d_ptr) { return publish_and_wait(p, d_ptr); }
 
 // ---------------------------------------------------------------------------------------------------
 // Synchronous dependency rounds.  Round k reads the list of pending tasks (count in counters[k%3]), runs
@@ -725,7 +742,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     {
         int32_t* hl = reinterpret_cast<int32_t*>(p->h_pinned);
         int32_t L = 0;
-        {
+        // both lists only depend on the mask (and on whether the call runs on the mirror): a call with the mask of the previous one takes them as they are
+        const bool listsKept = p->d_landInit && p->landListsOcean == p->oceanVersion && p->landListsMirror == mir.on && p->landListsL >= 0 && !p->opt.noLandListCache;
+        if (listsKept) L = p->landListsL;
+        else {
             const uint8_t* oc = p->h_ocean.data();
             std::vector<int64_t> cnt(host_threads() + 2, 0);
             parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t r = b; r < e; ++r) c += oc[r] ? 0 : 1; cnt[t + 1] = c; });
@@ -751,7 +771,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             mir.finish();
             clk.end(); clk.finish(); return;
         }
-        if (mir.on) {
+        if (listsKept) {
+            WO_HIP(hipMemcpyAsync(p->d_land[0], p->d_landInit, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        } else if (mir.on) {
             // initial landCells: the same cells in the same (ascending-r) order, under their mirror names
             WO_HIP(hipMemcpyAsync(p->d_listA, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
             launch(p, FAM_MISC, k_mirror_map_i32, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_listA, (const int32_t*)p->mirror.inv, p->d_land[0], L);
@@ -767,6 +789,11 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         } else {
             WO_HIP(hipMemcpyAsync(p->d_landIdx, hl, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, s));
             WO_HIP(hipMemcpyAsync(p->d_land[0], p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        }
+        if (!listsKept) {
+            if (!p->d_landInit) p->d_landInit = dalloc<int32_t>((size_t)N);
+            WO_HIP(hipMemcpyAsync(p->d_landInit, p->d_land[0], (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            p->landListsOcean = p->oceanVersion; p->landListsMirror = mir.on; p->landListsL = L;
         }
         WO_HIP(hipStreamSynchronize(s));       // h_pinned is reused by the flood stage
         p->landCur = 0;
@@ -1322,6 +1349,7 @@ Options Options::from_env() {
     Options o;
     o.layoutIndex = str("WO_LAYOUT") == "index";
     o.sortLibrary = str("WO_SORT") == "hipcub";
+    o.noLandListCache = on("WO_NO_LAND_LIST_CACHE");
     o.floodNoDirect = str("WO_FLOOD_STAGING") == "copy";
     o.basinBarrierKernel = str("WO_BASIN_KERNEL") == "barrier";
     o.basinStats = on("WO_BASIN_STATS"); o.basinStatsNoDepth = str("WO_BASIN_STATS") == "2";
@@ -1494,7 +1522,8 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_lateDonor);
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
-    dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
+    if (p->d_oceanKnown) { (void)hipFree(p->d_oceanKnown); p->d_oceanKnown = nullptr; } if (p->d_maskDiff) { (void)hipFree(p->d_maskDiff); p->d_maskDiff = nullptr; }
+    dfree(p->d_landInit); dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_affine[0]); dfree(p->d_affine[1]); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
@@ -1522,7 +1551,8 @@ int wo_planet_upload(wo_planet* p, const float* r_elevation, const uint8_t* r_is
         WO_HIP(hipMemcpyAsync(p->d_ocean, r_isOcean, (size_t)p->N, hipMemcpyHostToDevice, s));
         if (p->h_ocean.size() != (size_t)p->N || std::memcmp(p->h_ocean.data(), r_isOcean, (size_t)p->N) != 0) {
             p->h_ocean.assign(r_isOcean, r_isOcean + p->N);
-            p->flood.staticValid = false;
+            p->flood.staticValid = false; ++p->oceanVersion;
+            p->oceanKnownValid = false;                    // (the device-side copy of the known mask is brought up to date by the next download)
         }
         p->h_ocean_valid = true;
     }
