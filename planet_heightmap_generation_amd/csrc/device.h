@@ -140,6 +140,7 @@ struct wo_planet {
     // resident fields
     float *d_e = nullptr, *d_e2 = nullptr, *d_hot = nullptr, *d_orig = nullptr;
     uint8_t *d_ocean = nullptr, *d_coast = nullptr;
+    int64_t mirrorMaskVersion = -1;      // oceanVersion of the mask the mirror was built for (mirror_build), -1: another mask
     uint8_t* d_oceanKnown = nullptr; int32_t* d_maskDiff = nullptr; bool oceanKnownValid = false;   // the mask h_ocean describes, on the device (refresh_host_ocean)
     bool hot_valid = false;
     float* d_savedE = nullptr; uint8_t* d_savedOcean = nullptr; bool saved = false;
@@ -199,6 +200,10 @@ struct wo_planet {
     double famMs[wo::FAM_COUNT] = {0};
     int64_t famLaunches[wo::FAM_COUNT] = {0};
     std::vector<std::pair<std::string, double>> stageTiming;
+    // the stage brackets of the last erodeComposite call, not yet turned into milliseconds (wo_last_stage_timing does that: the queries are a
+    // millisecond of host work that the call itself no longer waits for)
+    struct StageBracket { std::string name; hipEvent_t a, b; };
+    std::vector<StageBracket> stageBrackets; std::vector<std::pair<std::string, std::pair<int64_t, int64_t>>> stageSeen; bool stagePending = false;
     std::vector<std::pair<std::string, double>> erodeStats;
 
     wo::Fields fields() const;

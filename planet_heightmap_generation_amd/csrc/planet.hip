@@ -362,17 +362,20 @@ struct StageClock {
     void end() { if (open) WO_HIP(hipEventRecord(ev.back().second.second, p->ctx->stream)); open = false; }
     void count_only(const char* name) { ++seen[name].first; }       // an occurrence that is not bracketed (an iteration replayed from the graph)
     void finish() {
-        WO_HIP(hipStreamSynchronize(p->ctx->stream));
-        std::map<std::string, double> acc; std::vector<std::string> order;
+        // the brackets are handed to the planet as they are; wo_last_stage_timing turns them into milliseconds when somebody asks
+        for (auto& b : p->stageBrackets) { p->eventPool.push_back(b.a); p->eventPool.push_back(b.b); }      // (an earlier call's, never asked for)
+        p->stageBrackets.clear(); p->stageSeen.clear();
+        std::vector<std::string> order;
         for (auto& e : ev) {
-            float ms = 0; WO_HIP(hipEventElapsedTime(&ms, e.second.first, e.second.second));
-            if (!acc.count(e.first)) order.push_back(e.first);
-            acc[e.first] += ms;
-            p->eventPool.push_back(e.second.first); p->eventPool.push_back(e.second.second);
+            bool known = false;
+            for (auto& n : order) if (n == e.first) { known = true; break; }
+            if (!known) order.push_back(e.first);
+            p->stageBrackets.push_back({e.first, e.second.first, e.second.second});
         }
+        for (auto& n : order) p->stageSeen.push_back({n, seen[n]});
         ev.clear();
         p->stageTiming.clear();
-        for (auto& n : order) { const auto& c = seen[n]; p->stageTiming.push_back({n, acc[n] * (c.second > 0 ? (double)c.first / (double)c.second : 1.0)}); }
+        p->stagePending = true;
     }
     // a call that ends by exception (RedoWithChecks, a failed exchange) never reaches finish(): its events go back to the pool
     ~StageClock() { for (auto& e : ev) { p->eventPool.push_back(e.second.first); p->eventPool.push_back(e.second.second); } }
@@ -624,7 +627,10 @@ static bool mirror_wanted(const wo_planet* p) {
 static void mirror_build(wo_planet* p, const uint8_t* mask = nullptr) {
     auto& M = p->mirror;
     const int32_t N = p->N; const size_t E = (size_t)p->E;
-    if (M.built && (!mask || (M.h_mask.size() == (size_t)N && std::memcmp(M.h_mask.data(), mask, (size_t)N) == 0))) return;
+    // (the planet's own host mask carries a version: the 10 MB comparison — 0.4 ms of host time with the device idle, at the top of every call — is only made for other masks)
+    const bool ownMask = mask && mask == p->h_ocean.data();
+    if (M.built && ownMask && M.h_mask.size() == (size_t)N && p->mirrorMaskVersion == p->oceanVersion) return;
+    if (M.built && (!mask || (M.h_mask.size() == (size_t)N && std::memcmp(M.h_mask.data(), mask, (size_t)N) == 0))) { if (ownMask) p->mirrorMaskVersion = p->oceanVersion; return; }
     hipStream_t s = p->ctx->stream;
     if (M.h_morton.empty()) morton_order_cells(N, p->h_xyz.data(), M.h_morton);
     M.h_perm.resize(N);
@@ -634,6 +640,7 @@ static void mirror_build(wo_planet* p, const uint8_t* mask = nullptr) {
         int32_t a = 0, b = nl;
         for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_morton[i]; if (mask[r]) M.h_perm[b++] = r; else M.h_perm[a++] = r; }
         M.h_mask.assign(mask, mask + N);
+        p->mirrorMaskVersion = ownMask ? p->oceanVersion : -1;
     } else {
         std::memcpy(M.h_perm.data(), M.h_morton.data(), (size_t)N * 4);
         M.h_mask.clear();
@@ -719,6 +726,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     if (gIters < 0) gIters = 0;
     if (gStrength != gStrength) gStrength = 0;
     const int32_t total = std::max(hIters, std::max(tIters, gIters));
+    for (auto& b : p->stageBrackets) { p->eventPool.push_back(b.a); p->eventPool.push_back(b.b); }
+    p->stageBrackets.clear(); p->stageSeen.clear(); p->stagePending = false;
     p->stageTiming.clear(); p->erodeStats.clear();
     p->floodX.calls = 0; p->floodX.gathers = 0; p->floodX.globalFloods = 0; p->floodX.received = 0;       // per call (the stats of a step, not of the planet's life)
     if (total <= 0) return;
@@ -1536,6 +1545,7 @@ void wo_planet_destroy(wo_planet* p) {
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->h_word) { (void)hipHostFree(p->h_word); p->h_word = nullptr; }
     for (auto& pe : p->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto& b : p->stageBrackets) { (void)hipEventDestroy(b.a); (void)hipEventDestroy(b.b); }
     for (auto e : p->eventPool) (void)hipEventDestroy(e);
     if (p->evStart) (void)hipEventDestroy(p->evStart);
     if (p->evStop) (void)hipEventDestroy(p->evStop);
@@ -2007,8 +2017,24 @@ int wo_profile_report(wo_planet* p, int32_t cap, const char** names, double* tot
     return 0;
     WO_CATCH("wo_profile_report")
 }
+static void stage_timing_resolve(wo_planet* p) {
+    if (!p->stagePending) return;
+    p->stagePending = false;
+    WO_HIP(hipStreamSynchronize(p->ctx->stream));
+    std::map<std::string, double> acc;
+    for (auto& b : p->stageBrackets) {
+        float ms = 0; WO_HIP(hipEventElapsedTime(&ms, b.a, b.b));
+        acc[b.name] += ms;
+        p->eventPool.push_back(b.a); p->eventPool.push_back(b.b);
+    }
+    p->stageBrackets.clear();
+    p->stageTiming.clear();
+    for (auto& n : p->stageSeen) { const auto& c = n.second; p->stageTiming.push_back({n.first, acc[n.first] * (c.second > 0 ? (double)c.first / (double)c.second : 1.0)}); }
+    p->stageSeen.clear();
+}
 int wo_last_stage_timing(wo_planet* p, int32_t cap, const char** stages, double* ms, int32_t* count) {
     if (!p || !count) return 1;
+    try { stage_timing_resolve(p); } catch (const wo::HipError& e) { wo::set_error(std::string("wo_last_stage_timing: ") + e.msg); return 1; }
     int32_t n = 0;
     for (auto& st : p->stageTiming) { if (n >= cap) break; if (stages) stages[n] = st.first.c_str(); if (ms) ms[n] = st.second; ++n; }
     *count = n;
@@ -2219,6 +2245,8 @@ static void assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plat
     if (d_super) (void)hipFree(d_super);
     if (d_dl) (void)hipFree(d_dl);
     dT.release(); dTS.release(); cS.release(); cP.release();
+    for (auto& b : p->stageBrackets) { p->eventPool.push_back(b.a); p->eventPool.push_back(b.b); }
+    p->stageBrackets.clear(); p->stageSeen.clear(); p->stagePending = false;
     p->stageTiming = timing;
 }
 
