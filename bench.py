@@ -585,8 +585,8 @@ def make_comm(TP, pl, args, rank, world, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cells", type=int, default=10_000_000)
     ap.add_argument("--iters", type=int, default=200, help="composite iterations per step (200 = BASELINE config)")
     ap.add_argument("--cpu-iters", type=int, default=4)
