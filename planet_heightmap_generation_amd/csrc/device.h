@@ -89,7 +89,6 @@ struct Options {
     bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror
     bool sortLibrary = false;          // WO_SORT=hipcub           the library's radix sort instead of radix.hip
     bool noLandListCache = false;      // WO_NO_LAND_LIST_CACHE=1  the land lists are rebuilt by every erodeComposite call (default: kept while the ocean mask stays the same)
-    bool floodNoDirect = false;        // WO_FLOOD_STAGING=copy    the flood stage copies the land heights through the planet's pinned buffer (default: straight into / out of the flood's own array)
     bool basinBarrierKernel = false;   // WO_BASIN_KERNEL=barrier  k_solve_coop (one barrier per super-chunk) instead of k_solve_flowing
     bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr (=2: without the depth bookkeeping, which doubles the kernel's time)
     bool basinStatsNoDepth = false;
@@ -125,7 +124,6 @@ struct wo_planet {
     wo::hvec<uint8_t> h_ocean;
     bool h_ocean_valid = false;
     float* h_pinned = nullptr;          // N floats, pinned
-    float* floodRegistered = nullptr;   // the flood's compact height array while it is page-locked (flood_stage_land)
     int32_t* h_count = nullptr;         // pinned scalar(s) for round-count read-back
     float* d_redoE = nullptr; int32_t* d_pendingEver = nullptr; int64_t redoCalls = 0;   // erode_composite_checked: the field at entry, tasks any basin launch of the call left pending, calls that had to run again
     unsigned long long *h_word = nullptr, *d_word = nullptr; uint32_t wordSerial = 0;   // host-mapped {serial, value} word the host polls (planet.hip: publish_and_wait)

@@ -473,7 +473,7 @@ void FloodHooks::read() {
     replayPrefix = num("WO_FLOOD_PREFIX", 1) != 0;
     forcePrefixPermille = std::min(1000, std::max(0, num("WO_FLOOD_FORCE_PREFIX", 0)));
     timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
-    pin = num("WO_FLOOD_PIN", 1) != 0;
+    pin = num("WO_FLOOD_PIN", 0) != 0;
 }
 
 // land elevations into the compact arrays + the start state of pass 1 (:107-113); every flood call starts here: the hooks are read
@@ -1101,8 +1101,7 @@ bool flood_pass23_host(float* e, double carveStrength, FloodScratch& S, const st
             if (!(untouched && p0 >= 0 && h > (double)eL[p0] && h > (double)eL[p1])) return false;
         }
     }
-    if (S.landOrder && e == eL) {}                       // the caller handed eL itself over (pinned by the planet: the result is uploaded straight from it)
-    else if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
+    if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
     else parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;
@@ -1518,8 +1517,7 @@ bool flood_landmass_pipeline(float* e, double carveStrength, FloodScratch& S, Fl
         T.lap("round 2");
     }
     const int32_t* landCell = S.landCell.data();
-    if (S.landOrder && e == eL) {}                       // the caller handed eL itself over (pinned by the planet: the result is uploaded straight from it)
-    else if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
+    if (S.landOrder) parallel_ranges(L, [&](int64_t b, int64_t en, int) { std::memcpy(e + b, eL + b, sizeof(float) * (size_t)(en - b)); });
     else parallel_ranges(L, [&](int64_t b, int64_t en, int) { for (int64_t i = b; i < en; ++i) e[landCell[i]] = eL[i]; });
     T.lap("writeback");
     return true;

@@ -500,10 +500,6 @@ static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
     return ok;
 }
 
-// the flood's compact height array may be page-locked (flood_stage_land): it must not be while the tables — the array with them — are rebuilt
-static void flood_unregister(wo_planet* p) {
-    if (p->floodRegistered) { (void)hipHostUnregister(p->floodRegistered); p->floodRegistered = nullptr; }
-}
 static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     hipStream_t s = p->ctx->stream;
     const size_t bytes = (size_t)p->N * sizeof(float);
@@ -520,7 +516,7 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     lap("ocean mask");
     FloodScratch& S = p->flood;
     if (!S.staticValid || S.staticN != p->N)
-        { flood_unregister(p); flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S); }
+        flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S);
     lap("static");
     if (S.L == 0 && !p->floodX.on) return;       // (a share without land still takes part in the exchange)
     const bool hostOnly = p->floodX.on || !p->opt.floodDevice;
@@ -572,21 +568,11 @@ static void flood_stage_land(wo_planet* p, double carveStrength, FloodRun& R) {
         t0 = now;
     };
     if (timing) { WO_HIP(hipStreamSynchronize(s)); lap("drain gpu"); }
-    // The land heights go straight into the flood's own compact array and come straight back from it: it is page-locked here (again whenever the
-    // tables were rebuilt), so neither the copy into it nor the copy of the result out of it (1.1 ms of an 11 MB sweep per call) is made.
+    // The land heights travel through the planet's own hipHostMalloc'ed buffer (allocated once per planet, N floats).  Round 5 page-locked the flood's
+    // own array instead (hipHostRegister of a THP-advised heap block, 0.5 ms of a 312 ms step): user-pointer registrations of transparent-huge-page memory
+    // are invalidated whenever the kernel collapses or splits those pages, and a copy in flight at that moment faults — the SIGABRT under
+    // hipStreamSynchronize of the round-5 GPU suite.  Nothing in this library registers memory it did not get from hipHostMalloc.
     float* host = p->h_pinned;
-    {
-        float* eL = S.eL.data();
-        if (p->floodRegistered != eL) {
-            if (p->floodRegistered) { (void)hipHostUnregister(p->floodRegistered); p->floodRegistered = nullptr; }
-            // (only an array that has its pages to itself — hvec's 2 MB-aligned blocks, from 4 MB up: locking part of the general heap's pages, which other
-            // planets' small arrays share, is asking for trouble; small planets keep the copy through the planet's pinned buffer)
-            const size_t regBytes = S.eL.size() * sizeof(float);
-            if (!p->opt.floodNoDirect && regBytes >= ((size_t)4 << 20) && hipHostRegister(eL, regBytes, hipHostRegisterDefault) == hipSuccess) p->floodRegistered = eL;
-            else (void)hipGetLastError();
-        }
-        if (p->floodRegistered == eL) host = eL;
-    }
     WO_HIP(hipMemcpyAsync(host, p->d_e, bytes, hipMemcpyDeviceToHost, s));
     WO_HIP(hipStreamSynchronize(s));
     lap("D2H (land)");
@@ -771,7 +757,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 WO_HIP(hipMemcpyAsync(p->h_pinned, mir.on ? p->mirror.o_e : p->d_e, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, s));
                 WO_HIP(hipStreamSynchronize(s));
                 if (!p->flood.staticValid || p->flood.staticN != N)
-                    { flood_unregister(p); flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), p->flood); }
+                    flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), p->flood);
                 for (int k = 0; k < calls; ++k) {
                     const int rc = flood_host_passes_exchange(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, 0.5, p->flood, nullptr, p->floodX);
                     if (rc) throw HipError{"flood exchange: the host's exchange function failed (status " + std::to_string(rc) + ")"};
@@ -812,7 +798,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         // spatial patches for the patch-local solve: land cells in Morton order (shared with the host flood's layout)
         if (hIters > 0 && !p->h_xyz.empty() && !p->opt.noSolvePatch) {
             if (!p->flood.staticValid || p->flood.staticN != N)
-                { flood_unregister(p); flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood); }
+                flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood);
             if (p->patchVersion != p->flood.staticVersion || p->patchMirror != mir.on) {
                 p->patchMirror = mir.on;
                 if (mir.on) WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));   // ascending mirror id IS Morton order
@@ -1359,7 +1345,6 @@ Options Options::from_env() {
     o.layoutIndex = str("WO_LAYOUT") == "index";
     o.sortLibrary = str("WO_SORT") == "hipcub";
     o.noLandListCache = on("WO_NO_LAND_LIST_CACHE");
-    o.floodNoDirect = str("WO_FLOOD_STAGING") == "copy";
     o.basinBarrierKernel = str("WO_BASIN_KERNEL") == "barrier";
     o.basinStats = on("WO_BASIN_STATS"); o.basinStatsNoDepth = str("WO_BASIN_STATS") == "2";
     o.basinScramble = on("WO_BASIN_SCRAMBLE");
@@ -1540,7 +1525,6 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
     if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);
     if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);
-    if (p->floodRegistered) { (void)hipHostUnregister(p->floodRegistered); p->floodRegistered = nullptr; }
     if (p->h_pinned) (void)hipHostFree(p->h_pinned);
     if (p->h_count) (void)hipHostFree(p->h_count);
     if (p->h_word) { (void)hipHostFree(p->h_word); p->h_word = nullptr; }

@@ -42,7 +42,7 @@ struct FloodHooks {
     bool hasReplayStop = false; float replayStop = 0.0f;     // WO_FLOOD_REPLAY_STOP  the level at which the replay of the single heap stops
     bool replayPrefix = true;      // WO_FLOOD_PREFIX=0     the replay walks undecided landmasses from their seeds (not from their first contested tie group)
     int32_t forcePrefixPermille = 0;   // WO_FLOOD_FORCE_PREFIX  how much of the forced landmass's pops counts as its decided prefix
-    bool pin = true;               // WO_FLOOD_PIN=0        the walk of the largest landmass does not get an L3 of its own (flood_landmass_pipeline)
+    bool pin = false;              // WO_FLOOD_PIN=1        the walk of the largest landmass keeps its CPU and the other flood workers keep off its L3 (opt-in: the library touches no thread affinity unasked)
     bool timing = false;           // WO_FLOOD_TIMING       laps -> stderr
     void read();
 };

@@ -229,6 +229,7 @@ def test_full_size_properties(TP):
     pl.close()
 
 
+@pytest.mark.isolated
 def test_headline_size_properties(TP):
     """BASELINE config 3 size (10 M cells, the bench workload): size-independent properties — bit-deterministic run
     to run (two different schedules of the same dataflow: the launch-count prediction differs between the runs),
@@ -272,6 +273,7 @@ def test_headline_size_properties(TP):
         del os.environ["WO_NO_SOLVE_PATCH"]
 
 
+@pytest.mark.isolated
 def test_headline_size_against_oracle(TP, oracle):
     """BASELINE config 3 size (10 M cells) head to head with the CPU oracle on a bounded number of iterations (the
     oracle needs ~7 s per composite iteration here): warp + erodeComposite(3, 3, 1) + creep, bit for bit where no
@@ -504,6 +506,7 @@ def test_config2_verbatim_against_oracle(TP, oracle):
     pl.close()
 
 
+@pytest.mark.isolated
 def test_config3_checksum_of_the_benched_field(TP):
     """The field bench.py times (BASELINE config 3: 10 M cells, warp + erodeComposite(200,200,10) + creep) has the CRC of
     the ORACLE's result for the same inputs (tests/golden/crc_config3.json, made by oracle/ref_harness/make_crc_config3.py).
@@ -557,6 +560,7 @@ def _checksum_case(TP, key, cells, seed, iters, g):
     return stats
 
 
+@pytest.mark.isolated
 def test_config4_size_checksum_on_one_gpu(TP):
     """BASELINE config 4's planet (40 M cells, seed 1) on one GPU, 20 composite iterations (1 glacial): CRC == the oracle's.
     At this size both flood calls meet equal keys whose order matters (13 contested cells per step in round 2, which sent the
@@ -567,6 +571,7 @@ def test_config4_size_checksum_on_one_gpu(TP):
     assert stats["solve_basin_passes_with_leftovers"] == 0
 
 
+@pytest.mark.isolated
 def test_config4_full_length_checksum_on_one_gpu(TP):
     """BASELINE config 4's planet at its OWN iteration count: 40 M cells, 200 composite iterations (10 glacial), one GPU.  The oracle's
     CRC (53 minutes of one core, oracle/ref_harness/make_crc_config3.py 40000000 1 200) is the one bench.py's one-planet leg checks
@@ -576,6 +581,7 @@ def test_config4_full_length_checksum_on_one_gpu(TP):
     assert stats["flood_host_serial_pass1"] == 0 and stats["solve_basin_passes_with_leftovers"] == 0
 
 
+@pytest.mark.isolated
 def test_config4_decomposed_8_shares_checksum(TP):
     """BASELINE config 4 as its 8-rank plan: the 40 M-cell planet dealt to 8 landmass shares (one host thread, context and
     planet per share on this GPU), 20 composite iterations, the flood exchange between the shares.  Both flood calls meet
@@ -606,6 +612,7 @@ def test_config4_decomposed_8_shares_checksum(TP):
     assert int(zlib.crc32(merged.tobytes())) == gold["crc32"], "merged field differs from the oracle's"
 
 
+@pytest.mark.isolated
 def test_config4_two_processes_over_gloo(TP, tmp_path):
     """BASELINE config 4's planet (40 M cells, 20 iterations) as two PROCESSES sharing this GPU, the flood exchange and the merge over
     torch.distributed (gloo): the multi-process path at a size where flood calls ARE undecided (the thread form of the same plan:
@@ -648,6 +655,7 @@ def test_decomposed_shares_with_flood_exchange_small(TP, oracle):
     assert stats[0]["flood_exchange_calls"] == 2
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("seed", list(range(2, 17)))
 def test_config5_seeds_checksum(TP, seed):
     """BASELINE config 5 runs config 3's stack on other seeds: 10 M cells, seeds 2 .. 16, 20 composite iterations (1 glacial),
@@ -657,6 +665,7 @@ def test_config5_seeds_checksum(TP, seed):
     assert stats["flood_host_serial_pass1"] == 0
 
 
+@pytest.mark.isolated
 @pytest.mark.parametrize("seed", list(range(2, 16)))
 def test_config5_seeds_full_length_checksum(TP, seed):
     """Fourteen more planets of BASELINE config 5 at the full 200 iterations (10 glacial): CRC == the oracle's (10-30 minutes of one core each,
@@ -994,3 +1003,37 @@ def test_flood_stage_inside_the_mirror_copies_the_land_only(TP, oracle, monkeypa
         seen_land_only += log.count("D2H (land)")
     assert seen_land_only >= 3, seen_land_only
     pl.close()
+
+
+@pytest.mark.soak
+@pytest.mark.isolated
+@pytest.mark.timeout(1800)
+def test_soak_hundred_planets_in_one_process(TP):
+    """100 create / warp / erode / creep / download / destroy cycles of 10 M-cell planets in ONE process (round 5's GPU suite died with SIGABRT
+    in its 61st test, ~50 planets into one interpreter, under the download's hipStreamSynchronize): 50 different terrains, each twice, 50 cycles
+    apart — the second run of a seed must give the first run's bits (nothing of a destroyed planet leaks into a later one), the fields are finite,
+    and the process does not grow (host RSS after cycle 100 within 1 GB of cycle 20)."""
+    import zlib
+    import psutil
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(10_000_000, 0.75, 1)
+    me = psutil.Process()
+    crcs, rss = [], []
+    for k in range(100):
+        seed = 100 + k % 50
+        pl = TP.Planet(mesh, xyz, nd)
+        pl.synthetic_terrain(seed)
+        pl.warp_terrain_resident(seed, 0.75)
+        pl.ocean_from_elevation()
+        pl.erode_composite_resident(6, 3e-4, 0.5, 1.0, 6, 1.16, 0.015, 2, 0.5)      # both floods (iteration 0 and round(0.75 x 6)), 2 glacial steps
+        pl.apply_soil_creep_resident(3, 0.1125)
+        out = pl.download()
+        pl.close()
+        assert np.isfinite(out).all(), k
+        crcs.append(int(zlib.crc32(out.tobytes())))
+        rss.append(me.memory_info().rss)
+        if k >= 50:
+            assert crcs[k] == crcs[k - 50], (k, seed)
+    assert len(set(crcs[:50])) == 50
+    print(f"soak: 100 planets, rss after cycle 20 / 100: {rss[19] / 2**30:.2f} / {rss[99] / 2**30:.2f} GiB")
+    assert rss[99] - rss[19] < (1 << 30)
