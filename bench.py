@@ -673,8 +673,9 @@ def main():
         step = lambda: virt.step(seed, params)
     # BASELINE config 5 (N > 1, ensemble): "10 M cells x 64 random seeds, one planet per GPU" — rank r erodes the planets of seeds
     # 1 + r + k x N (k = 0, 1, ...: round-robin over the ranks, 64 seeds per job at most), one planet per timed step, cycling when the
-    # job has more steps than seeds.  Every planet is built, uploaded and run once BEFORE the timed region (mesh + mask-dependent
-    # tables: the one-time upload SURVEY 8(d) excludes); inside it a step is the resident stack on the next planet of the cycle.
+    # job has more steps than seeds.  Every planet is built and uploaded BEFORE the timed region (the one-time mesh upload SURVEY 8(d)
+    # excludes) and warmed on another terrain; inside the region a step is the resident stack on the next planet of the cycle, its
+    # terrain-dependent tables included the first time round.
     fleet, fleet_seeds = [pl], [seed]
     if world > 1 and not decomposed_mode and args.seeds_per_rank != 1:
         want = args.seeds_per_rank if args.seeds_per_rank > 0 else max(1, min(args.steps, 64 // world))
@@ -682,7 +683,6 @@ def main():
             sk = 1 + rank + k * world
             mk, xk, nk, tk = build_inputs(args.cells, sk)
             q = TP.Planet(mk, xk, nk, ctx=pl.ctx)
-            q.synthetic_terrain(sk); q.save_state()
             fleet.append(q); fleet_seeds.append(sk)
             t_mesh += tk
             del mk, xk, nk
@@ -692,14 +692,24 @@ def main():
             i = turn[0] % len(fleet); turn[0] += 1
             one_step(fleet[i], fleet_seeds[i], params)
     cold_ms = None
-    for w in range(max(args.warmup, len(fleet) if len(fleet) > 1 else 0)):      # every planet of the cycle once (its tables), at least --warmup steps
-        tc = time.perf_counter()
-        step()
-        if w == 0:
-            pl.sync()
-            cold_ms = (time.perf_counter() - tc) * 1e3       # first step: mask-dependent tables, scratch allocation, launch-count prediction
     if len(fleet) > 1:
-        turn[0] = 0
+        # Config 5's planets are NEW TERRAINS inside the timed region: what is excluded is what SURVEY 8(d) excludes — the mesh and its
+        # upload, and with it the planet's scratch allocations — so every planet is warmed on ANOTHER terrain (seed + 1000: other mask, other tables), then
+        # given its own; its first timed step builds the mask-dependent tables (land-first mirror, flood tables, land lists) like any new planet's would.
+        for i, (q, sk) in enumerate(zip(fleet, fleet_seeds)):
+            q.synthetic_terrain(sk + 1000); q.save_state()
+            tc = time.perf_counter()
+            one_step(q, sk + 1000, params); q.sync()
+            if i == 0:
+                cold_ms = (time.perf_counter() - tc) * 1e3
+            q.synthetic_terrain(sk); q.save_state(); q.sync()
+    else:
+        for w in range(args.warmup):
+            tc = time.perf_counter()
+            step()
+            if w == 0:
+                pl.sync()
+                cold_ms = (time.perf_counter() - tc) * 1e3       # first step: mask-dependent tables, scratch allocation, launch-count prediction
     barrier()
     t0 = time.perf_counter()
     pl.timer_start()
@@ -723,6 +733,22 @@ def main():
         seeds_run = sorted((e for lst in allr for e in lst), key=lambda e: e["seed"])
     for q in fleet[1:]:
         q.close()
+    # What a NEW planet costs on a resident mesh: the timed steps above re-run one terrain, whose mask-dependent tables (land-first
+    # mirror, flood tables, land lists, launch-count prediction) are cached after the first step.  Three other terrains on the same mesh, one step each,
+    # with those tables rebuilt inside the clock; then the benched terrain again (untimed) for the legs below.
+    new_terrain = None
+    if rank == 0 and world == 1 and not virt and not args.timed_only:
+        ms_new = []
+        for s2 in (seed + 101, seed + 102, seed + 103):
+            pl.synthetic_terrain(s2); pl.save_state(); pl.sync()
+            tn = time.perf_counter()
+            one_step(pl, s2, params); pl.sync()
+            ms_new.append((time.perf_counter() - tn) * 1e3)
+        pl.synthetic_terrain(seed); pl.save_state()
+        one_step(pl, seed, params); pl.sync()
+        new_terrain = dict(ms=[round(v, 2) for v in ms_new], mean_ms=sum(ms_new) / len(ms_new), value=N * max(params["hIters"], params["tIters"], params["gIters"]) / (sum(ms_new) / len(ms_new) / 1e3) / 1e6,
+                           note="one step each on three other synthetic terrains (seeds +101..+103) of the resident mesh: the terrain-dependent set-up (land-first mirror, flood tables, "
+                                "land lists) is rebuilt inside the clock; `value` is the warm figure (same terrain every step), cold_first_step_ms additionally holds the planet's scratch allocations")
     L = int(stats.get("land_cells", 0))
     iters = max(params["hIters"], params["tIters"], params["gIters"])
 
@@ -885,7 +911,8 @@ def main():
             "decomposition": dec.summary() if dec else (virt.summary(unpart_ms) if virt else None),
             "value_with_transfers": transfers["value_with_transfers"] if transfers else None, "with_transfers": transfers, "one_planet": one_planet, "relaxed_mode": relaxed,
             "roofline": roofline, "cpu_baseline": cpu, "ensemble_in_flight": ensemble,
-            "parity": crc, "ensemble_seeds": seeds_run, "cold_first_step_ms": cold_ms, "host_threads": host_threads,
+            "parity": crc, "ensemble_seeds": seeds_run, "cold_first_step_ms": cold_ms, "new_terrain_step_ms": new_terrain["mean_ms"] if new_terrain else None, "new_terrain": new_terrain,
+            "ensemble_steps_are_new_terrain": (len(fleet_seeds) > 1 and args.steps <= len(fleet_seeds)) if world > 1 and not decomposed_mode else None, "host_threads": host_threads,
             "hbm_d2d_copy_GBs_measured": d2d_GBs,
             "stage_ms_last_step": {k: round(v, 2) for k, v in stages.items()},
             "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "host_numa_node": numa_node, "hip_event_ms_per_step": ev_ms / args.steps,

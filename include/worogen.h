@@ -204,11 +204,16 @@ int wo_planet_exchange_neighbors(wo_planet* planet, wo_comm* comm, int32_t nToPr
  *   fn(user, 1, float field[numRegions], numRegions)   in: the rank's own land cells hold their heights; out: every land cell does
  *   fn(user, 2, float land[n], n)          this rank flooded: it SENDS land (the planet's land cells in ascending id) to every rank
  *   fn(user, 3, float land[n], n)          every other rank: land := what the one rank in phase 2 sent
- * fn returns 0 on success; a non-zero status fails the erodeComposite call.  r_isOcean_true: the planet's real mask (the
+ *   fn(user, -1, int32_t proto[1], 1)      handshake, once, inside wo_planet_set_flood_exchange: proto[0] arrives as
+ *                                          WO_FLOOD_EXCHANGE_PROTOCOL; a callback that implements exactly these phases sets
+ *                                          proto[0] = -proto[0] and returns 0 (anything else: set_flood_exchange fails)
+ * fn returns 0 on success; a non-zero status fails the erodeComposite call.  fn MUST return non-zero for a phase it does
+ * not implement (never guess from "phase != 0").  r_isOcean_true: the planet's real mask (the
  * resident mask is the rank's: other ranks' landmasses are ocean).  fn == NULL switches the exchange off.
  * wo_planet_set_flood_exchange_comm: the same over RCCL — counts[j] land cells of rank j, their region ids concatenated in
  * rank order in cellsByRank (ncclAllReduce of the flag, ncclAllGather of the heights, ncclBroadcast of the flooded heights).
  * The comm must outlive the exchange: switch it off (fn == NULL) or destroy the planet before wo_comm_destroy. */
+#define WO_FLOOD_EXCHANGE_PROTOCOL 2
 typedef int (*wo_flood_exchange_fn)(void* user, int32_t phase, void* buf, int64_t n);
 int wo_planet_set_flood_exchange(wo_planet* planet, const uint8_t* r_isOcean_true, wo_flood_exchange_fn fn, void* user);
 int wo_planet_set_flood_exchange_comm(wo_planet* planet, const uint8_t* r_isOcean_true, wo_comm* comm, const int32_t* counts,

@@ -95,6 +95,7 @@ SIGNATURES = {
 
 # wo_flood_exchange_fn: int fn(void* user, int32_t phase, void* buf, int64_t n)
 FLOOD_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64)
+FLOOD_EXCHANGE_PROTOCOL = 2          # include/worogen.h: WO_FLOOD_EXCHANGE_PROTOCOL (the handshake of phase -1)
 
 _lib = None
 MISSING: list[str] = []

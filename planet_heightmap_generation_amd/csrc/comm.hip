@@ -120,6 +120,13 @@ void flood_link_free(void* v) {
 }
 int flood_link_exchange(void* user, int32_t phase, void* buf, int64_t n) {
     FloodLink* k = (FloodLink*)user;
+    if (phase == -1) {                                   // handshake (include/worogen.h): this link implements protocol 2 (phases 0-3)
+        int32_t* proto = (int32_t*)buf;
+        if (*proto != WO_FLOOD_EXCHANGE_PROTOCOL) return 1;
+        *proto = -*proto;
+        return 0;
+    }
+    if (phase < 0 || phase > 3) { wo::set_error("flood exchange: unknown phase"); return 1; }
     wo_comm* c = k->comm;
     if (!c || !c->comm) { wo::set_error("flood exchange: the communicator is closed"); return 1; }
     hipStream_t s = k->planet->ctx->stream;

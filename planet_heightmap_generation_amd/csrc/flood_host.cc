@@ -28,6 +28,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <stdexcept>
 #include <vector>
 
 #include "host_util.h"
@@ -1596,8 +1597,11 @@ int flood_host_passes_exchange(int32_t N, const int32_t* off, const int32_t* adj
         X.ownPos.resize((size_t)S.L);
         const uint8_t* toc = X.trueOcean.data();
         const int32_t* li = S.landIndex.data();
-        int32_t cnt = 0, lowest = -1;
-        for (int32_t r = 0; r < N; ++r) if (!toc[r]) { if (li[r] >= 0) { X.ownPos[(size_t)li[r]] = cnt; if (lowest < 0) lowest = r; } ++cnt; }
+        int32_t cnt = 0, lowest = -1, placed = 0;
+        for (int32_t r = 0; r < N; ++r) if (!toc[r]) { if (li[r] >= 0) { X.ownPos[(size_t)li[r]] = cnt; ++placed; if (lowest < 0) lowest = r; } ++cnt; }
+        // every land cell of the resident (this rank's) mask must be land in the planet's true mask: a cell that is not has no place among the planet's
+        // land heights (its ownPos entry would stay unset) and the election below has no bid for a rank without one
+        if (placed != S.L) throw std::runtime_error("flood exchange: the resident ocean mask has land cells that the planet's true mask (wo_planet_set_flood_exchange) calls ocean");
         X.landTotal = cnt; X.minOwnCell = lowest; X.posVersion = S.staticVersion;
     }
     const int32_t bid = mine ? INT32_MAX - X.minOwnCell : 0;

@@ -1586,6 +1586,16 @@ int wo_planet_set_flood_exchange(wo_planet* p, const uint8_t* trueOcean, wo_floo
         if (!trueOcean) { set_error("wo_planet_set_flood_exchange: the planet's true ocean mask is required"); return 1; }
         const bool same = X.trueOcean.size() == (size_t)p->N && std::memcmp(X.trueOcean.data(), trueOcean, (size_t)p->N) == 0;
         if (!same) { X.trueOcean.assign(trueOcean, trueOcean + p->N); X.global.staticValid = false; }
+        // protocol handshake (phase -1): the callback must know THIS protocol (phases 0-3; round 4's had 0-1 only, and a callback written for it that
+        // treats every phase != 0 as the all-gather would gather over the wrong buffer on phases 2 / 3 and report success)
+        int32_t hello = WO_FLOOD_EXCHANGE_PROTOCOL;
+        const int hrc = fn(user, -1, &hello, 1);
+        if (hrc != 0 || hello != -WO_FLOOD_EXCHANGE_PROTOCOL) {
+            X.on = false; X.fn = nullptr; X.user = nullptr;
+            set_error("wo_planet_set_flood_exchange: the callback did not acknowledge exchange protocol " + std::to_string(WO_FLOOD_EXCHANGE_PROTOCOL) +
+                      " (phase -1: negate buf[0] and return 0; return non-zero for any phase it does not implement)");
+            return 1;
+        }
         X.fn = fn; X.user = user; X.on = true;
         X.calls = X.gathers = X.globalFloods = X.received = 0; X.posVersion = -1; X.landTotal = -1;
         return 0;

@@ -211,15 +211,22 @@ class Planet:
 
         def _cb(_user, phase, buf, n):
             try:
-                if phase == 0:
+                if phase == -1:             # handshake: this callback implements protocol 2 (phases 0-3) and nothing else
+                    proto = C.cast(buf, C.POINTER(C.c_int32))
+                    if int(proto[0]) != capi.FLOOD_EXCHANGE_PROTOCOL:
+                        return 1
+                    proto[0] = -int(proto[0])
+                elif phase == 0:
                     flag = C.cast(buf, C.POINTER(C.c_int32))
                     flag[0] = int(exchange.allreduce_max(int(flag[0])))
                 elif phase == 1:
                     field = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(int(n),))
                     exchange.allgather(field)
-                else:                       # 2: this rank flooded the whole planet and sends the land heights; 3: it receives them
+                elif phase in (2, 3):       # 2: this rank flooded the whole planet and sends the land heights; 3: it receives them
                     land = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_float)), shape=(int(n),))
                     exchange.broadcast(land, phase == 2)
+                else:
+                    return 1                # a phase this callback does not know
                 return 0
             except Exception as e:          # never let an exception cross the C boundary
                 errors.append(e)

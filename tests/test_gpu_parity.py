@@ -706,6 +706,45 @@ def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells
         assert np.array_equal(out, ref), (r, int((out != ref).sum()))
 
 
+def test_flood_exchange_protocol_handshake_and_mask_check(TP):
+    """include/worogen.h, wo_planet_set_flood_exchange: (i) a callback that does not acknowledge the protocol (phase -1) — e.g. one written for
+    the two-phase protocol of round 4 that answers every phase != 0 with its all-gather and returns 0 — is refused when it is set, not at the
+    first undecided flood; (ii) a resident mask with land where the planet's true mask has ocean fails the erodeComposite call instead of reading
+    unset positions."""
+    import ctypes as C
+    from planet_heightmap_generation_amd import capi
+    from planet_heightmap_generation_amd import sphere_mesh as S
+    mesh, xyz, nd = S.build_sphere(20000, 0.75, 1)
+    pl = TP.Planet(mesh, xyz, nd)
+    pl.synthetic_terrain(1)
+    e, oc = pl.download(), pl.download_ocean()
+    seen = []
+
+    def old_style(_user, phase, buf, n):          # knows phases 0 and "the other one"
+        seen.append(int(phase))
+        return 0
+    cb = capi.FLOOD_EXCHANGE_FN(old_style)
+    rc = capi.lib().wo_planet_set_flood_exchange(pl.handle, capi.ptr(oc), cb, None)
+    assert rc != 0 and seen == [-1]
+    assert "protocol" in capi.lib().wo_last_error().decode()
+
+    class Alone:                                   # a one-rank exchange: nothing to pool
+        def allreduce_max(self, v): return v
+        def allgather(self, field): pass
+        def broadcast(self, land, sender): pass
+    true_oc = oc.copy()
+    true_oc[np.flatnonzero(oc == 0)[:7]] = 1       # seven cells the resident mask calls land, the "true" mask ocean
+    pl.set_flood_exchange(true_oc, Alone())
+    with pytest.raises(Exception, match="true mask"):
+        pl.erode_composite_resident(2, 3e-4, 0.5, 1.0, 2, 1.16, 0.015, 0, 0.0)
+    pl.set_flood_exchange(None)
+    pl.upload(e, oc)
+    pl.set_flood_exchange(oc, Alone())
+    pl.erode_composite_resident(2, 3e-4, 0.5, 1.0, 2, 1.16, 0.015, 0, 0.0)
+    assert pl.last_erode_stats()["flood_exchange_calls"] == 2
+    pl.close()
+
+
 def test_exchange_behind_the_c_abi_single_rank(TP):
     """wo_comm_* / wo_planet_exchange_*: the RCCL communicator and both exchange shapes on a real device.  RCCL refuses two
     ranks on one GPU, so a one-GPU box can only run the one-rank communicator: the all-gather then returns the rank's own
