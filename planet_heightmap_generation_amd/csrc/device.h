@@ -88,7 +88,6 @@ namespace wo {
 struct Options {
     bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror
     bool sortLibrary = false;          // WO_SORT=hipcub           the library's radix sort instead of radix.hip
-    bool sortSerial = false;           // WO_SORT=serial           the elevation sort on the main stream before the receivers pass (default: on the side stream beside it)
     bool noLandListCache = false;      // WO_NO_LAND_LIST_CACHE=1  the land lists are rebuilt by every erodeComposite call (default: kept while the ocean mask stays the same)
     bool basinBarrierKernel = false;   // WO_BASIN_KERNEL=barrier  k_solve_coop (one barrier per super-chunk) instead of k_solve_flowing
     bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr (=2: without the depth bookkeeping, which doubles the kernel's time)
@@ -149,7 +148,7 @@ struct wo_planet {
     bool landIdentity = false;          // erode_composite under the land-first mirror: landIdx[i] == i
     int64_t floodPrefixMirror = -1, floodPrefixStatic = -1;      // (mirror version, flood static version) for which the mirror's first L ids were checked to be the flood's land order
     bool floodPrefixOk = false;
-    int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_rankAlt = nullptr, *d_target = nullptr;
+    int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
     // the initial land list (ascending r, js/terrain-post.js:384-390) and the index-order list are functions of the ocean mask alone: kept while it stays
     int32_t* d_landInit = nullptr; int64_t oceanVersion = 0, landListsOcean = -1; bool landListsMirror = false; int32_t landListsL = -1;
     uint32_t* d_keys[2] = {nullptr, nullptr};
@@ -166,7 +165,7 @@ struct wo_planet {
     int32_t *d_iceTarget = nullptr, *d_arank = nullptr;
     uint8_t* d_iceUp = nullptr;
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
-    hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr, evTop = nullptr, evSorted = nullptr; bool onSide = false;
+    hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; bool onSide = false;
     hipStream_t side2 = nullptr; hipEvent_t evJoin2 = nullptr; uint8_t* d_lateDonor = nullptr;        // third stream: the solve's event lists beside the flow accumulation and the layout; late-donor flags of the receivers pass   // second stream of the planet: the basin layout runs beside the flow accumulation (planet.hip)
     uint32_t* d_basinKey = nullptr; int32_t* d_basinVals[2] = {nullptr, nullptr}; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; uint8_t* d_basinLong = nullptr; int64_t basinLaunches = 0; wo::Affine* d_affine[2] = {nullptr, nullptr};   /* relaxed mode: the affine recurrence, ping-pong */ int64_t solvePassSerial = 0;   /* unchecked basin passes so far (their output tag: planet.hip, passTag) */   // basin.hip: component roots (Morton slot space), group-major store order of the pass
     int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
@@ -246,14 +245,14 @@ inline void launch_shmem(wo_planet* p, int fam, void (*kernel)(KArgs...), int gr
 }
 
 // sort.hip: stable descending sort of the land list by current elevation + rank scatter
-void sort_land_by_elevation(wo_planet* p, bool beside = false);
+void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
 void rank_from_land(wo_planet* p);
 void sort_by_level(wo_planet* p);
 // radix.hip: the in-tree stable radix sort (scratch: radix_scratch_words(nMax) u32, zero before the first use; flip: call parity kept by the caller)
 size_t radix_scratch_words(int32_t nMax);
 int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t* const vals[2], int32_t n, int beginBit, int endBit, int32_t* posOut,
-                     uint32_t* scratch, int32_t nMax, int& flip, int32_t* posOut2 = nullptr);
+                     uint32_t* scratch, int32_t nMax, int& flip);
 uint32_t* radix_scratch(wo_planet* p, int which);      // 0: elevation sort, 1: basin sort (allocated and cleared on first use)
 void select_active_by_rank(wo_planet* p, const int32_t* arank, int32_t* out, int32_t* outCount);   // carve tasks in landCells order
 // basin.hip: group-major store order of the solve (d_basinSlot, sorted group keys in d_keys[1]) and the one-launch solve over it

@@ -99,7 +99,6 @@ struct Fields {
     const int32_t* landIdx;    // land cells in ascending id (the order of the index-order passes over land) [L]
     int32_t xcdTileL;          // blocks per XCD tile for passes over the land list
     int32_t* rank;             // rank[c] = index of c in land, -1 for ocean [N]
-    const int32_t* rankOld;    // nullptr, or: `rank` is being written by the elevation sort that runs BESIDE this pass (planet.hip) and this is the order before it [N]
     int32_t* target;           // drainTarget [N]
     TargetRank* tr;            // {target, rank} written by the receivers pass [N] (ocean: {-1, -1})
     float* cellDist;           // [N]
@@ -358,20 +357,13 @@ WO_HD inline int32_t receiver_cell_t(const Fields& F, int32_t r, Elev elev) {
         }
     }
     if (F.target) F.target[r] = bestNb;          // (the device passes read the target out of tr[]: Fields::target is nullptr there)
-    if (F.rankOld) reinterpret_cast<int32_t*>(F.tr + r)[0] = bestNb;         // the sort running beside this pass writes the .rank halves (radix.hip: posOut2)
-    else { TargetRank v; v.target = bestNb; v.rank = F.rank[r]; F.tr[r] = v; }
+    { TargetRank v; v.target = bestNb; v.rank = F.rank[r]; F.tr[r] = v; }
     if (bestNb >= 0) { const float d = F.dist[bestJ]; F.cellDist[r] = (d == 0.0f || d != d) ? (float)1e-6 : d; }
     return bestNb;
 }
 
 WO_HD inline int32_t receiver_cell(const Fields& F, int32_t r) { return receiver_cell_t(F, r, [&](int32_t c) { return F.e[c]; }); }
 
-// "r is ranked before t" in the order the elevation sort is producing beside this pass: the stable sort by desc_key of the previous order compares
-// {key, previous rank} (sort.hip); er / et: the two heights.  The previous ranks are only read when the keys tie.
-WO_HD inline bool ranked_before_after_sort(const Fields& F, int32_t r, float er, int32_t t, float et) {
-    const uint32_t kr = desc_key(er), kt = desc_key(et);
-    return kr < kt || (kr == kt && F.rankOld[r] < F.rankOld[t]);
-}
 // Flow (js/terrain-post.js:604-611).  fwd edge: receiver is land and ranked after the donor.
 WO_HD inline int32_t flow_forward_target(const Fields& F, int32_t r) {
     const int32_t t = F.tr[r].target;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
     WO_XCD_LAND(i, r) {
         const int32_t t = receiver_cell_t(F, r, E);
         int32_t j = -1; const uint32_t a = 1;
-        if (t >= 0 && !F.ocean[t] && (F.rankOld ? ranked_before_after_sort(F, r, E(r), t, E(t)) : F.rank[r] < F.rank[t])) j = t;      // flow_forward_target
+        if (t >= 0 && !F.ocean[t] && F.rank[r] < F.rank[t]) j = t;      // flow_forward_target
         if (F.accA) F.accA[r] = a;                           // (the pointer doubling's accumulator: nullptr on the default route, where k_flow_climb retires every cell)
         F.jumpA[r] = j; F.accCnt[r] = 1ull;
         if (j >= 0 && donorCnt) atomicAdd(&donorCnt[j], 1);  // donorCnt is all zero on entry (k_flow_final leaves it so); nullptr: the tile route counts a cell's donors itself (k_flow_tiles)

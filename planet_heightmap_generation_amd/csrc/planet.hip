@@ -57,7 +57,7 @@ static void ensure_scratch(wo_planet* p) {
     const size_t N = (size_t)p->N;
     p->d_landIdx = dalloc<int32_t>(N); p->d_land[0] = dalloc<int32_t>(N); p->d_land[1] = dalloc<int32_t>(N);
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
-    p->d_rank = dalloc<int32_t>(N); p->d_rankAlt = dalloc<int32_t>(N);
+    p->d_rank = dalloc<int32_t>(N);
     p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); WO_HIP(hipMemset(p->d_out, 0, N * sizeof(SolveOut)));   /* tags of the unchecked basin passes count up from here: no stale tag may look like a coming one */ p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_ev = dalloc<EventList>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
     p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_accCnt = dalloc<unsigned long long>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
@@ -712,18 +712,6 @@ struct MirrorScope {
     ~MirrorScope() { if (on) { point_at_planet(); p->mirror.active = false; } }      // error path: pointers only, the planet's field is what it was at the last suspend
 };
 
-// The planet's side stream (the basin layout beside the flow accumulation, the sort beside the receivers pass).
-static void ensure_side_stream(wo_planet* p) {
-    if (p->side) return;
-    // the side chain of short launches is the longer of the two: at equal priority its workgroups queue behind the thousands of
-    // the flow kernels' (a 22 us scatter pass took 108 us beside k_flow_final), so the side stream gets the highest priority
-    int prLeast = 0, prGreatest = 0;
-    WO_HIP(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
-    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prGreatest));
-    WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
-    WO_HIP(hipEventCreateWithFlags(&p->evTop, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evSorted, hipEventDisableTiming));
-}
-
 // erodeComposite on the resident field (js/terrain-post.js:369-707)
 // Thrown by erode_composite when a basin-solve launch whose result was not checked on the spot turns out to have left tasks pending:
 // the caller restores the field and runs the call again with the check after every pass (erode_composite_checked).
@@ -815,7 +803,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         WO_HIP(hipStreamSynchronize(s));       // h_pinned is reused by the flood stage
         p->landCur = 0;
         launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
-        launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rankAlt, N);      // (ocean cells: -1 in both rank arrays; the sort beside the receivers pass alternates between them)
         rank_from_land(p);      // thermal-only runs never sort: landCells stays in ascending-r order
         launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_level, 1, N);   // no level history yet: everything in round 1
         // spatial patches for the patch-local solve: land cells in Morton order (shared with the host flood's layout)
@@ -905,11 +892,8 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const Options& O = p->opt;
     const bool graphRoute = O.graphs && !p->profiling && !checkEveryPass && basinSolve && p->patchVersion >= 0 && O.flowClimbCap == 0x7fffffff && !O.flowEventsStream &&
                             !O.noEventLists && !O.basinStats && !O.sortLibrary && O.relaxedSortEvery <= 1 && p->maxDeg <= 16 && total > 16;
-    int64_t graphReplays = 0, sortsBeside = 0;
+    int64_t graphReplays = 0;
     bool sortAfterFlood = false;
-    // the sort beside the receivers pass (below): on the default route only — its forward-edge test lives in k_receivers_flow_init
-    const bool sortBesideOk = !O.sortSerial && !O.sortLibrary && !graphRoute && basinSolve && O.flowClimbCap == 0x7fffffff && !O.flowClimbOnly && !O.flowEventsStream &&
-                              !O.noEventLists && O.relaxedSortEvery <= 1 && !O.relaxedFull && p->landIdentity;
     for (int32_t iter = 0; iter < total; ++iter) {
         clk.on = true;
         if (!midDone && iter >= midIter) { midDone = true; flood(0.85); sortAfterFlood = true; }
@@ -933,22 +917,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         const bool relaxedFull = p->opt.relaxedFull;           // RELAXED MODE, not parity (kernels_impl.h): one sort per flood, affine solve, Jacobi carve
         const bool sortNow = relaxedFull ? (iter == 0 || sortAfterFlood) : (p->opt.relaxedSortEvery <= 1 || iter % p->opt.relaxedSortEvery == 0);
         if ((gNow || hNow) && sortNow) sortAfterFlood = false;
-        // The sort of a hydraulic iteration runs on the planet's side stream BESIDE the receivers pass and the flow accumulation: neither needs the new order —
-        // "is r ranked before its receiver t?" is {key(r), old rank(r)} < {key(t), old rank(t)}, the stable sort's own comparison, and the flow accumulation
-        // works on the forward edges that test leaves — so ~140 us of sort leave the iteration's critical chain; k_flow_final (event lists by rank) waits for the
-        // sort, the basin layout follows it on the side stream.  Not in a glacial iteration (the glacial step walks the new order first).
-        const bool sortBeside = sortBesideOk && hNow && !gNow && sortNow && !relaxedFull && !capturing && p->patchVersion >= 0;
-        if (sortBeside) {
-            ensure_side_stream(p);
-            clk.count_only("sort");
-            WO_HIP(hipEventRecord(p->evTop, s));
-            WO_HIP(hipStreamWaitEvent(p->side, p->evTop, 0));
-            p->onSide = true;
-            try { sort_land_by_elevation(p, true); } catch (...) { p->onSide = false; throw; }
-            p->onSide = false;
-            WO_HIP(hipEventRecord(p->evSorted, p->side));
-            ++sorts; ++sortsBeside;
-        } else
         if ((gNow || hNow) && sortNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
 
         if (gNow) {
@@ -1072,7 +1040,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (gNow && sortNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             F.solveK = K; F.solveM = m; F.solveDt = dt;
-            F.rankOld = sortBeside ? p->d_rankAlt : nullptr;          // (after the swap inside sort_land_by_elevation: the ranks BEFORE the sort that runs beside this step)
             const bool basin = basinSolve && p->patchVersion >= 0 && !relaxedFull;
             // the receivers pass also leaves the start state of the layout's component search
             const bool basinJFromReceivers = basin;
@@ -1117,7 +1084,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             // latency-bound launches that leave most of the chip idle: the layout runs on the planet's side stream beside the flow
             // accumulation and the solve's setup waits for both (WO_BASIN_OVERLAP=0: one after the other on the main stream).
             if (basin && basinOverlap) {
-                ensure_side_stream(p);
+                if (!p->side) {
+                    // the layout's chain of short launches is the longer of the two: at equal priority its workgroups queue behind the thousands of
+                    // the flow kernels' (a 22 us scatter pass took 108 us beside k_flow_final), so the side stream gets the highest priority
+                    int prLeast = 0, prGreatest = 0;
+                    WO_HIP(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+                    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prGreatest));
+                    WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
+                }
                 // two-level flow accumulation: its first kernel also shortens the layout's start state inside every tile (k_flow_tiles<false>:
                 // J[c] <- an ancestor at most a tile away), so the layout's component search starts after it, from chains of tiles instead of cells
                 const bool tilesFeedLayout = flowTiles && basinJFromReceivers && slotIdentity;
@@ -1186,7 +1160,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                                (const int32_t*)p->d_nj, out, outC, zeroC);
                     }, &flowCountHint);
             }
-            if (sortBeside) WO_HIP(hipStreamWaitEvent(s, p->evSorted, 0));      // the event lists are ordered by the NEW ranks
             {
                 Fields Ff = F;
                 if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
@@ -1282,7 +1255,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const bool mirrored = mir.on;
     if (mir.on) { clk.begin("setup"); mir.finish(); clk.end(); }
     clk.finish();
-    p->erodeStats = {{"land_cells", (double)L}, {"mirror_layout", mirrored ? 1.0 : 0.0}, {"iterations", (double)total}, {"sorts", (double)sorts}, {"sorts_beside_receivers", (double)sortsBeside},
+    p->erodeStats = {{"land_cells", (double)L}, {"mirror_layout", mirrored ? 1.0 : 0.0}, {"iterations", (double)total}, {"sorts", (double)sorts},
                      {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
                      {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
@@ -1381,7 +1354,6 @@ Options Options::from_env() {
     Options o;
     o.layoutIndex = str("WO_LAYOUT") == "index";
     o.sortLibrary = str("WO_SORT") == "hipcub";
-    o.sortSerial = str("WO_SORT") == "serial";
     o.noLandListCache = on("WO_NO_LAND_LIST_CACHE");
     o.basinBarrierKernel = str("WO_BASIN_KERNEL") == "barrier";
     o.basinStats = on("WO_BASIN_STATS"); o.basinStatsNoDepth = str("WO_BASIN_STATS") == "2";
@@ -1549,15 +1521,13 @@ void wo_planet_destroy(wo_planet* p) {
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); p->side = nullptr; }
     if (p->evFork) { (void)hipEventDestroy(p->evFork); p->evFork = nullptr; }
     if (p->evJoin) { (void)hipEventDestroy(p->evJoin); p->evJoin = nullptr; }
-    if (p->evTop) { (void)hipEventDestroy(p->evTop); p->evTop = nullptr; }
-    if (p->evSorted) { (void)hipEventDestroy(p->evSorted); p->evSorted = nullptr; }
     if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); p->side2 = nullptr; }
     if (p->evJoin2) { (void)hipEventDestroy(p->evJoin2); p->evJoin2 = nullptr; }
     dfree(p->d_lateDonor);
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     if (p->d_oceanKnown) { (void)hipFree(p->d_oceanKnown); p->d_oceanKnown = nullptr; } if (p->d_maskDiff) { (void)hipFree(p->d_maskDiff); p->d_maskDiff = nullptr; }
-    dfree(p->d_landInit); dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_rankAlt); dfree(p->d_target);
+    dfree(p->d_landInit); dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
     dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_affine[0]); dfree(p->d_affine[1]); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);

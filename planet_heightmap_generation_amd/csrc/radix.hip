@@ -53,12 +53,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_count(const uint32_t* __restr
     if (c) atomicAdd(&groupTot[(size_t)(tile / RS_GROUP) * RS_DIGITS + threadIdx.x], c);
 }
 
-// posOut (may be null): posOut[value] = destination, written by the last pass; posOut2 (may be null): the same number into the odd words of an array of
-// 8-byte {target, rank} records
+// posOut (may be null): posOut[value] = destination, written by the last pass
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
                                                           int32_t* __restrict__ valsOut, int32_t n, int shift, const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ groupTot, int32_t groups, uint32_t* clearNext, int32_t* __restrict__ posOut,
-                                                          int32_t* __restrict__ posOut2) {
+                                                          const uint32_t* __restrict__ groupTot, int32_t groups, uint32_t* clearNext, int32_t* __restrict__ posOut) {
     __shared__ uint32_t s_cnt[RS_WAVES][RS_DIGITS];       // per wave: pairs with the digit (running while the wave ranks its keys), then the wave's base inside the digit
     __shared__ uint32_t s_off[RS_DIGITS];                 // destination of the pair at tile position q with this digit: s_off[digit] + q
     __shared__ uint32_t s_start[RS_DIGITS];               // first tile position of the digit
@@ -173,7 +171,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t* __res
         keysOut[dst] = k;
         valsOut[dst] = v;
         if (posOut) posOut[v] = (int32_t)dst;
-        if (posOut2) posOut2[2 * (size_t)v + 1] = (int32_t)dst;          // the .rank half of tr[v] (erode_ops.h: TargetRank), see sort_land_by_elevation
     }
 }
 }  // namespace
@@ -189,7 +186,7 @@ size_t radix_scratch_words(int32_t nMax) { return (size_t)2 * rs_groups(nMax) * 
 // before the first call (afterwards every pass clears the group totals the next pass adds into); flip: parity of the passes run so far
 // on this scratch, kept by the caller.
 int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t* const vals[2], int32_t n, int beginBit, int endBit, int32_t* posOut,
-                     uint32_t* scratch, int32_t nMax, int& flip, int32_t* posOut2) {
+                     uint32_t* scratch, int32_t nMax, int& flip) {
     const int passes = (endBit - beginBit + 7) / 8;
     if (passes <= 0 || n <= 0) return 0;
     // every pass clears the group totals the NEXT pass adds into, up to this sort's group count: with an even number of passes per
@@ -215,8 +212,7 @@ int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t*
         uint32_t* gtOther = scratch + (size_t)((flip + 1) & 1) * gtWords;
         bracketed([&] { hipLaunchKernelGGL(k_rs_count, dim3(tiles), dim3(RS_THREADS), 0, s, (const uint32_t*)keys[cur], n, beginBit + 8 * q, counts, gt); });
         bracketed([&] { hipLaunchKernelGGL(k_rs_scatter, dim3(tiles), dim3(RS_THREADS), 0, s, (const uint32_t*)keys[cur], (const int32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n,
-                           beginBit + 8 * q, (const uint32_t*)counts, (const uint32_t*)gt, (int32_t)groups, gtOther, (q == passes - 1) ? posOut : (int32_t*)nullptr,
-                           (q == passes - 1) ? posOut2 : (int32_t*)nullptr); });
+                           beginBit + 8 * q, (const uint32_t*)counts, (const uint32_t*)gt, (int32_t)groups, gtOther, (q == passes - 1) ? posOut : (int32_t*)nullptr); });
         cur ^= 1;
     }
     WO_HIP(hipGetLastError());

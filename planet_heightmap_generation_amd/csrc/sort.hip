@@ -141,10 +141,7 @@ size_t sort_temp_bytes(int32_t n) {
     return std::max(bytes, std::max(bytes2, bytes3));
 }
 
-// beside (planet.hip: the sort of a hydraulic iteration on the planet's side stream, beside the receivers pass and the flow accumulation): the new ranks go to
-// the planet's OTHER rank array, which becomes d_rank — the receivers pass running beside this sort compares cells by {key, OLD rank}, which is this sort's own
-// order — and into the .rank halves of tr[] (the receivers pass writes only the .target halves then).
-void sort_land_by_elevation(wo_planet* p, bool beside) {
+void sort_land_by_elevation(wo_planet* p) {
     const int32_t L = p->L;
     const int cur = p->landCur;
     // (measured in round 4: the keys made inside the first counting pass of the in-tree sort instead of by a launch of their own — sort stage 34.6 ms
@@ -160,10 +157,7 @@ void sort_land_by_elevation(wo_planet* p, bool beside) {
     if (!library) {
         uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
         int32_t* const vb[2] = {p->d_land[cur], p->d_land[cur ^ 1]};
-        if (beside && !p->d_rankAlt) throw HipError{"sort_land_by_elevation: no second rank array"};
-        const int r = radix_sort_pairs(p, FAM_SORT_RADIX, kb, vb, L, 0, 32, beside ? p->d_rankAlt : p->d_rank, radix_scratch(p, 0), p->N, p->rsFlip[0],
-                                       beside ? reinterpret_cast<int32_t*>(p->d_tr) : (int32_t*)nullptr);
-        if (beside) std::swap(p->d_rank, p->d_rankAlt);
+        const int r = radix_sort_pairs(p, FAM_SORT_RADIX, kb, vb, L, 0, 32, p->d_rank, radix_scratch(p, 0), p->N, p->rsFlip[0]);
         p->landCur = r == 0 ? cur : (cur ^ 1);
         rankWritten = true;
     } else {
