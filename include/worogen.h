@@ -21,6 +21,25 @@
  *     the reference's single worker.  Different contexts may be driven from different threads concurrently (the
  *     library keeps no shared mutable state); several planets in flight on one GPU this way raise throughput ~2x
  *     (DESIGN.md section 7).
+ *
+ * Environment (every variable the library reads; read once per API call or flood call, never inside a pass)
+ *   sizing       WO_HOST_THREADS=<n>        workers of the host-side parallel sweeps (default: the process's CPUs, <= 64)
+ *                WO_FLOOD_THREADS=<n>       workers of the priority flood's per-landmass walks (default 24)
+ *                WO_FLOOD_PIN=1             the walk of the largest landmass keeps its CPU and the other flood workers keep off its L3
+ *                                           (the library touches no thread affinity unless asked)
+ *   routes       WO_LAYOUT=index            erodeComposite on the planet's own cell order instead of the land-first Morton mirror
+ *   (same bits)  WO_TILE_LDS=1              receivers / thermal passes stage their tile's neighbour window in LDS (measured no faster)
+ *                WO_FLOOD=device            pass 1 of the flood as the device label-correcting fixed point (exact, ~16x slower than the host walk)
+ *                WO_FLOOD_HOST=two-phase    host flood: pass 1 of all landmasses, then passes 2 / 3 (default: pipelined per landmass)
+ *                WO_FLOOD_HOST=serial       host flood: the reference's single heap, one thread (WO_FLOOD_HOST is read once per process)
+ *   relaxed      WO_RELAXED=full            NOT the reference's semantics: one sort per flood, affine solve, Jacobi carve
+ *   (labelled)   WO_RELAXED_SORT_EVERY=<k>  NOT the reference's semantics: landCells re-sorted every k-th iteration only
+ *   diagnostics  WO_FLOOD_TIMING=1          laps of the flood stage and of a new terrain's set-up -> stderr
+ *                WO_STAGE_TIMING=all        wo_last_stage_timing brackets every iteration instead of every 8th
+ *                WO_ELEV_TIMING=1           laps of assignElevation's host stage -> stderr
+ *   tests only   WO_TEST_HOOKS=k=v,k=v      the test suite's hooks (csrc/host_util.h: forced undecided landmasses, replay cuts, a wrong basin
+ *                                           layout, a carve launch that gives up, ...); never set in production
+ * (The Python loader additionally honours WO_LIBWOROGEN=<path to the .so>; bench.py has WO_BENCH_* switches of its own.)
  */
 #ifndef WOROGEN_H
 #define WOROGEN_H

@@ -27,7 +27,6 @@
 // and a task whose predecessor is NOT where the layout promised (a cycle longer than two cells that the jumping gave
 // up on) simply stays pending and is finished by k_solve_patch launches over the same store order (planet.hip).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <string>
 
@@ -146,108 +145,10 @@ __device__ inline bool block_range(const int32_t* __restrict__ rangeStart, int32
     return true;
 }
 
+// (Round 3's cooperative form — NW waves per range walking super-chunks of 64 x NW tasks with ONE barrier per super-chunk, k_solve_coop — was the
+// default until round 4 and a cross-check route until round 6: 350 us per launch against 228 for what follows; removed.)
 // ---------------------------------------------------------------------------------------------------------------------
-// Cooperative streaming form: NW waves per range.  A launch of k_solve_stream lasts as long as its longest range — one wave
-// walking the biggest component alone, 100-330 chunks at ~2.4 us — while the chip is empty.  Here a workgroup of NW waves
-// walks the range in super-chunks of 64 x NW tasks: every lane takes one task and polls the granules of its predecessors
-// that lie in the workgroup's LDS ring (the current super-chunk included) until they carry the slot it waits for; the
-// lowest open slot of a super-chunk always finds its predecessors done, so the polling ends.  One barrier per super-chunk
-// keeps the waves together (ring entries are reused RING slots later).  Loads are pipelined as in k_solve_stream.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 6) void k_solve_coop(Fields F, int32_t L, const int32_t* __restrict__ rangeStart, int32_t nRanges, int32_t launchTag,
-                                                            int32_t* patchPending, int32_t* totalPending, const int32_t* __restrict__ big, const uint8_t* __restrict__ longFlag) {
-    constexpr int SC = 64 * NW;                        // tasks per super-chunk
-    constexpr int RING = (2 * SC > 1024) ? 2 * SC : 1024;    // tasks whose granules the workgroup keeps in LDS (power of two, >= 2 super-chunks)
-    __shared__ unsigned long long s_ring[2 * RING];
-    const int tid = threadIdx.x;
-    int32_t S, E;
-    if (!block_range(rangeStart, nRanges, L, big, longFlag, S, E)) return;
-    const unsigned long long* G = reinterpret_cast<const unsigned long long*>(F.out);
-    // LDS keeps what the last workgroup left: last pass's launch wrote the very tags this one waits for.  Clear the ring first.
-    for (int i = tid; i < 2 * RING; i += SC) s_ring[i] = 0;
-    __syncthreads();
-    // ring word = {value, tag}: tag = slot + 1 once the granule is there, -(slot + 1) when its task is blocked; anything else: not yet
-    auto ring_put = [&](int32_t word, float v, int32_t tag) {
-        __hip_atomic_store(&s_ring[word], (unsigned long long)__float_as_uint(v) | ((unsigned long long)(uint32_t)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    auto record = [&](int32_t q) { return F.task[q < L ? q : L - 1]; };
-    auto far_index = [&](int32_t g, int32_t cbase) { const int32_t sq = g >> 1; return (g >= 0 && (sq < S || sq < cbase - (RING - SC))) ? g : 0; };
-    SolveTask T1 = record(S + tid), T2 = record(S + SC + tid);
-    unsigned long long a0 = G[far_index(T1.predSelf, S)], a1 = G[far_index(T1.predT, S)], a2 = G[far_index(T1.predT2, S)];
-    SolveOut oPrev; oPrev.self.v = 0; oPrev.self.tag = 0; oPrev.dep.v = 0; oPrev.dep.tag = 0;
-    bool storePrev = false;
-    uint32_t fPrev = 0; int32_t rPrev = 0, tPrev = 0;                  // Fields::solveFinals: the previous task's finality flags and cells
-    // with solveFinals a task that leaves the LAST event of the pass on a cell writes the cell's new height (and masked height) itself:
-    // k_solve_final — a pass over all land cells that looks the last event up again — is not launched (planet.hip)
-    auto store_prev = [&](int32_t slot) {
-        F.out[slot] = oPrev;
-        if (F.solveFinals) {
-            if (fPrev & 16u) { F.e2[rPrev] = oPrev.self.v; F.me[rPrev] = oPrev.self.v; }
-            if (fPrev & 32u) { F.e2[tPrev] = oPrev.dep.v; F.me[tPrev] = oPrev.dep.v; }
-        }
-    };
-    for (int32_t base = S; base < E; base += SC) {
-        const int32_t q = base + tid;
-        const bool mine = q < E;
-        if (storePrev) store_prev(q - SC);                             // a super-chunk late: the wait for this super-chunk's loads at the top of the loop would otherwise also wait for a store issued a moment ago
-        const SolveTask T = T1;
-        T1 = T2;
-        T2 = record(base + 2 * SC + tid);
-        const unsigned long long n0 = G[far_index(T1.predSelf, base + SC)], n1 = G[far_index(T1.predT, base + SC)], n2 = G[far_index(T1.predT2, base + SC)];
-        double er = T.e0r, et = T.e0t, et2 = T.e0t2;
-        bool blocked = false;
-        int32_t r0 = -1, r1 = -1, r2 = -1, x0 = 0, x1 = 0, x2 = 0;     // ring word and expected tag of the predecessors that come through the ring
-        if (mine) {
-            auto classify = [&](int32_t g, unsigned long long far, double& v, int32_t& rw, int32_t& expect) {
-                if (g < 0) return;
-                const int32_t sq = g >> 1;
-                if (sq >= q) { blocked = true; return; }                                         // not in processing order: the layout is off
-                if (sq >= S && sq >= base - (RING - SC)) { rw = g & (2 * RING - 1); expect = sq + 1; return; }
-                const int32_t tag = (int32_t)(far >> 32);
-                const bool own = sq >= S;                                                        // written by this workgroup, long ago
-                // valid: this workgroup's own output of THIS launch (launchTag: 1 in a checked pass, whose outputs were cleared; in an unchecked
-                // pass a number no earlier pass used — nothing is cleared and whatever an earlier pass left there carries another tag).  A
-                // predecessor outside the range is never valid in this launch: the layout promised there is none.
-                if (!own || tag != launchTag) { blocked = true; return; }
-                v = __uint_as_float((uint32_t)far);
-            };
-            classify(T.predSelf, a0, er, r0, x0); classify(T.predT, a1, et, r1, x1); classify(T.predT2, a2, et2, r2, x2);
-        }
-        const SolvePrepared pre = solve_prepare(T, F.solveK, F.solveM, F.solveDt);
-        const int32_t myWord = (2 * q) & (2 * RING - 1);
-        bool open = mine;
-        SolveOut o; o.self.v = 0; o.self.tag = 0; o.dep.v = 0; o.dep.tag = 0;
-        if (mine && blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
-        while (__any(open)) {
-            if (open) {
-                auto poll = [&](int32_t& rw, int32_t expect, double& v) {
-                    if (rw < 0) return;
-                    const unsigned long long w = __hip_atomic_load(&s_ring[rw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int32_t tag = (int32_t)(w >> 32);
-                    if (tag == expect) { v = __uint_as_float((uint32_t)w); rw = -1; }
-                    else if (tag == -expect) { blocked = true; }
-                };
-                poll(r0, x0, er); poll(r1, x1, et); poll(r2, x2, et2);
-                if (blocked) { ring_put(myWord, 0.0f, -(q + 1)); ring_put(myWord + 1, 0.0f, -(q + 1)); open = false; }
-                else if (r0 < 0 && r1 < 0 && r2 < 0) {
-                    o = solve_apply(T, pre, er, et, et2, launchTag);
-                    ring_put(myWord, o.self.v, q + 1); ring_put(myWord + 1, o.dep.v, q + 1);
-                    open = false;
-                }
-            }
-        }
-        oPrev = o; storePrev = mine && !blocked; fPrev = T.flags; rPrev = T.pad_[0]; tPrev = T.pad_[1];
-        if (mine && blocked) { atomicAdd(&patchPending[q / WO_PATCH], 1); atomicAdd(totalPending, 1); }
-        a0 = n0; a1 = n1; a2 = n2;
-        __syncthreads();
-    }
-    if (storePrev) store_prev(S + ((E - S - 1) / SC) * SC + tid);
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// The same walk WITHOUT the barrier.  Phase clocks of k_solve_coop on a 1 600-slot range (WO_BASIN_STATS, profiles/r04c_*): 48 % of
+// The walk of a range by a workgroup of NW waves, super-chunk by super-chunk of 64 x NW tasks, WITHOUT a barrier.  Phase clocks of the barrier form on a 1 600-slot range (profiles/r04c_*): 48 % of
 // a wave's time is the wait at the super-chunk barrier (the waves' in-chunk chains differ in length and the launch pays the
 // SUM over the super-chunks of the longest chain in each), 35 % the polling loop at ~1 500 clocks per pass (three LDS reads,
 // each waited for on its own, then the turn's three divisions).  Here
@@ -497,7 +398,6 @@ void basin_alloc(wo_planet* p) {
 // cell's Morton slot is its id (land-first mirror).
 void basin_layout(wo_planet* p, bool slotIdentity) {
     const int32_t L = p->L;
-    hipStream_t s = cur_stream(p);
     basin_alloc(p);
     int bitsL = 1;
     while (((int64_t)1 << bitsL) < (int64_t)L) ++bitsL;
@@ -508,22 +408,11 @@ void basin_layout(wo_planet* p, bool slotIdentity) {
     const int nRanges = (int)(((int64_t)L + rangeT - 1) / rangeT);
     launch(p, FAM_BASIN, k_basin_keys, grid, WO_BLOCK, (const int32_t*)p->d_land[p->landCur], (const uint32_t*)p->d_basinKey, L, p->d_keys[0], p->d_basinVals[0],
            (int32_t)(p->opt.basinScramble ? 1 : 0), p->d_basinRange, (int32_t)(nRanges + 1));
-    // the in-tree sort (radix.hip; its last pass also writes slotOf[cell] = position); WO_SORT=hipcub: the library sort
-    const bool library = p->opt.sortLibrary;
-    int sorted = 1;                                  // which of d_keys / d_basinVals holds the result
-    if (!library) {
-        uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
-        int32_t* const vb[2] = {p->d_basinVals[0], p->d_basinVals[1]};
-        sorted = radix_sort_pairs(p, FAM_BASIN_SORT, kb, vb, L, 0, 16 /* always two digits: the sort's two group-total buffers swap roles every pass and only stay consistent over an even number of passes; key bits above bitsL - shift are zero */, p->d_basinSlot, radix_scratch(p, 1), p->N, p->rsFlip[1]);
-    } else {
-        hipEvent_t a = nullptr, b = nullptr;
-        if (p->profiling) { a = profile_event(p); b = profile_event(p); WO_HIP(hipEventRecord(a, s)); }
-        size_t bytes = p->sortTempBytes;
-        WO_HIP(hipcub::DeviceRadixSort::SortPairs(p->d_sortTemp, bytes, (const uint32_t*)p->d_keys[0], p->d_keys[1],
-                                                 (const int32_t*)p->d_basinVals[0], p->d_basinVals[1], L, 0, bitsL - shift, s));
-        if (p->profiling) { WO_HIP(hipEventRecord(b, s)); p->pending.push_back({FAM_BASIN_SORT, a, b}); }
-    }
-    launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[sorted], (const uint32_t*)p->d_keys[sorted], library ? p->d_basinSlot : (int32_t*)nullptr, L, p->d_basinRange, (int32_t)rangeT);
+    // the in-tree sort (radix.hip); its last pass also writes slotOf[cell] = position
+    uint32_t* const kb[2] = {p->d_keys[0], p->d_keys[1]};
+    int32_t* const vb[2] = {p->d_basinVals[0], p->d_basinVals[1]};
+    const int sorted = radix_sort_pairs(p, FAM_BASIN_SORT, kb, vb, L, 0, 16 /* always two digits: the sort's two group-total buffers swap roles every pass and only stay consistent over an even number of passes; key bits above bitsL - shift are zero */, p->d_basinSlot, radix_scratch(p, 1), p->N, p->rsFlip[1]);
+    launch(p, FAM_BASIN, k_basin_slots, blocks_for(L, 4096), WO_BLOCK, (const int32_t*)p->d_basinVals[sorted], (const uint32_t*)p->d_keys[sorted], (int32_t*)nullptr, L, p->d_basinRange, (int32_t)rangeT);
     launch(p, FAM_BASIN, k_basin_long, blocks_for(nRanges), WO_BLOCK, (const int32_t*)p->d_basinRange, (int32_t)nRanges, L, p->d_basinRange + nRanges + 1, p->d_basinLong);
 }
 
@@ -534,26 +423,9 @@ void basin_solve_launch(wo_planet* p, const Fields& F, int32_t launchTag, int32_
     const int32_t* big = (const int32_t*)(p->d_basinRange + nRanges + 1);
     const uint8_t* flag = (const uint8_t*)p->d_basinLong;
     const int grid = nRanges + WO_LONG_MAX;
-    if (p->opt.basinBarrierKernel) {           // WO_BASIN_KERNEL=barrier: the walk with one barrier per super-chunk (cross-check route)
-        launch(p, FAM_SOLVE_BASIN, k_solve_coop<4>, grid, 256, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag);
-        return;
-    }
-    if (!p->opt.basinStats) {
-        launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, false>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
-        return;
-    }
-    // WO_BASIN_STATS=1 (diagnostic): the slowest range of the launch, its clocks and the depth of its dependency DAG -> stderr
-    static unsigned long long* dstats = nullptr;
-    if (!dstats) WO_HIP(hipMalloc((void**)&dstats, 8 * sizeof(unsigned long long)));
-    WO_HIP(hipMemsetAsync(dstats, 0, 8 * sizeof(unsigned long long), cur_stream(p)));
-    if (p->opt.basinStatsNoDepth) launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, true, 3>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    else launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, true>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, dstats);
-    unsigned long long h[8];
-    WO_HIP(hipStreamSynchronize(cur_stream(p)));
-    WO_HIP(hipMemcpy(h, dstats, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[basin stats] slowest range: %llu slots, %llu clocks, DAG depth (ring window) %llu -> %.0f clocks per level; busiest wave: %llu polling passes, %llu with a turn\n", h[1], h[0] >> 24, h[0] & 0xffffffull,
-            (double)(h[0] >> 24) / (double)std::max<unsigned long long>(1, h[0] & 0xffffffull), h[2], h[3]);
-    fprintf(stderr, "[basin stats]   wave 0 of it: %llu passes; clocks waiting for the other wave %llu, from there to the first poll (stores, record / far loads, classify) %llu, inside turns %llu\n", h[6], h[4], h[7], h[5]);
+    launch(p, FAM_SOLVE_BASIN, k_solve_flowing<2, false>, grid, 128, F, p->L, (const int32_t*)p->d_basinRange, (int32_t)nRanges, launchTag, p->d_patchPending, totalPending, big, flag, (unsigned long long*)nullptr);
+    // (k_solve_flowing<2, true>: the same kernel with phase clocks and the depth of the slowest range's dependency DAG written to its last argument — the
+    // diagnostic build behind DESIGN.md's "clocks per level" figures, profiles/r04c_*; not instantiated in the product)
 }
 
 void basin_free(wo_planet* p) {

@@ -28,8 +28,6 @@ struct HipError { std::string msg; };
     } while (0)
 
 constexpr int WO_BLOCK = 256;
-constexpr int WO_LEVEL_BITS = 12;                       // predicted solve levels are clamped to 4095
-constexpr int WO_MAX_LEVEL = (1 << WO_LEVEL_BITS) - 1;
 inline int blocks_for(int64_t n, int maxBlocks = 1 << 20) {
     int64_t b = (n + WO_BLOCK - 1) / WO_BLOCK;
     if (b < 1) b = 1;
@@ -83,33 +81,21 @@ struct wo_flood_gpu {
 };
 
 namespace wo {
-// Environment switches, read once per API call (check_planet -> Options::from_env), never inside an iteration.  What is left are
-// the cross-check routes the tests drive (every one must give the default route's bits), test hooks and diagnostics.
+// Environment switches, read once per API call (check_planet -> Options::from_env), never inside an iteration: cross-check routes the tests drive
+// (every one must give the default route's bits), the labelled relaxed mode, diagnostics.  The full list with the host-side ones (WO_HOST_THREADS,
+// WO_FLOOD_THREADS, WO_FLOOD_HOST, WO_FLOOD_PIN, WO_ELEV_TIMING) is in include/worogen.h; the test suite's hooks come in ONE variable (host_util.h: WO_TEST_HOOKS).
 struct Options {
-    bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror
-    bool sortLibrary = false;          // WO_SORT=hipcub           the library's radix sort instead of radix.hip
-    bool noLandListCache = false;      // WO_NO_LAND_LIST_CACHE=1  the land lists are rebuilt by every erodeComposite call (default: kept while the ocean mask stays the same)
-    bool basinBarrierKernel = false;   // WO_BASIN_KERNEL=barrier  k_solve_coop (one barrier per super-chunk) instead of k_solve_flowing
-    bool basinStats = false;           // WO_BASIN_STATS=1         diagnostic: slowest range of every solve launch -> stderr (=2: without the depth bookkeeping, which doubles the kernel's time)
-    bool basinStatsNoDepth = false;
-    bool basinScramble = false;        // WO_BASIN_SCRAMBLE=1      test hook: a deliberately wrong layout (leftovers for the patch finisher)
-    bool tileLds = false;              // WO_TILE_LDS=1            neighbour window of a workgroup's tile staged in LDS
-    bool noSolvePatch = false;         // WO_NO_SOLVE_PATCH        level-synchronous solve rounds
-    bool noEventLists = false;         // WO_NO_EVENT_LISTS        solve setup by row scans
-    int  flowClimbCap = 0x7fffffff;    // WO_FLOW_CLIMB=n          cap of a thread's climb (0: rake rounds + pointer doubling)
-    bool flowEventsStream = false;     // WO_FLOW_EVENTS_STREAM=1  the solve's event lists on a third stream
-    bool flowClimbOnly = false;        // WO_FLOW=climb            flow accumulation by k_flow_climb alone (no tile-local level: kernels_impl.h, k_flow_tiles)
-    bool iceRounds = false;            // WO_ICE_ROUNDS=1          synchronous ice accumulation rounds
-    int  carveFlow = 2;                // WO_CARVE_FLOW            2 granules, 1 done words, 0 rounds
-    long long carveFlowBudgetMs = 200; // WO_CARVE_FLOW_BUDGET_MS  spin budget of the one-launch carve
-    int  carveFlowBlocks = 0;          // WO_CARVE_FLOW_BLOCKS     test hook: at most this many workgroups
+    bool layoutIndex = false;          // WO_LAYOUT=index          no patch-major mirror: the call runs on the planet's own cell order (flow accumulation by k_flow_climb)
+    bool tileLds = false;              // WO_TILE_LDS=1            neighbour window of a workgroup's tile staged in LDS (receivers, thermal)
     bool floodDevice = false;          // WO_FLOOD=device          pass 1 of the flood as the device label-correcting fixed point
-    bool floodTiesById = false;        // WO_FLOOD_TIES=id         accept the cell-id order between equal labels (device flood)
     bool floodTiming = false;          // WO_FLOOD_TIMING          stage laps -> stderr
     bool stageTimingAll = false;       // WO_STAGE_TIMING=all      bracket every iteration
-    bool graphs = false;               // WO_GRAPH=1               hipGraph replay of the steady composite iteration (measured slower: planet.hip)
     int  relaxedSortEvery = 1;         // WO_RELAXED_SORT_EVERY=K  RELAXED MODE (not parity): re-sort landCells every K-th iteration only
     bool relaxedFull = false;          // WO_RELAXED=full          RELAXED MODE (not parity): one sort per flood, affine pointer-jumping solve with deferred deposition, Jacobi carve (kernels_impl.h)
+    // test hooks (WO_TEST_HOOKS)
+    bool basinScramble = false;        // basin_scramble=1         a deliberately wrong basin layout (leftovers for the patch finisher)
+    long long carveBudgetMs = 200;     // carve_budget_ms=<n>      spin budget of the one-launch carve (0: it gives up at once and the rounds finish)
+    int  carveBlocks = 0;              // carve_blocks=<n>         at most this many workgroups for the one-launch carve
     static Options from_env();
 };
 }  // namespace wo
@@ -166,9 +152,8 @@ struct wo_planet {
     uint8_t* d_iceUp = nullptr;
     int32_t *d_patchOrder = nullptr, *d_slotOf = nullptr, *d_patchPending = nullptr, *d_patchTotals = nullptr, *d_patchBlk = nullptr; int64_t patchVersion = -1; bool patchMirror = false; int32_t numPatches = 0; int64_t lastPatchLaunches = 1; int64_t solveCalls = 0;
     hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; bool onSide = false;
-    hipStream_t side2 = nullptr; hipEvent_t evJoin2 = nullptr; uint8_t* d_lateDonor = nullptr;        // third stream: the solve's event lists beside the flow accumulation and the layout; late-donor flags of the receivers pass   // second stream of the planet: the basin layout runs beside the flow accumulation (planet.hip)
     uint32_t* d_basinKey = nullptr; int32_t* d_basinVals[2] = {nullptr, nullptr}; int32_t *d_basinJ = nullptr, *d_basinSlot = nullptr, *d_basinRange = nullptr; uint8_t* d_basinLong = nullptr; int64_t basinLaunches = 0; wo::Affine* d_affine[2] = {nullptr, nullptr};   /* relaxed mode: the affine recurrence, ping-pong */ int64_t solvePassSerial = 0;   /* unchecked basin passes so far (their output tag: planet.hip, passTag) */   // basin.hip: component roots (Morton slot space), group-major store order of the pass
-    int32_t *d_level = nullptr, *d_byLevel = nullptr, *d_levelStart = nullptr, *h_levelStart = nullptr;
+    int32_t* h_patchTotals = nullptr;      // pinned: the pending totals of a burst of k_solve_patch launches (run_solve_patches)
     int32_t *d_listA = nullptr, *d_listB = nullptr, *d_counters = nullptr;   // round lists + 4 counters
     void* d_sortTemp = nullptr; size_t sortTempBytes = 0;
     int landCur = 0;                    // which of d_land[] holds the current order
@@ -248,7 +233,6 @@ inline void launch_shmem(wo_planet* p, int fam, void (*kernel)(KArgs...), int gr
 void sort_land_by_elevation(wo_planet* p);
 size_t sort_temp_bytes(int32_t n);
 void rank_from_land(wo_planet* p);
-void sort_by_level(wo_planet* p);
 // radix.hip: the in-tree stable radix sort (scratch: radix_scratch_words(nMax) u32, zero before the first use; flip: call parity kept by the caller)
 size_t radix_scratch_words(int32_t nMax);
 int radix_sort_pairs(wo_planet* p, int family, uint32_t* const keys[2], int32_t* const vals[2], int32_t n, int beginBit, int endBit, int32_t* posOut,

@@ -39,11 +39,10 @@ struct ElevHostState {
 };
 
 void blend_collision_layers(int32_t N, const CollisionHost& S, const CollisionHost* P, ElevHostState& H);
-// bfsOnDevice (may be empty): called once the scalars are known and BEFORE the distance fields; when set, the host does
-// not compute the FIFO BFS fields (H.dBdry ... H.arcStress stay empty): the caller produces them on the device
-// (elevation_bfs.h) while the distance fields run here.  Arguments: the scalars, maxCD, maxStress.
+// bfsOnDevice: called once the scalars are known and BEFORE the distance fields: the caller produces the FIFO BFS fields on the device
+// (elevation_bfs.h; H.dBdry ... H.arcStress stay empty) while the distance fields run here.  Arguments: the scalars, maxCD, maxStress.
 void elevation_host_stage(const ElevMesh& M, const ElevInputs& I, const CollisionHost& S, const CollisionHost* P,
                           ElevHostState& H, ElevParams& Q, std::vector<Dome>& domes,
-                          const std::function<void(const ElevParams&, int32_t, double)>& bfsOnDevice = {});
+                          const std::function<void(const ElevParams&, int32_t, double)>& bfsOnDevice);
 
 }  // namespace wo

@@ -114,7 +114,6 @@ struct Fields {
     int32_t solveFinals;                // 1: records carry the finality flags and cells (SolveTask::pad_), cells without any event get their height copied by the setup
     int32_t solveLean;                  // 1: solve_setup writes the task record only — the outputs were cleared by a memset and the blocker hints are
                                         //    made from the records if a launch ever leaves tasks pending (basin-local solve: 20 of the 68 scattered bytes per task)
-    uint8_t* lateDonor;                 // [N] set by the receivers pass on a land cell that has a donor ranked after it (its total reaches the cell's flow only in the totals pass); all zero between iterations; nullptr: off
     int32_t* basinJ;                    // basin layout (basin.hip): the receivers pass leaves the start state of the component search here — J[slot of r] = slot of
     const int32_t* basinMslot;          //    r's land receiver, or r's own slot; basinMslot: Morton slot of a cell, nullptr: slot == cell id (land-first mirror).  nullptr: off
     int32_t* blk;                       // patch solve: granule that was seen unresolved when the task last failed, or -1 [N], at the store index
@@ -422,43 +421,6 @@ WO_HD inline void flow_final_cell(const Fields& F, int32_t c) {
     }
     F.flow[c] = (float)f;
     if (F.ev) { if (over) E.rank[0] = -2; F.ev[c] = E; }
-}
-// The two halves of flow_final_cell for the three-stream form of the pass (planet.hip): the event list depends on the receivers
-// only and is built beside the flow accumulation; the totals need the accumulation and, thanks to the late-donor flag the
-// receivers pass leaves, touch a neighbour only on the few cells that have a late donor.
-WO_HD inline void flow_events_cell(const Fields& F, int32_t c) {
-    const TargetRank trc = F.tr[c];
-    EventList E;
-#pragma unroll
-    for (int q = 0; q < WO_EVENTS; ++q) { E.cell[q] = -1; E.rank[q] = -1; }
-    int n = 0; bool over = false;
-    if (trc.target >= 0) event_insert(E, n, over, c, trc.rank);
-    int32_t b, nbs[WO_ROW];
-    const int deg = load_row(F, c, b, nbs);
-    if (deg <= WO_ROW) {
-        TargetRank q[WO_ROW];
-#pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) q[k] = F.tr[nbs[k]];
-#pragma unroll
-        for (int k = 0; k < WO_ROW; ++k) if (k < deg && q[k].target == c) event_insert(E, n, over, nbs[k], q[k].rank);
-    } else {
-        for (int32_t j = b; j < b + deg; ++j) { const int32_t nb = F.adj[j]; const TargetRank v = F.tr[nb]; if (v.target == c) event_insert(E, n, over, nb, v.rank); }
-    }
-    if (over) E.rank[0] = -2;
-    F.ev[c] = E;
-}
-WO_HD inline void flow_totals_cell(const Fields& F, int32_t c) {
-    uint32_t f = flow_total(F, c);
-    if (F.lateDonor[c]) {
-        F.lateDonor[c] = 0;
-        const int32_t rc = F.tr[c].rank;
-        for (int32_t j = F.off[c]; j < F.off[c + 1]; ++j) {
-            const int32_t nb = F.adj[j];
-            const TargetRank v = F.tr[nb];
-            if (v.target == c && v.rank > rc) f += flow_total(F, nb);          // late donor, un-forwarded
-        }
-    }
-    F.flow[c] = (float)f;
 }
 // latest event on the list's location strictly before the turn of task r (rank rr), r's own events excluded; -1: none
 WO_HD inline int32_t event_before(const EventList& E, int32_t r, int32_t rr) {

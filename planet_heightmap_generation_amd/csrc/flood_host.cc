@@ -273,7 +273,7 @@ int64_t flood_queues_differ(int64_t ops, uint64_t seed) { return queues_differ(o
 // open-ocean component (largest, first wins ties, js/terrain-post.js:66-94) and the seed list (land cells whose
 // first open-ocean neighbour in adjacency order exists, ascending r, :118-128).  Shared by both flood calls of
 // an erodeComposite and kept across calls while the ocean mask is unchanged.
-void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S) {
+void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S, const int32_t* mortonAll) {
     const bool timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -320,7 +320,15 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     lap("ocean labels");
     // land cells in Morton order of their positions (identity order when no positions are given)
     hvec<int32_t> landCells;
-    {
+    if (xyz && mortonAll) {
+        // the caller has ALL cells in that order already (morton_order_cells: same keys, same stable sort, so the land cells appear in it in the order the sort
+        // below would give them): a new mask on a known mesh is a filter, not a sort (32 -> 3 ms of a new terrain's set-up at 10 M cells)
+        std::vector<int64_t> cnt(host_threads() + 2, 0);
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t i = b; i < e; ++i) c += ocean[mortonAll[i]] ? 0 : 1; cnt[t + 1] = c; });
+        for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+        landCells.resize(cnt.back());
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t o = cnt[t]; for (int64_t i = b; i < e; ++i) { const int32_t r = mortonAll[i]; if (!ocean[r]) landCells[o++] = r; } });
+    } else {
         std::vector<int64_t> cnt(host_threads() + 2, 0);
         parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t r = b; r < e; ++r) c += ocean[r] ? 0 : 1; cnt[t + 1] = c; });
         for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
@@ -328,7 +336,7 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
         parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t o = cnt[t]; for (int64_t r = b; r < e; ++r) if (!ocean[r]) landCells[o++] = (int32_t)r; });
     }
     const int32_t L = (int32_t)landCells.size();
-    if (xyz && L > 1) {
+    if (xyz && L > 1 && !mortonAll) {
         std::vector<uint32_t> keys(L);
         parallel_ranges(L, [&](int64_t b, int64_t e, int) {
             for (int64_t i = b; i < e; ++i) {
@@ -361,7 +369,7 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
             S.offL[i + 1] = c;
         }
     });
-    for (int32_t i = 0; i < L; ++i) S.offL[i + 1] += S.offL[i];
+    inclusive_scan_parallel(S.offL.data() + 1, L);
     S.adjL.resize(S.offL[L]);
     parallel_ranges(L, [&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; ++i) {
@@ -465,16 +473,17 @@ struct FloodTimer {
 }  // namespace
 
 void FloodHooks::read() {
-    auto num = [](const char* n, int32_t dflt) { const char* v = std::getenv(n); return v ? (int32_t)std::atoi(v) : dflt; };
-    ringMin = num("WO_FLOOD_RING_MIN", 4096);
-    chainsMin = num("WO_FLOOD_CHAINS_MIN", 2048);
-    forceDirty = num("WO_FLOOD_FORCE_DIRTY", -1);
-    const char* rs = std::getenv("WO_FLOOD_REPLAY_STOP");
-    hasReplayStop = rs != nullptr; replayStop = rs ? (float)std::atof(rs) : 0.0f;
-    replayPrefix = num("WO_FLOOD_PREFIX", 1) != 0;
-    forcePrefixPermille = std::min(1000, std::max(0, num("WO_FLOOD_FORCE_PREFIX", 0)));
+    // test hooks (host_util.h: WO_TEST_HOOKS), then the two documented switches
+    ringMin = (int32_t)test_hook_int("flood_ring_min", 4096);
+    chainsMin = (int32_t)test_hook_int("flood_chains_min", 2048);
+    forceDirty = (int32_t)test_hook_int("flood_force_dirty", -1);
+    std::string rs;
+    hasReplayStop = test_hook("flood_replay_stop", &rs); replayStop = hasReplayStop ? (float)std::atof(rs.c_str()) : 0.0f;
+    replayPrefix = test_hook_int("flood_prefix", 1) != 0;
+    forcePrefixPermille = (int32_t)std::min<long long>(1000, std::max<long long>(0, test_hook_int("flood_force_prefix", 0)));
     timing = std::getenv("WO_FLOOD_TIMING") != nullptr;
-    pin = num("WO_FLOOD_PIN", 0) != 0;
+    const char* pn = std::getenv("WO_FLOOD_PIN");
+    pin = pn && std::atoi(pn) != 0;
 }
 
 // land elevations into the compact arrays + the start state of pass 1 (:107-113); every flood call starts here: the hooks are read

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <functional>
 #include <thread>
+#include <string>
 #include <vector>
 #include <sys/mman.h>
 
@@ -126,6 +127,28 @@ private:
     std::exception_ptr error_;
 };
 
+// The test suite's hooks: ONE environment variable, WO_TEST_HOOKS="key=value,key=value,..." (a key without a value reads "1"), never set in production and
+// read where the product reads its options (once per API call / flood call), never inside a pass.  Returns whether the key is there.
+inline bool test_hook(const char* key, std::string* value = nullptr) {
+    const char* v = std::getenv("WO_TEST_HOOKS");
+    if (!v || !*v) return false;
+    const std::string s(v), k(key);
+    for (size_t pos = 0; pos <= s.size();) {
+        size_t e = s.find(',', pos);
+        if (e == std::string::npos) e = s.size();
+        const std::string item = s.substr(pos, e - pos);
+        const size_t eq = item.find('=');
+        if (item.substr(0, eq) == k) { if (value) *value = eq == std::string::npos ? std::string("1") : item.substr(eq + 1); return true; }
+        pos = e + 1;
+    }
+    return false;
+}
+inline long long test_hook_int(const char* key, long long dflt) { std::string v; return test_hook(key, &v) ? std::atoll(v.c_str()) : dflt; }
+
+// a[i] := a[0] + ... + a[i], i < n, on the host's workers (three sweeps: range sums, their serial scan, ranges again; the ranges of two
+// parallel_ranges calls over the same n are the same).  Declared here, defined after parallel_ranges.
+template <class T> inline void inclusive_scan_parallel(T* a, int64_t n);
+
 // Static-chunked parallel loop over [0, n). fn(begin, end, tid).
 template <class F>
 inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
@@ -144,6 +167,12 @@ inline void parallel_ranges(int64_t n, F fn, int64_t min_chunk = 4096) {
         th.emplace_back([=, &fn]() { fn(b, e, (int)c); });
     }
     for (auto& t : th) t.join();
+}
+template <class T> inline void inclusive_scan_parallel(T* a, int64_t n) {
+    std::vector<T> sum(host_threads() + 2, T(0));
+    parallel_ranges(n, [&](int64_t b, int64_t e, int t) { T s = 0; for (int64_t i = b; i < e; ++i) s += a[i]; sum[t + 1] = s; });
+    for (size_t t = 1; t < sum.size(); ++t) sum[t] += sum[t - 1];
+    parallel_ranges(n, [&](int64_t b, int64_t e, int t) { T s = sum[t]; for (int64_t i = b; i < e; ++i) { s += a[i]; a[i] = s; } });
 }
 
 // ---- where the host threads run (Linux) ----

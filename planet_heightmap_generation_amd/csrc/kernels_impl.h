@@ -229,7 +229,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         if (F.accA) F.accA[r] = a;                           // (the pointer doubling's accumulator: nullptr on the default route, where k_flow_climb retires every cell)
         F.jumpA[r] = j; F.accCnt[r] = 1ull;
         if (j >= 0 && donorCnt) atomicAdd(&donorCnt[j], 1);  // donorCnt is all zero on entry (k_flow_final leaves it so); nullptr: the tile route counts a cell's donors itself (k_flow_tiles)
-        if (F.lateDonor && t >= 0 && !F.ocean[t] && !(F.rank[r] < F.rank[t])) F.lateDonor[t] = 1;      // r's total is added to t's flow by the totals pass, not forwarded
         if (F.basinJ) {                                      // start state of the drainage-component search (basin.hip: k_basin_init's job, one launch less on the layout's chain)
             const bool landT = t >= 0 && !F.ocean[t];
             const int32_t sr = F.basinMslot ? F.basinMslot[r] : r;
@@ -237,65 +236,12 @@ __global__ __launch_bounds__(WO_BLOCK) void k_receivers_flow_init(Fields F, int3
         }
     }
 }
-// Flow accumulation, part 1: rake.  Subtree sizes are integers, so any order of the additions is exact.  Most land
-// cells sit on short hillslope branches: a few rounds of "cells whose donors are all in hand their total to their
-// receiver and retire" remove them, and the pointer doubling (part 2) only runs on the river skeleton that is left.
-// up to four values per thread, one global atomic per workgroup: the list counter is a single address, and at ~10 ns per
-// atomic a 10^4-block append is atomic-bound (it was 130 us for 2.8 M entries with one value per thread)
-__device__ inline void block_append4(int cnt, const int32_t (&vals)[4], int32_t* out, int32_t* outCount) {
-    __shared__ int32_t s_w4[WO_BLOCK / 64];
-    __shared__ int32_t s_b4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    if (lane == 63) s_w4[wave] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t tot = 0;
-        for (int w = 0; w < WO_BLOCK / 64; ++w) { const int32_t c = s_w4[w]; s_w4[w] = tot; tot += c; }
-        s_b4 = tot ? atomicAdd(outCount, tot) : 0;
-    }
-    __syncthreads();
-    int32_t at = s_b4 + s_w4[wave] + incl - cnt;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) if (q < cnt) out[at++] = vals[q];
-    __syncthreads();
-}
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_rake(Fields F, int32_t* donorCnt, const int32_t* in, const int32_t* inCount, int32_t* out, int32_t* outCount,
-                                                         int32_t* zeroCount, int32_t firstN) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    // first round (inCount == nullptr): `in` is the whole land list and the leaves (no donors, a receiver) pick themselves
-    const int32_t n = inCount ? *inCount : firstN;
-    const int32_t groups = (n + 3) / 4;
-    WO_BLOCK_STRIDE(g, valid, groups) {
-        int32_t vals[4]; int cnt = 0;
-        if (valid) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int32_t i = 4 * g + q;
-                if (i >= n) continue;
-                const int32_t d = in[i];
-                // donorCnt: low 16 bits = forward donors (fixed once the receivers pass is over), high bits = donors retired so
-                // far; the leaf test reads only the low half, which no round changes (a plain countdown could reach 0
-                // mid-round and make a receiver pass for a leaf)
-                if (!inCount && !((donorCnt[d] & 0xffff) == 0 && F.jumpA[d] >= 0)) continue;
-                const int32_t j = F.jumpA[d];
-                atomicAdd(&F.accA[j], F.accA[d]);           // d's total is final: all its donors retired in earlier rounds
-                F.jumpA[d] = -2;                            // retired
-                const int32_t old = atomicAdd(&donorCnt[j], 0x10000);
-                if (((old >> 16) + 1 == (old & 0xffff)) && F.jumpA[j] >= 0) vals[cnt++] = j;    // last donor in: j goes next (roots just keep the sum)
-            }
-        }
-        block_append4(cnt, vals, out, outCount);
-    }
-}
-// The rake as ONE launch (WO_FLOW_CLIMB=<cap>): every leaf hands its total to its receiver, and the thread whose hand-over
-// completes a receiver (last donor in) carries on with that receiver, at most `cap` cells up; what is left goes to the pointer
-// doubling as before.  Integer sums: any order is exact.  A cell's running total and the number of donors that have arrived
-// share one 64-bit word (accCnt), so ONE returning atomic both delivers a total and tells the deliverer whether it was the
-// last — then old total + its own contribution IS the cell's total: no ordering between two atomics to arrange, one memory
-// round trip per step.  k_flow_remaining copies the totals of the cells that stay into accA for the pointer doubling.
+// Flow accumulation on the planet's own cell order (WO_LAYOUT=index; under the land-first mirror: k_flow_tiles below).  Subtree sizes are integers, so any
+// order of the additions is exact.  ONE launch: every leaf hands its total to its receiver, and the thread whose hand-over completes a receiver (last
+// donor in) carries on with that receiver.  A cell's running total and the number of donors that have arrived share one 64-bit word (accCnt), so ONE
+// returning atomic both delivers a total and tells the deliverer whether it was the last — then old total + its own contribution IS the cell's total: no
+// ordering between two atomics to arrange, one memory round trip per step.  (Round 2's rake rounds + pointer doubling, 108 ms of flow stage per step
+// against 45, and the capped climb between them were cross-check routes until round 6.)
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_climb(Fields F, const int32_t* donorCnt, int32_t cap) {
     WO_XCD_LAND(i, r) {
         int32_t d = r;
@@ -476,68 +422,7 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_root_climb(Fields F, FlowTile
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_remaining(Fields F, const int32_t* land, int32_t L, int32_t* out, int32_t* outCount, int32_t fromClimb) {
-    const int32_t groups = (L + 3) / 4;
-    WO_BLOCK_STRIDE(g, valid, groups) {
-        int32_t vals[4]; int cnt = 0;
-        if (valid) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int32_t i = 4 * g + q;
-                if (i < L) {
-                    const int32_t r = land[i];
-                    if (fromClimb) F.accA[r] = (uint32_t)F.accCnt[r];          // totals after k_flow_climb (retired cells: no longer read)
-                    if (F.jumpA[r] >= 0) vals[cnt++] = r;
-                }
-            }
-        }
-        block_append4(cnt, vals, out, outCount);
-    }
-}
 
-// pointer-doubling round, part 1: snapshot the value each active cell will send and its next ancestor
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_snap(Fields F, const int32_t* list, const int32_t* count, uint32_t* snap, int32_t* nj) {
-    const int32_t n = *count;
-    WO_GRID_STRIDE(i, n) {
-        const int32_t d = list[i];
-        const int32_t j = F.jumpA[d];
-        snap[i] = F.accA[d];
-        nj[i] = (j >= 0) ? F.jumpA[j] : -1;
-    }
-}
-// part 2: A[jump[d]] += snapshot (integer atomics: exact, order-free), jump[d] <- jump[jump[d]]
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_apply(Fields F, const int32_t* list, const int32_t* count, const uint32_t* snap,
-                                                          const int32_t* nj, int32_t* out, int32_t* outCount, int32_t* zeroCount) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    const int32_t n = *count;
-    WO_BLOCK_STRIDE(i, valid, n) {
-        bool again = false; int32_t d = -1;
-        if (valid) {
-            d = list[i];
-            const int32_t j = F.jumpA[d];
-            if (j >= 0) {
-                atomicAdd(&F.accA[j], snap[i]);
-                const int32_t j2 = nj[i];
-                F.jumpA[d] = j2;
-                again = j2 >= 0;
-            }
-        }
-        block_append(again, d, out, outCount);
-    }
-}
-// three-stream form (planet.hip): event lists beside the flow accumulation; totals after it
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_events(Fields F, SolveOut* clearOut) {
-    WO_XCD_LAND(i, c) {
-        if (clearOut) { SolveOut z; z.self.v = 0; z.self.tag = 0; z.dep.v = 0; z.dep.tag = 0; clearOut[i] = z; }
-        flow_events_cell(F, c);
-    }
-}
-__global__ __launch_bounds__(WO_BLOCK) void k_flow_totals(Fields F, int32_t* donorCnt) {
-    WO_XCD_LAND(i, c) {
-        if (donorCnt) donorCnt[c] = 0;                      // for the next iteration's receivers pass
-        flow_totals_cell(F, c);
-    }
-}
 __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* donorCnt, SolveOut* clearOut) {
     WO_XCD_LAND(i, c) {
         if (donorCnt) donorCnt[c] = 0;                      // for the next iteration's receivers pass (only land cells are counted into)
@@ -546,7 +431,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_flow_final(Fields F, int32_t* dono
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_setup(Fields F) { WO_XCD_LAND(i, r) solve_setup_cell(F, r); }
 
 // The same setup, written for the memory pipeline.  solve_setup_cell decides what to load next from what it has just loaded (has a
 // receiver? is it land? did a list overflow?), so the compiler must wait for every load before the branch that follows it: the ISA
@@ -677,24 +561,6 @@ __global__ __launch_bounds__(WO_BLOCK, WO_SETUP_WAVES) void k_solve_setup_batche
     if ((int32_t)threadIdx.x < s_n) { solve_setup_cell_rows(F, s_deferred[threadIdx.x]); if (F.solveFinals) solve_setup_finals_by_rows(F, s_deferred[threadIdx.x]); }
 }
 
-// One synchronous round of the solve dataflow.  Tasks come from two places: the leftovers of earlier rounds
-// and the bucket of tasks whose level in the previous erosion iteration was exactly this round (levels barely
-// move between iterations, so almost every task is examined once, when it is ready).
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_t* left, const int32_t* leftCount,
-                                                           const int32_t* bucket, int32_t bucketCount, int32_t* out, int32_t* outCount,
-                                                           int32_t* zeroCount, int32_t round, double K, double m, double dt) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    const int32_t nl = *leftCount;
-    const int32_t n = nl + bucketCount;
-    WO_BLOCK_STRIDE(i, valid, n) {
-        bool pending = false; int32_t r = -1;
-        if (valid) {
-            r = (i < nl) ? left[i] : bucket[i - nl];
-            pending = !solve_task(F, r, round, K, m, dt);
-        }
-        block_append(pending, r, out, outCount);
-    }
-}
 // The tail of the solve DAG: once only river main stems are left (a few hundred tasks per round for hundreds of
 // rounds) a kernel launch per round is all latency.  One 1024-thread workgroup then runs the remaining rounds
 // itself: same tasks, same "consume only earlier rounds" rule, but a round boundary is a __syncthreads()
@@ -703,48 +569,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_solve_round(Fields F, const int32_
 // rebuilds the pending list from the round tags and goes back to one launch per round).
 constexpr int WO_TAIL_THREADS = 1024;
 constexpr int WO_TAIL_CAP = 14336;          // 2 lists x 56 KiB of the CU's 160 KiB LDS
-__global__ __launch_bounds__(WO_TAIL_THREADS) void k_solve_tail(Fields F, const int32_t* leftIn, const int32_t* leftCountPtr,
-                                                                 const int32_t* byLevel, const int32_t* levelStart, int32_t firstRound,
-                                                                 int32_t maxPred, int32_t lookahead, int32_t maxLevel, int32_t maxRounds,
-                                                                 int32_t* stats, double K, double m, double dt) {
-    __shared__ int32_t s_list[2][WO_TAIL_CAP];
-    __shared__ int32_t s_cnt[2];
-    __shared__ int32_t s_overflow;
-    const int tid = threadIdx.x;
-    const int32_t n0 = *leftCountPtr;
-    if (n0 > WO_TAIL_CAP) { if (tid == 0) { stats[0] = firstRound - 1; stats[1] = 1; } return; }
-    for (int32_t i = tid; i < n0; i += WO_TAIL_THREADS) s_list[0][i] = leftIn[i];
-    if (tid == 0) { s_cnt[0] = n0; s_cnt[1] = 0; s_overflow = 0; }
-    __syncthreads();
-    int cur = 0;
-    int32_t k = firstRound;
-    for (;; ++k) {
-        const int32_t nl = s_cnt[cur];
-        const int32_t loL = (k == 1) ? 1 : min(k + lookahead, maxLevel + 1);
-        const int32_t hiL = min(k + lookahead, maxLevel);
-        const int32_t b0 = (hiL >= loL) ? levelStart[loL] : 0;
-        const int32_t bc = (hiL >= loL) ? levelStart[hiL + 1] - b0 : 0;
-        const int32_t n = nl + bc;
-        for (int32_t i = tid; i < n; i += WO_TAIL_THREADS) {
-            const int32_t r = (i < nl) ? s_list[cur][i] : byLevel[b0 + (i - nl)];
-            if (!solve_task(F, r, k, K, m, dt)) {
-                const int32_t pos = atomicAdd(&s_cnt[cur ^ 1], 1);
-                if (pos < WO_TAIL_CAP) s_list[cur ^ 1][pos] = r; else s_overflow = 1;
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        const int32_t nextCount = s_cnt[cur ^ 1];
-        const bool over = s_overflow != 0;
-        __syncthreads();
-        if (tid == 0) s_cnt[cur] = 0;
-        cur ^= 1;
-        if (over) { if (tid == 0) { stats[0] = k; stats[1] = 1; } return; }
-        if ((k + lookahead >= maxPred && nextCount == 0) || k >= maxRounds) break;
-        __syncthreads();
-    }
-    if (tid == 0) { stats[0] = k; stats[1] = (s_cnt[cur] != 0) ? 2 : 0; }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Patch-local solve.  Land cells are grouped in spatial patches of WO_PATCH cells (Morton order); one workgroup
@@ -940,21 +764,12 @@ __global__ __launch_bounds__(WO_BLOCK) void k_slot_scatter(const int32_t* patchO
     WO_GRID_STRIDE(s, L) slotOf[patchOrder[s]] = s;
 }
 
-// pending = land tasks whose round tag is still 0 (recovery after a tail overflow)
-__global__ __launch_bounds__(WO_BLOCK) void k_collect_pending(Fields F, const int32_t* landIdx, int32_t L, int32_t* out, int32_t* outCount) {
-    WO_BLOCK_STRIDE(i, valid, L) {
-        bool pend = false; int32_t r = -1;
-        if (valid) { r = landIdx[i]; pend = F.out[r].self.tag == 0; }
-        block_append(pend, r, out, outCount);
-    }
-}
 
 // `masked` (may be null): the thermal step's masked elevation of the new field, written in the same pass
-__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, int32_t* level, float* masked) {
+__global__ __launch_bounds__(WO_BLOCK) void k_solve_final(Fields F, float* out, float* masked) {
     WO_XCD_LAND(i, r) {
         const float v = solve_final_cell(F, r);
         out[r] = v;
-        level[r] = F.out[store_index(F, r)].self.tag;
         if (masked) masked[r] = v;
     }
 }
@@ -996,16 +811,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_thermal_apply(Fields F, float* out
 __global__ __launch_bounds__(WO_BLOCK) void k_glac_index(Fields F, double strength) { WO_XCD_CELLS(r, F.N) F.glac[r] = glac_index_cell(F, r, strength); }
 __global__ __launch_bounds__(WO_BLOCK) void k_ice_receivers(Fields F) {
     WO_XCD_CELLS(r, F.N) { ice_receiver_cell(F, r); F.blocker[r] = 0; if (F.ocean[r]) { F.iceFlow[r] = 0.0f; F.iceUp[r] = 0; } }      // blocker: k_ice_climb's arrival counts (carve_setup_cell resets it)
-}
-__global__ __launch_bounds__(WO_BLOCK) void k_ice_round(Fields F, const int32_t* in, const int32_t* inCount, int32_t* out,
-                                                         int32_t* outCount, int32_t* zeroCount, int32_t round) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zeroCount = 0;
-    const int32_t n = *inCount;
-    WO_BLOCK_STRIDE(i, valid, n) {
-        bool pending = false; int32_t t = -1;
-        if (valid) { t = in[i]; pending = !ice_accumulate_task(F, t, round); }
-        block_append(pending, t, out, outCount);
-    }
 }
 // ---- in-launch hand-offs between workgroups (MI355X: a CU's L1 is never refreshed by other CUs' stores and the eight XCD L2s are not
 // coherent with each other): every word that crosses between threads inside one launch is written AND read at agent scope
@@ -1094,13 +899,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_ice_climb(Fields F, int32_t* arriv
     }
 }
 
-__global__ __launch_bounds__(WO_BLOCK) void k_carve_setup(Fields F, int32_t* list, int32_t* count) {
-    WO_BLOCK_STRIDE(r, valid, F.N) {
-        bool act = false;
-        if (valid) { carve_setup_cell(F, r); act = F.arank[r] != WO_NOT_DONE; }
-        block_append(act, r, list, count);
-    }
-}
 __global__ __launch_bounds__(WO_BLOCK) void k_carve_setup_cells(Fields F) {          // the list comes from select_active_by_rank
     WO_XCD_CELLS(r, F.N) carve_setup_cell(F, r);
 }
@@ -1195,82 +993,6 @@ __device__ inline void carve_flow_turn_rows(const Fields& F, int32_t r, double d
         st_agent(&F.e[nb], (float)((double)en - deepening * 0.4 * f));
     }
     if (up >= 2) st_agent(&F.e[r], (float)((double)ld_agent(&F.e[r]) - bonus));
-}
-__global__ __launch_bounds__(WO_BLOCK, 4) void k_carve_flow(Fields F, const CarveRec* __restrict__ recs, int32_t* slotDone, const int32_t* __restrict__ count,
-                                                          int32_t* done, long long budget, int32_t watchMode, int32_t longSleep) {
-    const int32_t n = *count;
-    const int32_t stride = (int32_t)(gridDim.x * blockDim.x);
-    int32_t i = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    const long long t0 = wall_clock64();
-    int32_t finished = 0;
-    bool active = i < n;
-    CarveRec R;
-    uint32_t open = 0;
-    bool listed = false;
-    // polling: a task first looks at all its dependencies at once (sweep), then WATCHES the first one still open — the lists are
-    // in descending rank, so that is the one likeliest to finish last — with one load per turn of the loop, and sweeps again when
-    // it is set.  (Sweeping every turn kept ~5 loads per waiting task in flight all the time: the hand-offs on the critical chain
-    // then queue behind the polls of 130 000 other tasks in every CU's memory pipeline — 6.2 us per level instead of ~2.)
-    int32_t watch = -1;                                           // cell whose done word is watched, -1: sweep next
-    if (active) { R = recs[i]; listed = R.depCnt >= 0 && R.deg <= WO_EAGER_ROW; open = listed ? ((1u << R.depCnt) - 1u) : 1u; }
-    for (;;) {
-        if (active) {
-            if (listed && watch >= 0 && watchMode) {
-                if (ld_agent(&F.doneAt[watch]) != WO_NOT_DONE) watch = -1;      // sweep in the next turn
-            } else if (listed) {
-                int32_t da[WO_CARVE_DEPS];
-#pragma unroll
-                for (int k = 0; k < WO_CARVE_DEPS; ++k) da[k] = ((open >> k) & 1u) ? ld_agent(&F.doneAt[R.deps[k]]) : 0;
-#pragma unroll
-                for (int k = 0; k < WO_CARVE_DEPS; ++k) if (((open >> k) & 1u) && da[k] != WO_NOT_DONE) open &= ~(1u << k);
-                if (open) {
-                    const int first = __ffs(open) - 1;
-                    watch = R.deps[0];
-#pragma unroll
-                    for (int k = 1; k < WO_CARVE_DEPS; ++k) if (k == first) watch = R.deps[k];
-                }
-            } else {
-                open = carve_flow_open_scan(F, R.r) ? 1u : 0u;
-            }
-            if (open == 0) {
-                watch = -1;
-                if (listed) {
-                    float en[WO_EAGER_ROW]; uint8_t on[WO_EAGER_ROW];
-                    const float e0 = ld_agent(&F.e[R.r]);
-#pragma unroll
-                    for (int k = 0; k < WO_EAGER_ROW; ++k) { on[k] = F.ocean[R.nbs[k]]; en[k] = ld_agent(&F.e[R.nbs[k]]); }
-                    const double deepening = R.deepening;
-                    float er = (float)((double)e0 - deepening);
-#pragma unroll
-                    for (int k = 0; k < WO_EAGER_ROW; ++k) {
-                        if (k >= R.deg || on[k]) continue;
-                        const double d = nd_or_eps(R.dist[k]);
-                        const double slope = fabs((double)er - (double)en[k]) / d;
-                        double f = 1 - slope;
-                        if (!(f > 0)) f = (f != f) ? f : 0;
-                        st_agent(&F.e[R.nbs[k]], (float)((double)en[k] - deepening * 0.4 * f));
-                    }
-                    if (R.up >= 2) er = (float)((double)er - R.bonus);
-                    st_agent(&F.e[R.r], er);
-                } else {
-                    carve_flow_turn_rows(F, R.r, R.deepening, R.bonus, R.up);
-                }
-                drain_stores();                                     // the heights are out before the done word is
-                st_agent(&F.doneAt[R.r], 1);
-                slotDone[i] = 1;
-                ++finished;
-                i += stride;
-                active = i < n;
-                if (active) { R = recs[i]; listed = R.depCnt >= 0 && R.deg <= WO_EAGER_ROW; open = listed ? ((1u << R.depCnt) - 1u) : 1u; }
-            } else if (wall_clock64() - t0 > budget) {
-                active = false;                                     // left to the synchronous rounds
-            }
-        }
-        if (!__any(active)) break;
-        if (longSleep) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(2);
-    }
-    for (int o = 32; o > 0; o >>= 1) finished += __shfl_down(finished, o);
-    if ((threadIdx.x & 63) == 0 && finished) atomicAdd(done, finished);
 }
 // ---- the same launch with the heights as self-validating granules ------------------------------------------------------------------
 // k_carve_flow pays four memory round trips per level of the DAG: the finished task's stores must be acknowledged before its done

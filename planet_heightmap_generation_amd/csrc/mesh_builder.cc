@@ -223,7 +223,6 @@ int star_of(int p, const P3* pts, int V, const Grid& g, const Orient& orient, in
         int q = q0;
         for (;;) {
             if (deg >= MAX_STAR) { ok = false; failcode = -2;
-                if (getenv("WO_MESH_DEBUG")) { fprintf(stderr, "p=%d level=%d ncand=%zu q0=%d seq:", p, level, cand.size(), q0); for (int i = 0; i < 16; ++i) fprintf(stderr, " %d", out[i]); fprintf(stderr, "\n"); }
                 break; }
             out[deg++] = q;
             // Jarvis step: r such that every other candidate lies on the origin side of plane (p,q,r)

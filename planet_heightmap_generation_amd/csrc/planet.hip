@@ -36,7 +36,6 @@ void profile_resolve(wo_planet* p) {
     if (p->pending.empty()) return;
     WO_HIP(hipStreamSynchronize(p->ctx->stream));
     if (p->side) WO_HIP(hipStreamSynchronize(p->side));
-    if (p->side2) WO_HIP(hipStreamSynchronize(p->side2));
     for (auto& pe : p->pending) {
         float ms = 0; WO_HIP(hipEventElapsedTime(&ms, pe.a, pe.b));
         p->famMs[pe.fam] += ms; p->famLaunches[pe.fam] += 1;
@@ -49,7 +48,6 @@ template <class T> static T* dalloc(size_t n) { void* q = nullptr; WO_HIP(hipMal
 template <class T> static void dfree(T*& q) { if (q) { (void)hipFree(q); q = nullptr; } }
 
 constexpr int WO_PATCH_TOTAL_SLOTS = 4096;         // pending-total slots of the patch solve (one per launch, reused modulo)
-constexpr int WO_FLOW_RAKE_ROUNDS = 8;             // rake rounds before the pointer doubling of the flow accumulation (WO_FLOW_CLIMB=0)
 
 
 static void ensure_scratch(wo_planet* p) {
@@ -66,8 +64,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_iceUp = dalloc<uint8_t>(N);
     p->d_listA = dalloc<int32_t>(N); p->d_listB = dalloc<int32_t>(N); p->d_counters = dalloc<int32_t>(8);
     p->d_patchOrder = dalloc<int32_t>(N); p->d_slotOf = dalloc<int32_t>(N); p->d_patchPending = dalloc<int32_t>(N / WO_PATCH + 2); p->d_patchTotals = dalloc<int32_t>(WO_PATCH_TOTAL_SLOTS); p->d_patchBlk = dalloc<int32_t>(N);
-    p->d_level = dalloc<int32_t>(N); p->d_byLevel = dalloc<int32_t>(N); p->d_levelStart = dalloc<int32_t>(WO_MAX_LEVEL + 2);
-    WO_HIP(hipHostMalloc((void**)&p->h_levelStart, (WO_MAX_LEVEL + 2) * sizeof(int32_t)));
+    WO_HIP(hipHostMalloc((void**)&p->h_patchTotals, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t)));          // read-back buffer of run_solve_patches
     p->sortTempBytes = sort_temp_bytes(p->N);
     WO_HIP(hipMalloc(&p->d_sortTemp, std::max<size_t>(p->sortTempBytes, 16)));
     WO_HIP(hipMemsetAsync(p->d_glac, 0, N * sizeof(float), p->ctx->stream));
@@ -79,7 +76,7 @@ static void ensure_scratch(wo_planet* p) {
 wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = opt.tileLds ? 1 : 0; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
-    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = nullptr; F.tr = d_tr; F.ev = opt.noEventLists ? nullptr : d_ev; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
+    F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = nullptr; F.tr = d_tr; F.ev = d_ev; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
     F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
@@ -153,136 +150,6 @@ static int32_t publish_and_wait(wo_planet* p, const int32_t* d_ptr) {
 
 int32_t read_count(wo_planet* p, const int32_t* d_ptr) { return publish_and_wait(p, d_ptr); }
 
-// ---------------------------------------------------------------------------------------------------
-// Synchronous dependency rounds.  Round k reads the list of pending tasks (count in counters[k%3]), runs
-// those whose predecessors finished in rounds < k and appends the rest to the other list (count in
-// counters[(k+1)%3]); counters[(k+2)%3] is zeroed for the round after.  Rounds are launched in batches and
-// the pending count is read back once per batch (the grid is sized by the last known count; counts only
-// shrink).  Returns the number of rounds launched.
-// ---------------------------------------------------------------------------------------------------
-template <class LaunchRound>
-static int64_t run_rounds(wo_planet* p, const int32_t* firstList, int32_t firstCount, bool countOnDevice, int batch,
-                          LaunchRound launchRound, int32_t* firstCountHint = nullptr) {
-    int32_t* c = p->d_counters;
-    hipStream_t s = p->ctx->stream;
-    bool hinted = false;
-    if (countOnDevice) {
-        // caller left the count in c[3]; move it to c[1], clear c[0], c[2]
-        WO_HIP(hipMemcpyAsync(c + 1, c + 3, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        WO_HIP(hipMemsetAsync(c, 0, sizeof(int32_t), s));
-        WO_HIP(hipMemsetAsync(c + 2, 0, sizeof(int32_t), s));
-        // The count only sizes the grid (the kernels read it on the device and stride over their list): a caller whose first
-        // list barely changes between calls passes last call's count instead of paying a stream synchronisation for this one;
-        // the true count comes back with the first batch's read-back.
-        if (firstCountHint && *firstCountHint > 0) { firstCount = *firstCountHint + *firstCountHint / 4 + 1024; hinted = true; }
-        else firstCount = read_count(p, c + 1);
-    } else {
-        hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, firstCount, 0, 0);
-    }
-    int32_t count = firstCount;
-    int64_t k = 1;
-    const int32_t* in = firstList;
-    int32_t* out = p->d_listA;
-    while (count > 0) {
-        const int grid = blocks_for(count, 2048);
-        for (int b = 0; b < batch; ++b, ++k) {
-            launchRound((int32_t)k, in, (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), grid);
-            in = out;
-            out = (out == p->d_listA) ? p->d_listB : p->d_listA;
-        }
-        int32_t next;
-        if (firstCountHint && countOnDevice) {               // c[3] still holds the first list's count
-            WO_HIP(hipMemcpyAsync(p->h_count, c, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            WO_HIP(hipStreamSynchronize(s));
-            next = p->h_count[k % 3];
-            *firstCountHint = p->h_count[3];
-        } else next = read_count(p, c + (k % 3));
-        if (k > 4 * (int64_t)p->N + 1024) throw HipError{"dependency rounds do not converge"};
-        count = next;
-    }
-    (void)hinted;
-    return k - 1;
-}
-
-// Solve rounds with level prediction: round k examines the leftovers of earlier rounds plus the bucket of
-// tasks that completed in round k during the previous erosion iteration (sort_by_level).  Any schedule
-// that respects the dependencies produces the same bits (the dataflow is single-assignment), so a wrong
-// prediction only costs re-examinations.
-constexpr int WO_LOOKAHEAD = 3;
-static int64_t run_solve_rounds(wo_planet* p, const Fields& F, double K, double m, double dt, int64_t* examined, int64_t* tailRounds) {
-    sort_by_level(p);
-    const int32_t* ls = p->h_levelStart;
-    int32_t maxPred = 1;
-    for (int32_t l = 1; l <= WO_MAX_LEVEL; ++l) if (ls[l + 1] > ls[l]) maxPred = l;
-    // largest predicted bucket at or above each level: decides when the single-workgroup tail can take over
-    static thread_local std::vector<int32_t> sufMax;
-    sufMax.assign(WO_MAX_LEVEL + 3, 0);
-    for (int32_t l = WO_MAX_LEVEL; l >= 1; --l) sufMax[l] = std::max(sufMax[l + 1], ls[l + 1] - ls[l]);
-    int32_t* c = p->d_counters;
-    hipStream_t s = p->ctx->stream;
-    hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
-    const int batch = 16;
-    int64_t k = 1;
-    int32_t leftKnown = 0;
-    const int32_t* in = p->d_listB;
-    int32_t* out = p->d_listA;
-    const bool tailEnabled = true;
-    for (;;) {
-        for (int b = 0; b < batch; ++b, ++k) {
-            // tasks enter WO_LOOKAHEAD rounds ahead of their predicted level: a few cheap re-examinations buy
-            // back the rounds that cascaded mispredictions would add (emulator: 1393 -> 1047 rounds, optimum 1023)
-            const int64_t loL = (k == 1) ? 1 : std::min<int64_t>(k + WO_LOOKAHEAD, WO_MAX_LEVEL + 1);
-            const int64_t hiL = std::min<int64_t>(k + WO_LOOKAHEAD, WO_MAX_LEVEL);
-            const int32_t bc = (hiL >= loL) ? ls[hiL + 1] - ls[loL] : 0;
-            const int32_t* bucket = p->d_byLevel + ((hiL >= loL) ? ls[loL] : 0);
-            const int grid = blocks_for((int64_t)bc + 2 * (int64_t)leftKnown + 1024, 2048);
-            launch(p, FAM_SOLVE_ROUND, k_solve_round, grid, WO_BLOCK, F, in, (const int32_t*)(c + (k % 3)), bucket, bc, out,
-                   c + ((k + 1) % 3), c + ((k + 2) % 3), (int32_t)k, K, m, dt);
-            if (examined) *examined += bc;
-            in = out;
-            out = (out == p->d_listA) ? p->d_listB : p->d_listA;
-        }
-        leftKnown = read_count(p, c + (k % 3));
-        if (examined) *examined += (int64_t)leftKnown * batch;       // rough: leftovers are re-examined every round
-        if (k + WO_LOOKAHEAD > maxPred && leftKnown == 0) break;
-        if (k > 4 * (int64_t)p->N + 1024) throw HipError{"solve rounds do not converge"};
-        // hand the tail to one workgroup when what is left is thin: few leftovers and only small buckets ahead
-        const int64_t nextLevel = std::min<int64_t>(k + WO_LOOKAHEAD, WO_MAX_LEVEL + 1);
-        if (tailEnabled && leftKnown <= WO_TAIL_CAP / 4 && sufMax[nextLevel] <= WO_TAIL_CAP / 8) {
-            int32_t* stats = c + 4;
-            WO_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), s));
-            launch(p, FAM_SOLVE_TAIL, k_solve_tail, 1, WO_TAIL_THREADS, F, in, (const int32_t*)(c + (k % 3)), (const int32_t*)p->d_byLevel,
-                   (const int32_t*)p->d_levelStart, (int32_t)k, maxPred, (int32_t)WO_LOOKAHEAD, (int32_t)WO_MAX_LEVEL,
-                   (int32_t)std::min<int64_t>(k + 65536, 2000000000), stats, K, m, dt);
-            WO_HIP(hipMemcpyAsync(p->h_count, stats, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            WO_HIP(hipStreamSynchronize(s));
-            const int32_t lastRound = p->h_count[0], flag = p->h_count[1];
-            if (tailRounds) *tailRounds += std::max<int64_t>(0, lastRound - (k - 1));
-            if (flag == 0) { k = (int64_t)lastRound + 1; break; }
-            // overflow (or round cap): rebuild the pending list from the round tags and continue one launch per round;
-            // every still-pending task is re-listed, so the predicted buckets are not used again in this pass
-            k = (int64_t)lastRound + 1;
-            WO_HIP(hipMemsetAsync(c, 0, 3 * sizeof(int32_t), s));
-            launch(p, FAM_MISC, k_collect_pending, blocks_for(p->L, 2048), WO_BLOCK, F, (const int32_t*)p->d_landIdx, p->L, p->d_listA, c + (k % 3));
-            in = p->d_listA; out = p->d_listB;
-            leftKnown = read_count(p, c + (k % 3));
-            for (;;) {
-                if (leftKnown == 0) break;
-                for (int b = 0; b < batch; ++b, ++k) {
-                    launch(p, FAM_SOLVE_ROUND, k_solve_round, blocks_for(2 * (int64_t)leftKnown + 1024, 2048), WO_BLOCK, F, in,
-                           (const int32_t*)(c + (k % 3)), (const int32_t*)p->d_byLevel, 0, out, c + ((k + 1) % 3), c + ((k + 2) % 3), (int32_t)k, K, m, dt);
-                    in = out;
-                    out = (out == p->d_listA) ? p->d_listB : p->d_listA;
-                }
-                leftKnown = read_count(p, c + (k % 3));
-                if (k > 4 * (int64_t)p->N + 1024) throw HipError{"solve rounds do not converge"};
-            }
-            break;
-        }
-    }
-    return k - 1;
-}
-
 // Patch-local solve driver: launches k_solve_patch until no task is pending.  Returns the number of launches.
 // basin: the store order is the group-major one of basin_layout() and the first launch of the pass is k_solve_basin, which
 // normally leaves nothing pending; whatever it does leave (layout off: see basin.hip) is finished by k_solve_patch launches.
@@ -328,13 +195,12 @@ static int64_t run_solve_patches(wo_planet* p, const Fields& F, double K, double
             }
             ++launches;
         }
-        static_assert(WO_PATCH_TOTAL_SLOTS <= WO_MAX_LEVEL + 2, "h_levelStart doubles as the read-back buffer of the pending totals");
         if (basin && first == 1 && tag == 2) {                     // the usual case: the one launch of the basin solve, one total to look at
             if (publish_and_wait(p, tot + 1) == 0) need = 1;
         } else {
-            WO_HIP(hipMemcpyAsync(p->h_levelStart, tot, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            WO_HIP(hipMemcpyAsync(p->h_patchTotals, tot, (size_t)WO_PATCH_TOTAL_SLOTS * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             WO_HIP(hipStreamSynchronize(s));
-            for (int32_t t = first; t < tag && !need; ++t) if (p->h_levelStart[t % WO_PATCH_TOTAL_SLOTS] == 0) need = t;
+            for (int32_t t = first; t < tag && !need; ++t) if (p->h_patchTotals[t % WO_PATCH_TOTAL_SLOTS] == 0) need = t;
         }
         if (need) break;
         if (launches > 4 * (int64_t)p->N + 1024) throw HipError{"patch solve does not converge"};
@@ -493,13 +359,16 @@ static bool flood_device_pass1(wo_planet* p, FloodRun& R) {
     if (ok && hC->notFixed != 0) ok = false;                // cannot happen at termination; refuse the result if it does
     if (ok) {
         R.ties += hC->ties;
-        const bool acceptIdOrder = p->opt.floodTiesById;
-        if (hC->ties > 0 && !acceptIdOrder) ok = false;
+        if (hC->ties > 0) ok = false;
     }
     if (!ok) R.fellBack = true;
     return ok;
 }
 
+// every cell of the planet in Morton order, if the mirror has worked it out (mask-independent, once per planet): the flood's tables filter it
+static const int32_t* morton_if_known(const wo_planet* p) {
+    return (!p->h_xyz.empty() && p->mirror.h_morton.size() == (size_t)p->N) ? p->mirror.h_morton.data() : nullptr;
+}
 static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     hipStream_t s = p->ctx->stream;
     const size_t bytes = (size_t)p->N * sizeof(float);
@@ -516,7 +385,7 @@ static void flood_stage(wo_planet* p, double carveStrength, FloodRun& R) {
     lap("ocean mask");
     FloodScratch& S = p->flood;
     if (!S.staticValid || S.staticN != p->N)
-        flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S);
+        flood_build_static(p->N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), S, morton_if_known(p));
     lap("static");
     if (S.L == 0 && !p->floodX.on) return;       // (a share without land still takes part in the exchange)
     const bool hostOnly = p->floodX.on || !p->opt.floodDevice;
@@ -628,10 +497,17 @@ static void mirror_build(wo_planet* p, const uint8_t* mask = nullptr) {
     if (M.h_morton.empty()) { morton_order_cells(N, p->h_xyz.data(), M.h_morton); lap("morton order"); }
     M.h_perm.resize(N);
     if (mask) {
-        int32_t nl = 0;
-        for (int32_t i = 0; i < N; ++i) nl += mask[M.h_morton[i]] ? 0 : 1;
-        int32_t a = 0, b = nl;
-        for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_morton[i]; if (mask[r]) M.h_perm[b++] = r; else M.h_perm[a++] = r; }
+        // land cells first, each class in Morton order: per range of the Morton list the land count, then both classes written behind the ranges before
+        std::vector<int64_t> cnt(host_threads() + 2, 0);
+        const int32_t* mo = M.h_morton.data();
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) { int64_t c = 0; for (int64_t i = b; i < e; ++i) c += mask[mo[i]] ? 0 : 1; cnt[t + 1] = c; });
+        for (size_t t = 1; t < cnt.size(); ++t) cnt[t] += cnt[t - 1];
+        const int64_t nl = cnt.back();
+        int32_t* perm = M.h_perm.data();
+        parallel_ranges(N, [&](int64_t b, int64_t e, int t) {
+            int64_t a = cnt[t], o = nl + (b - cnt[t]);          // land before this range: cnt[t]; ocean before it: b - cnt[t]
+            for (int64_t i = b; i < e; ++i) { const int32_t r = mo[i]; if (mask[r]) perm[o++] = r; else perm[a++] = r; }
+        });
         M.h_mask.assign(mask, mask + N);
         p->mirrorMaskVersion = ownMask ? p->oceanVersion : -1;
     } else {
@@ -641,7 +517,11 @@ static void mirror_build(wo_planet* p, const uint8_t* mask = nullptr) {
     lap("land-first perm");
     hvec<int32_t> moff((size_t)N + 1);
     moff[0] = 0;
-    for (int32_t i = 0; i < N; ++i) { const int32_t r = M.h_perm[i]; moff[i + 1] = moff[i] + (p->h_off[r + 1] - p->h_off[r]); }
+    {
+        const int32_t* perm = M.h_perm.data(); const int32_t* ho = p->h_off.data(); int32_t* mo = moff.data();
+        parallel_ranges(N, [&](int64_t b, int64_t e, int) { for (int64_t i = b; i < e; ++i) { const int32_t r = perm[i]; mo[i + 1] = ho[r + 1] - ho[r]; } });
+        inclusive_scan_parallel(mo + 1, (int64_t)N);
+    }
     lap("row offsets");
     if (!M.perm) {
         M.perm = dalloc<int32_t>(N); M.inv = dalloc<int32_t>(N); M.off = dalloc<int32_t>((size_t)N + 1); M.adj = dalloc<int32_t>(E + WO_ROW);
@@ -712,6 +592,17 @@ struct MirrorScope {
     ~MirrorScope() { if (on) { point_at_planet(); p->mirror.active = false; } }      // error path: pointers only, the planet's field is what it was at the last suspend
 };
 
+// The planet's side stream (the basin layout beside the flow accumulation).
+static void ensure_side_stream(wo_planet* p) {
+    if (p->side) return;
+    // the layout's chain of short launches is the longer of the two: at equal priority its workgroups queue behind the thousands of
+    // the flow kernels' (a 22 us scatter pass took 108 us beside k_flow_final), so the side stream gets the highest priority
+    int prLeast = 0, prGreatest = 0;
+    WO_HIP(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
+    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prGreatest));
+    WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
+}
+
 // erodeComposite on the resident field (js/terrain-post.js:369-707)
 // Thrown by erode_composite when a basin-solve launch whose result was not checked on the spot turns out to have left tasks pending:
 // the caller restores the field and runs the call again with the check after every pass (erode_composite_checked).
@@ -734,7 +625,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t N = p->N;
     const int gridN = xcd_grid(N);
     StageClock clk(p);
-    int64_t carveFlowLeft = 0, solveRounds = 0, maxSolve = 0, flowRounds = 0, iceRounds = 0, carveRounds = 0, sorts = 0, solveExamined = 0, tailRounds = 0, patchLaunches = 0;
+    int64_t carveFlowLeft = 0, maxSolve = 0, iceRounds = 0, carveRounds = 0, sorts = 0, patchLaunches = 0;
     double floodHostMs = 0;
 
     clk.begin("setup");
@@ -748,7 +639,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         int32_t* hl = reinterpret_cast<int32_t*>(p->h_pinned);
         int32_t L = 0;
         // both lists only depend on the mask (and on whether the call runs on the mirror): a call with the mask of the previous one takes them as they are
-        const bool listsKept = p->d_landInit && p->landListsOcean == p->oceanVersion && p->landListsMirror == mir.on && p->landListsL >= 0 && !p->opt.noLandListCache;
+        const bool listsKept = p->d_landInit && p->landListsOcean == p->oceanVersion && p->landListsMirror == mir.on && p->landListsL >= 0;
         if (listsKept) L = p->landListsL;
         else {
             const uint8_t* oc = p->h_ocean.data();
@@ -767,7 +658,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 WO_HIP(hipMemcpyAsync(p->h_pinned, mir.on ? p->mirror.o_e : p->d_e, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, s));
                 WO_HIP(hipStreamSynchronize(s));
                 if (!p->flood.staticValid || p->flood.staticN != N)
-                    flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), p->flood);
+                    flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_ocean.data(), p->flood, morton_if_known(p));
                 for (int k = 0; k < calls; ++k) {
                     const int rc = flood_host_passes_exchange(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.empty() ? nullptr : p->h_xyz.data(), p->h_pinned, 0.5, p->flood, nullptr, p->floodX);
                     if (rc) throw HipError{"flood exchange: the host's exchange function failed (status " + std::to_string(rc) + ")"};
@@ -804,11 +695,10 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
         p->landCur = 0;
         launch(p, FAM_MISC, k_init_rank, gridN, WO_BLOCK, p->d_rank, N);
         rank_from_land(p);      // thermal-only runs never sort: landCells stays in ascending-r order
-        launch(p, FAM_MISC, k_fill_i32, gridN, WO_BLOCK, p->d_level, 1, N);   // no level history yet: everything in round 1
         // spatial patches for the patch-local solve: land cells in Morton order (shared with the host flood's layout)
-        if (hIters > 0 && !p->h_xyz.empty() && !p->opt.noSolvePatch) {
+        if (hIters > 0) {
             if (!p->flood.staticValid || p->flood.staticN != N)
-                flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood);
+                flood_build_static(N, p->h_off.data(), p->h_adj.data(), p->h_xyz.data(), p->h_ocean.data(), p->flood, morton_if_known(p));
             if (p->patchVersion != p->flood.staticVersion || p->patchMirror != mir.on) {
                 p->patchMirror = mir.on;
                 if (mir.on) WO_HIP(hipMemcpyAsync(p->d_patchOrder, p->d_landIdx, (size_t)L * sizeof(int32_t), hipMemcpyDeviceToDevice, s));   // ascending mirror id IS Morton order
@@ -871,46 +761,17 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     const int32_t midIter = (int32_t)std::floor(total * 0.75 + 0.5);
     bool midDone = false;
     // (round 2's river-aligned patch lists, WO_RIVER_PATCHES, were measured and dropped: profiles/r02c_river_patch_experiment.txt)
-    const bool basinSolve = true;          // (k_solve_patch launches remain as the finisher of tasks a basin launch leaves pending)
     int64_t basinPasses = 0, basinLeftoverPasses = 0, carveActive = 0;
-    int32_t flowCountHint = 0;         // size of the pointer doubling's first list in the previous iteration (run_rounds)
 
     const bool stageAll = p->opt.stageTimingAll;
-    // One composite iteration as a hipGraph.  Outside the glacial iterations and the flood, an iteration with both the hydraulic and
-    // the thermal step is the same ~25 launches on two streams with the same arguments every time (the elevation buffers swap
-    // twice, every radix sort has an even number of passes, the solve launch's tag is constant): it is captured once per call —
-    // the side stream's fork and join become dependencies of the graph — and replayed, which takes the host out of the loop.
-    // MEASURED SLOWER on ROCm 7.2 / MI355X (10 M cells, 200 iterations, 167 of them replayed: 499.5 ms per step against 384.1 with
-    // plain launches, profiles/r04j_*; same field, CRC checked): a graph launch costs more than the ~25 stream launches it
-    // replaces, whose gaps (~130 us of a 1.35 ms iteration) the host already hides by running ahead of the device.  Off by
-    // default; WO_GRAPH=1 switches it on (test_graph_replay_route_agrees).  Iterations whose stages are timed (every 8th),
-    // profiled runs and every other cross-check route always take the plain path.
-    struct IterGraph {
-        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        ~IterGraph() { if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
-    } iterGraph;
-    const Options& O = p->opt;
-    const bool graphRoute = O.graphs && !p->profiling && !checkEveryPass && basinSolve && p->patchVersion >= 0 && O.flowClimbCap == 0x7fffffff && !O.flowEventsStream &&
-                            !O.noEventLists && !O.basinStats && !O.sortLibrary && O.relaxedSortEvery <= 1 && p->maxDeg <= 16 && total > 16;
-    int64_t graphReplays = 0;
+    // (one composite iteration as a hipGraph — captured once per call, replayed 167 times — was built and measured in round 4: 499.5 ms per step against 384.1 with
+    // plain launches, profiles/r04j_*: a graph launch costs more than the ~25 stream launches it replaces; removed in round 6)
     bool sortAfterFlood = false;
     for (int32_t iter = 0; iter < total; ++iter) {
         clk.on = true;
         if (!midDone && iter >= midIter) { midDone = true; flood(0.85); sortAfterFlood = true; }
         clk.on = stageAll || p->profiling || total <= 16 || iter % 8 == 0;
         const bool gNow = iter < gIters && glacial, hNow = iter < hIters;
-        const bool graphable = graphRoute && !clk.on && !gNow && hNow && iter < tIters && iter >= 2 && p->side != nullptr;
-        if (graphable && iterGraph.exec) {
-            WO_HIP(hipGraphLaunch(iterGraph.exec, s));
-            ++graphReplays; ++sorts; ++basinPasses; ++patchLaunches; maxSolve = std::max<int64_t>(maxSolve, 1); ++p->basinLaunches;
-            for (const char* st : {"sort", "receivers", "flow", "solve", "thermal"}) clk.count_only(st);
-            continue;
-        }
-        const bool capturing = graphable;
-        if (capturing) WO_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        struct CaptureGuard {       // an exception inside a capture must not leave the stream capturing
-            hipStream_t s; bool on; ~CaptureGuard() { if (on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } }
-        } captureGuard{s, capturing};
         // WO_RELAXED_SORT_EVERY=K (relaxed mode, NOT the reference's semantics: SURVEY 7.3): landCells is re-sorted only every K-th
         // iteration; in between the passes run with a stale visiting order (still a consistent order: every pass compares ranks
         // pairwise, so the dataflow is well defined, it is just not the reference's).  Measured, never reported as parity.
@@ -923,30 +784,16 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             clk.begin("glacial");
             Fields F = p->fields();
             launch(p, FAM_ICE_RECV, k_ice_receivers, gridN, WO_BLOCK, F);
-            // ice accumulation: one launch in which the last donor to arrive runs its receiver's task (k_ice_climb);
-            // WO_ICE_ROUNDS=1: the synchronous rounds of earlier builds (cross-check)
-            const bool iceRoundsEnv = p->opt.iceRounds;
-            if (!iceRoundsEnv) { launch(p, FAM_ICE_ROUND, k_ice_climb, gridL, WO_BLOCK, F, F.blocker); ++iceRounds; }
-            else iceRounds += run_rounds(p, p->d_landIdx, L, false, 8,
-                [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
-                    launch(p, FAM_ICE_ROUND, k_ice_round, grid, WO_BLOCK, F, in, inC, out, outC, zeroC, k);
-                });
+            // ice accumulation: one launch in which the last donor to arrive runs its receiver's task (k_ice_climb)
+            launch(p, FAM_ICE_ROUND, k_ice_climb, gridL, WO_BLOCK, F, F.blocker); ++iceRounds;
             if (relaxedFull) {          // RELAXED: the carve from a snapshot of the heights, one sweep
                 launch(p, FAM_CARVE_ROUND, k_carve_jacobi, gridL, WO_BLOCK, F, (const float*)p->d_e, p->d_e2, gCarve, gConv, gStrength);
                 swap_elev(p);
                 launch(p, FAM_MORAINE, k_moraine_fjord, gridN, WO_BLOCK, p->fields(), gDep, gFjord);
                 clk.end();
             } else {
-            // WO_CARVE_FLOW=0: no one-launch carve (k_carve_flow), activation list in arrival order as in earlier builds
-            const int carveFlowMode = p->opt.carveFlow;      // 2: heights as granules (k_carve_granules), 1: done words (k_carve_flow), 0: rounds
-            const bool carveFlow = carveFlowMode != 0;
-            if (carveFlow) {
-                launch(p, FAM_CARVE_SETUP, k_carve_setup_cells, gridN, WO_BLOCK, F);
-                select_active_by_rank(p, F.arank, p->d_listB, p->d_counters + 3);     // the active tasks in landCells order
-            } else {
-                WO_HIP(hipMemsetAsync(p->d_counters + 3, 0, sizeof(int32_t), s));
-                launch(p, FAM_CARVE_SETUP, k_carve_setup, gridN, WO_BLOCK, F, p->d_listB, p->d_counters + 3);
-            }
+            launch(p, FAM_CARVE_SETUP, k_carve_setup_cells, gridN, WO_BLOCK, F);
+            select_active_by_rank(p, F.arank, p->d_listB, p->d_counters + 3);     // the active tasks in landCells order
             int32_t activeTasks = 0;
             {   // dependency lists of the active tasks (once per glacial step)
                 const int32_t active = read_count(p, p->d_counters + 3);
@@ -960,22 +807,20 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     p->d_carveRecs = dalloc<CarveRec>((size_t)p->carveCap); p->d_carveSlotDone = dalloc<int32_t>((size_t)p->carveCap); p->d_carveExpect = dalloc<CarveExpect>((size_t)p->carveCap);
                 }
                 F.carveDeps = p->d_carveDeps; F.carveDepCnt = p->d_carveDepCnt; F.carveDepPos = p->d_carveDepPos;
-                // the dependency lists (a two-hop walk per task) are for the done-word launch and the rounds; the granule launch waits on the
-                // heights themselves and makes the lists only if it leaves tasks to the rounds
-                if (active > 0 && carveFlowMode != 2)
-                    launch(p, FAM_CARVE_SETUP, k_carve_deps, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveSlot);
+                // (the dependency lists — a two-hop walk per task — are for the rounds: the granule launch waits on the heights themselves and the lists are only
+                // made if it leaves tasks to the rounds)
                 if (active > 0)
                     launch(p, FAM_CARVE_SETUP, k_carve_records, blocks_for(active), WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(p->d_counters + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength,
-                           (int32_t)(carveFlowMode == 2 ? 0 : carveFlowMode == 1 ? 2 : 1), (int32_t)1);
+                           (int32_t)0, (int32_t)1);
             }
             {
                 int32_t* c = p->d_counters;
                 const int32_t count = activeTasks;
                 int64_t k = 1;
-                // The one launch (k_carve_granules / k_carve_flow), then — for whatever it leaves, and as the WO_CARVE_FLOW=0 route — rounds
-                // over the static activation list (k_carve_round_static): every launch covers all active tasks, a finished one leaves
-                // after one load, an open one issues its loads at once; the number of finished tasks is read back after a burst.
-                // (Round 2 also tried all rounds in ONE cooperative launch with a grid barrier: slower, profiles/r02f_persistent_rounds_grid.txt.)
+                // The one launch (k_carve_granules), then — for whatever it leaves — rounds over the static activation list (k_carve_round_static): every
+                // launch covers all active tasks, a finished one leaves after one load, an open one issues its loads at once; the number of finished tasks
+                // is read back after a burst.  (Round 2 also tried all rounds in ONE cooperative launch with a grid barrier: slower,
+                // profiles/r02f_persistent_rounds_grid.txt; the done-word form of the one launch, k_carve_flow, and the rounds-only route were removed in round 6.)
                 if (count > 0) {
                     const int32_t active = count;
                     int32_t* done = c + 4;
@@ -985,41 +830,32 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                     // finished tasks is read back every 32 rounds (a read-back costs about as much as three empty rounds)
                     constexpr int burst = 32;
                     bool allDone = false;
-                    if (carveFlow) {
-                        // every task in one launch (k_carve_flow); the grid is what is certainly resident at once: the occupancy
-                        // query's blocks per CU less one (the query is known to answer one too many near register-file edges)
+                    {
+                        // every task in one launch; the grid is what is certainly resident at once: the occupancy query's blocks per CU less one
+                        // (the query is known to answer one too many near register-file edges)
                         static int flowBlocks = 0;
                         if (!flowBlocks) {
                             int perCu = 0, dev = 0; hipDeviceProp_t prop;
-                            int perCuG = 0;
-                            WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_carve_flow, WO_BLOCK, 0));
-                            WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCuG, k_carve_granules, WO_BLOCK, 0));
-                            perCu = std::min(perCu, perCuG);
+                            WO_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_carve_granules, WO_BLOCK, 0));
                             WO_HIP(hipGetDevice(&dev)); WO_HIP(hipGetDeviceProperties(&prop, dev));
                             flowBlocks = std::max(1, std::min(perCu, 8) - 1) * prop.multiProcessorCount;
                         }
-                        // WO_CARVE_FLOW_BLOCKS=<n> (test hook, read per step): at most n workgroups, so that every thread takes many tasks in turn
-                        const int blocksNow = p->opt.carveFlowBlocks > 0 ? std::max(1, std::min(flowBlocks, p->opt.carveFlowBlocks)) : flowBlocks;
-                        constexpr int32_t flowWatch = 1, flowSleep = 0;
-                        const long long flowBudget = p->opt.carveFlowBudgetMs * 100000ll;   // 100 MHz ticks
-                        if (carveFlowMode == 2) {
-                            if (!p->d_carveG) p->d_carveG = dalloc<unsigned long long>((size_t)N);
-                            launch(p, FAM_CARVE_SETUP, k_carve_expect, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const int32_t*)(c + 3), p->d_carveExpect);
-                            launch(p, FAM_CARVE_SETUP, k_carve_pack, blocks_for(N, 4096), WO_BLOCK, (const float*)F.e, p->d_carveG, N);
-                            launch(p, FAM_CARVE_ROUND, k_carve_granules, std::min(grid, blocksNow), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const CarveExpect*)p->d_carveExpect, p->d_carveG,
-                                   p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget);
-                            launch(p, FAM_CARVE_SETUP, k_carve_unpack, blocks_for(N, 4096), WO_BLOCK, (const unsigned long long*)p->d_carveG, F.e, N);
-                        } else
-                        launch(p, FAM_CARVE_ROUND, k_carve_flow, std::min(grid, blocksNow), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget, flowWatch, flowSleep);
+                        // hook carve_blocks=<n>: at most n workgroups, so that every thread takes many tasks in turn
+                        const int blocksNow = p->opt.carveBlocks > 0 ? std::max(1, std::min(flowBlocks, p->opt.carveBlocks)) : flowBlocks;
+                        const long long flowBudget = p->opt.carveBudgetMs * 100000ll;   // 100 MHz ticks
+                        if (!p->d_carveG) p->d_carveG = dalloc<unsigned long long>((size_t)N);
+                        launch(p, FAM_CARVE_SETUP, k_carve_expect, grid, WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const int32_t*)(c + 3), p->d_carveExpect);
+                        launch(p, FAM_CARVE_SETUP, k_carve_pack, blocks_for(N, 4096), WO_BLOCK, (const float*)F.e, p->d_carveG, N);
+                        launch(p, FAM_CARVE_ROUND, k_carve_granules, std::min(grid, blocksNow), WO_BLOCK, F, (const CarveRec*)p->d_carveRecs, (const CarveExpect*)p->d_carveExpect, p->d_carveG,
+                               p->d_carveSlotDone, (const int32_t*)(c + 3), done, flowBudget);
+                        launch(p, FAM_CARVE_SETUP, k_carve_unpack, blocks_for(N, 4096), WO_BLOCK, (const unsigned long long*)p->d_carveG, F.e, N);
                         ++k;
                         const int32_t fin = read_count(p, done);
                         allDone = fin >= active;
-                        if (!allDone) {
+                        if (!allDone) {          // the rounds want the dependency lists after all
                             ++carveFlowLeft;
-                            if (carveFlowMode == 2) {          // the rounds want the dependency lists after all
-                                launch(p, FAM_CARVE_SETUP, k_carve_deps, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), p->d_carveSlot);
-                                launch(p, FAM_CARVE_SETUP, k_carve_records, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength, (int32_t)1, (int32_t)0);
-                            }
+                            launch(p, FAM_CARVE_SETUP, k_carve_deps, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), p->d_carveSlot);
+                            launch(p, FAM_CARVE_SETUP, k_carve_records, grid, WO_BLOCK, F, (const int32_t*)p->d_listB, (const int32_t*)(c + 3), p->d_carveRecs, p->d_carveSlotDone, gCarve, gConv, gStrength, (int32_t)1, (int32_t)0);
                         }
                     }
                     for (; !allDone;) {
@@ -1040,17 +876,14 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             if (gNow && sortNow) { clk.begin("sort"); sort_land_by_elevation(p); ++sorts; clk.end(); }
             Fields F = p->fields();
             F.solveK = K; F.solveM = m; F.solveDt = dt;
-            const bool basin = basinSolve && p->patchVersion >= 0 && !relaxedFull;
-            // the receivers pass also leaves the start state of the layout's component search
-            const bool basinJFromReceivers = basin;
+            const bool basin = !relaxedFull;           // exact mode: the basin-local solve (basin.hip); relaxed mode: the affine recurrence below
             const bool slotIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;          // land-first mirror: a land cell's Morton slot is its id
-            if (basinJFromReceivers) { basin_alloc(p); F.basinJ = p->d_basinJ; F.basinMslot = slotIdentity ? nullptr : p->d_slotOf; }
-            const bool basinOverlap = true;
-            const int climbCap = p->opt.flowClimbCap;
-            const bool climbAll = climbCap == 0x7fffffff;
-            if (climbAll) F.accA = nullptr;            // no pointer doubling after the one-launch climb: the receivers pass does not write its accumulator
-            // two-level accumulation (k_flow_tiles): needs the land cells to be the ids 0 .. L-1 in Morton order (land-first mirror)
-            const bool flowTiles = climbAll && p->landIdentity && !p->opt.flowClimbOnly;
+            // the receivers pass also leaves the start state of the layout's component search
+            if (basin) { basin_alloc(p); F.basinJ = p->d_basinJ; F.basinMslot = slotIdentity ? nullptr : p->d_slotOf; }
+            F.accA = nullptr;                          // (the accumulator of round 2's pointer doubling: not written any more)
+            // two-level accumulation (k_flow_tiles): needs the land cells to be the ids 0 .. L-1 in Morton order (land-first mirror); on the planet's
+            // own cell order (WO_LAYOUT=index) the one-launch climb over all cells (k_flow_climb)
+            const bool flowTiles = p->landIdentity;
             FlowTiles FT{};
             if (flowTiles) {
                 if (!p->d_ftLr) {
@@ -1061,40 +894,22 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             }
             int32_t* const donorCnt = flowTiles ? (int32_t*)nullptr : p->d_flowCnt;
             bool tilesFirstDone = false, linksDone = false;
-            // three streams: the event lists of the solve (they need the receivers only) are built on a stream of their own beside the flow
-            // accumulation (main) and the basin layout (side); the totals pass after the accumulation is a coalesced sweep, because the
-            // receivers pass flags the few cells that have a late donor.  MEASURED, NOT FASTER, off by default (WO_FLOW_EVENTS_STREAM=1): with
-            // three kernels at once the climb takes 274 us instead of 200, the events 261 instead of ~90, the layout's scatter 75 instead of
-            // 27, and the setup starts at the same moment (profiles/r03bc_*): these "latency-bound" launches do fill the memory pipelines
-            // when two of them already run side by side.  Default: k_flow_final after the accumulation.
             // unchecked basin pass: its one launch tags what it produces with a number no earlier pass of this planet used
-            const bool passTagged = basin && !checkEveryPass && F.ev != nullptr && !graphRoute;      // (a replayed graph launches with the captured tag)
-            const bool eventsStreamEnv = p->opt.flowEventsStream;
-            const bool eventsStream = eventsStreamEnv && basin && basinOverlap && climbAll && F.ev;
-            if (eventsStream) {
-                if (!p->d_lateDonor) { p->d_lateDonor = dalloc<uint8_t>((size_t)N); WO_HIP(hipMemsetAsync(p->d_lateDonor, 0, (size_t)N, s)); }
-                F.lateDonor = p->d_lateDonor;
-            }
+            const bool passTagged = basin && !checkEveryPass;
             clk.begin("receivers");
             launch(p, FAM_RECEIVERS, k_receivers_flow_init, gridL, WO_BLOCK, F, donorCnt);        // + flow start state and donor counts
             clk.end();
             F.basinJ = nullptr;
             // basin-local solve (basin.hip): this pass's store order groups every drainage component with everything it depends on.
-            // The layout needs the receivers only and touches none of the flow accumulation's arrays, and both are chains of
-            // latency-bound launches that leave most of the chip idle: the layout runs on the planet's side stream beside the flow
-            // accumulation and the solve's setup waits for both (WO_BASIN_OVERLAP=0: one after the other on the main stream).
-            if (basin && basinOverlap) {
-                if (!p->side) {
-                    // the layout's chain of short launches is the longer of the two: at equal priority its workgroups queue behind the thousands of
-                    // the flow kernels' (a 22 us scatter pass took 108 us beside k_flow_final), so the side stream gets the highest priority
-                    int prLeast = 0, prGreatest = 0;
-                    WO_HIP(hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest));
-                    WO_HIP(hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prGreatest));
-                    WO_HIP(hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming)); WO_HIP(hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
-                }
+            // The layout needs the receivers only and touches none of the flow accumulation's arrays: it runs on the planet's side stream
+            // beside the flow accumulation and the solve's setup waits for both.  (A third stream for the solve's event lists was measured in
+            // round 3 and a side stream for the elevation sort in round 6 — profiles/r03bc_*, r06d_*: no faster, a launch of these sizes already
+            // occupies the chip's workgroup slots and two side by side take turns; both removed.)
+            if (basin) {
+                ensure_side_stream(p);
                 // two-level flow accumulation: its first kernel also shortens the layout's start state inside every tile (k_flow_tiles<false>:
                 // J[c] <- an ancestor at most a tile away), so the layout's component search starts after it, from chains of tiles instead of cells
-                const bool tilesFeedLayout = flowTiles && basinJFromReceivers && slotIdentity;
+                const bool tilesFeedLayout = flowTiles && slotIdentity;
                 if (tilesFeedLayout) {
                     FT.basinJ = p->d_basinJ;
                     launch(p, FAM_FLOW_TILES, k_flow_tiles<false>, (int)(((int64_t)L + FT_CELLS - 1) / FT_CELLS), FT_THREADS, F, FT);
@@ -1109,24 +924,12 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 try { basin_layout(p, slotIdentity); } catch (...) { p->onSide = false; throw; }
                 p->onSide = false;
                 WO_HIP(hipEventRecord(p->evJoin, p->side));
-                if (eventsStream) {
-                    if (!p->side2) { WO_HIP(hipStreamCreateWithFlags(&p->side2, hipStreamNonBlocking)); WO_HIP(hipEventCreateWithFlags(&p->evJoin2, hipEventDisableTiming)); }
-                    WO_HIP(hipStreamWaitEvent(p->side2, p->evFork, 0));
-                    hipStream_t keep = p->side; p->side = p->side2; p->onSide = true;          // launch() follows cur_stream(): the planet's side stream slot
-                    try { launch(p, FAM_FLOW_FINAL, k_flow_events, gridL, WO_BLOCK, F, passTagged ? (SolveOut*)nullptr : p->d_out); } catch (...) { p->side = keep; p->onSide = false; throw; }
-                    p->side = keep; p->onSide = false;
-                    WO_HIP(hipEventRecord(p->evJoin2, p->side2));
-                }
             }
             clk.begin("flow");
-            // Flow accumulation = subtree sizes of the forward forest (integers: any order of the additions is exact).
-            //  default           one launch: every leaf hands its total to its receiver and the thread that completes a receiver
-            //                    carries on with it (k_flow_climb).  Every cell with a forward receiver is retired this way, so
-            //                    nothing is left for the pointer doubling; k_flow_final reads the packed totals.
-            //  WO_FLOW_CLIMB=n   a thread carries on for at most n cells; the rest by pointer doubling (cross-check / terrain with
-            //                    very long unbranched chains, where one thread's walk would bound the launch)
-            //  WO_FLOW_CLIMB=0   the synchronous rake rounds + pointer doubling of earlier builds
-            // 10 M cells, flow stage per step: rake rounds 108 ms, cap 12: 69, cap 128: 60, cap 256: 59, no cap: 45 (profiles/r02r_*).
+            // Flow accumulation = subtree sizes of the forward forest (integers: any order of the additions is exact): in two levels under the mirror
+            // (kernels_impl.h: k_flow_tiles), else one launch in which every leaf hands its total to its receiver and the thread that completes a
+            // receiver carries on with it (k_flow_climb).  Every cell with a forward receiver is retired either way; k_flow_final reads the packed totals.
+            // (10 M cells, flow stage per step: round 2's rake rounds + pointer doubling 108 ms, the climb 45, two levels 29: profiles/r02r_*, r05g_*.)
             if (flowTiles) {
                 const int tiles = (int)(((int64_t)L + FT_CELLS - 1) / FT_CELLS);
                 if (!tilesFirstDone) launch(p, FAM_FLOW_TILES, k_flow_tiles<false>, tiles, FT_THREADS, F, FT);
@@ -1134,40 +937,13 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 launch(p, FAM_FLOW_TILES, k_flow_root_climb, blocks_for(L, 4096), WO_BLOCK, F, FT);
                 launch(p, FAM_FLOW_TILES, k_flow_tiles<true>, tiles, FT_THREADS, F, FT);
             } else
-            if (climbCap > 0) launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, (const int32_t*)p->d_flowCnt, (int32_t)climbCap);
-            if (!climbAll) {
-                {   // rake: WO_FLOW_RAKE_ROUNDS rounds retire the hillslope branches (no readback: the lists only shrink)
-                    int32_t* c = p->d_counters;
-                    hipLaunchKernelGGL(k_set_counters, dim3(1), dim3(1), 0, s, c, 0, 0, 0, 0);
-                    const int32_t* in = p->d_landIdx;
-                    constexpr int rakeRounds = WO_FLOW_RAKE_ROUNDS;
-                    for (int k = 1; k <= rakeRounds && climbCap == 0; ++k) {
-                        int32_t* out = (in == p->d_listB) ? p->d_listA : p->d_listB;
-                        launch(p, FAM_FLOW_SNAP, k_flow_rake, blocks_for((L / (k < 3 ? 1 : 4) + 3) / 4, 2048), WO_BLOCK, F, p->d_flowCnt, in,
-                               k == 1 ? (const int32_t*)nullptr : (const int32_t*)(c + (k % 3)), out, c + ((k + 1) % 3), c + ((k + 2) % 3), L);
-                        in = out;
-                    }
-                    WO_HIP(hipMemsetAsync(c + 3, 0, sizeof(int32_t), s));
-                    launch(p, FAM_FLOW_INIT, k_flow_remaining, blocks_for((L + 3) / 4), WO_BLOCK, F, (const int32_t*)p->d_landIdx, L, p->d_listB, c + 3, (int32_t)(climbCap > 0));
-                }
-                // pointer doubling on what is left (the cells queued for the next rake round included); 8 rounds per read-back: a
-                // stream synchronisation costs as much as several empty rounds
-                constexpr int flowBatch = 8;
-                flowRounds += run_rounds(p, p->d_listB, 0, true, flowBatch,
-                    [&](int32_t k, const int32_t* in, const int32_t* inC, int32_t* out, int32_t* outC, int32_t* zeroC, int grid) {
-                        launch(p, FAM_FLOW_SNAP, k_flow_snap, grid, WO_BLOCK, F, in, inC, p->d_snap, p->d_nj);
-                        launch(p, FAM_FLOW_APPLY, k_flow_apply, grid, WO_BLOCK, F, in, inC, (const uint32_t*)p->d_snap,
-                               (const int32_t*)p->d_nj, out, outC, zeroC);
-                    }, &flowCountHint);
-            }
+                launch(p, FAM_FLOW_SNAP, k_flow_climb, gridL, WO_BLOCK, F, (const int32_t*)p->d_flowCnt, (int32_t)0x7fffffff);
             {
                 Fields Ff = F;
-                if (!climbAll) Ff.accCnt = nullptr;              // totals in accA (pointer doubling) instead of the packed words
                 if (relaxedFull) Ff.ev = nullptr;                // (no event lists: the relaxed solve has no order)
-                if (eventsStream) launch(p, FAM_FLOW_FINAL, k_flow_totals, gridL, WO_BLOCK, Ff, donorCnt);
                 // the solve's outputs are cleared (tags 0) only for a pass whose result is checked on the spot (k_solve_patch / k_solve_final read
                 // the tags as launch numbers); the unchecked pass stamps them with a tag of its own instead (passTag below): 16 B per land cell less to write
-                else launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, donorCnt, (basin && !passTagged) ? p->d_out : (SolveOut*)nullptr);
+                launch(p, FAM_FLOW_FINAL, k_flow_final, gridL, WO_BLOCK, Ff, donorCnt, (basin && !passTagged) ? p->d_out : (SolveOut*)nullptr);
             }
             clk.end();
             clk.begin("solve");
@@ -1181,43 +957,27 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                 swap_elev(p);
                 clk.end();
             } else {
-            if (basin) {
-                if (basinOverlap && eventsStream) WO_HIP(hipStreamWaitEvent(s, p->evJoin2, 0));
                 WO_HIP(hipStreamWaitEvent(s, p->evJoin, 0));
                 F.slotOf = p->d_basinSlot;
                 F.solveLean = 1;
                 // (the outputs' tags were cleared by k_flow_final: one coalesced sweep instead of one scattered 16-byte write per task)
-            }
-            bool countersCleared = false, solveFinals = false;
-            if (F.ev) {
                 // the solve launch writes the final heights itself (SolveTask finality flags) when its result is not looked at pass by pass and
                 // no k_solve_final then
-                solveFinals = basin && !checkEveryPass;
+                const bool solveFinals = !checkEveryPass;
                 F.solveFinals = solveFinals ? 1 : 0;
-                // (with the basin solve the setup launch also clears the counters of the solve launch: run_solve_patches' countersCleared)
-                int32_t* zA = basin ? p->d_patchPending : nullptr; const int32_t nA = basin ? p->numPatches : 0;
-                int32_t* zB = basin ? p->d_patchTotals : nullptr; const int32_t nB = basin ? (int32_t)WO_PATCH_TOTAL_SLOTS : 0;
-                if (F.slotOf) launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<true>, gridL, WO_BLOCK, F, zA, nA, zB, nB);
-                else launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<false>, gridL, WO_BLOCK, F, zA, nA, zB, nB);
-                countersCleared = basin;
-            } else
-                launch(p, FAM_SOLVE_SETUP, k_solve_setup, gridL, WO_BLOCK, F);
-            if (p->patchVersion >= 0) {
+                // (the setup launch also clears the counters of the solve launch: run_solve_patches' countersCleared)
+                launch(p, FAM_SOLVE_SETUP, k_solve_setup_batched<true>, gridL, WO_BLOCK, F, p->d_patchPending, (int32_t)p->numPatches, p->d_patchTotals, (int32_t)WO_PATCH_TOTAL_SLOTS);
                 int32_t passTag = 1;
                 if (passTagged) {
                     if (p->solvePassSerial >= 0x3ff00000) { WO_HIP(hipMemsetAsync(p->d_out, 0, (size_t)N * sizeof(SolveOut), s)); p->solvePassSerial = 0; }
                     passTag = (1 << 20) + (int32_t)(++p->solvePassSerial);
                 }
-                const int64_t r = run_solve_patches(p, F, K, m, dt, basin, countersCleared, !checkEveryPass, passTag);
-                if (basin) { ++basinPasses; if (r > 1) ++basinLeftoverPasses; }
+                const int64_t r = run_solve_patches(p, F, K, m, dt, true, true, !checkEveryPass, passTag);
+                ++basinPasses; if (r > 1) ++basinLeftoverPasses;
                 patchLaunches += r; maxSolve = std::max(maxSolve, r);
-            } else {
-                const int64_t r = run_solve_rounds(p, F, K, m, dt, &solveExamined, &tailRounds);
-                solveRounds += r; maxSolve = std::max(maxSolve, r);
-            }
-            if (!solveFinals) launch(p, FAM_SOLVE_FINAL, k_solve_final, gridL, WO_BLOCK, F, p->d_e2, p->d_level, (iter < tIters) ? p->d_me : (float*)nullptr);
-            swap_elev(p);
-            clk.end();
+                if (!solveFinals) launch(p, FAM_SOLVE_FINAL, k_solve_final, gridL, WO_BLOCK, F, p->d_e2, (iter < tIters) ? p->d_me : (float*)nullptr);
+                swap_elev(p);
+                clk.end();
             }
         }
 
@@ -1236,13 +996,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             swap_elev(p);
             clk.end();
         }
-        if (capturing) {
-            captureGuard.on = false;
-            WO_HIP(hipStreamEndCapture(s, &iterGraph.graph));
-            WO_HIP(hipGraphInstantiate(&iterGraph.exec, iterGraph.graph, nullptr, nullptr, 0));
-            WO_HIP(hipGraphLaunch(iterGraph.exec, s));                 // the captured iteration itself
-            ++graphReplays;
-        }
     }
     clk.on = true;
     leftovers_so_far();
@@ -1256,10 +1009,9 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
     if (mir.on) { clk.begin("setup"); mir.finish(); clk.end(); }
     clk.finish();
     p->erodeStats = {{"land_cells", (double)L}, {"mirror_layout", mirrored ? 1.0 : 0.0}, {"iterations", (double)total}, {"sorts", (double)sorts},
-                     {"solve_rounds_total", (double)solveRounds}, {"solve_rounds_max", (double)maxSolve},
-                     {"solve_tasks_examined_est", (double)solveExamined}, {"solve_rounds_in_tail_kernel", (double)tailRounds}, {"solve_patch_launches_total", (double)patchLaunches},
+                     {"solve_launches_max_per_pass", (double)maxSolve}, {"solve_patch_launches_total", (double)patchLaunches},
                      {"solve_basin_passes", (double)basinPasses}, {"solve_basin_passes_with_leftovers", (double)basinLeftoverPasses},
-                     {"flow_rounds_total", (double)flowRounds}, {"flow_two_level", (p->d_ftLr && p->landIdentity && !p->opt.flowClimbOnly && p->opt.flowClimbCap == 0x7fffffff && hIters > 0) ? 1.0 : 0.0}, {"ice_rounds_total", (double)iceRounds},
+                     {"flow_two_level", (p->d_ftLr && p->landIdentity && hIters > 0) ? 1.0 : 0.0}, {"ice_rounds_total", (double)iceRounds},
                      {"carve_rounds_total", (double)carveRounds}, {"carve_active_total", (double)carveActive}, {"carve_flow_launches_with_leftovers", (double)carveFlowLeft}, {"solve_check_every_pass", checkEveryPass ? 1.0 : 0.0}, {"calls_run_again_with_checks", (double)p->redoCalls}, {"flood_stage_ms", floodHostMs},
                      {"flood_device_pass1_ms", floodRun.deviceMs}, {"flood_device_rounds", (double)floodRun.rounds}, {"flood_device_epochs", (double)floodRun.epochs},
                      {"flood_device_evaluations", (double)floodRun.evals}, {"flood_equal_key_decisions", (double)floodRun.ties},
@@ -1269,7 +1021,7 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
                      {"flood_host_open_parents", (double)floodRun.host.openParents}, {"flood_host_unresolved", (double)floodRun.host.unresolved},
                      {"flood_host_path_redo", (double)floodRun.host.pathRedo}, {"flood_host_replays", (double)floodRun.host.replays}, {"flood_host_replayed_landmasses", (double)floodRun.host.replayedLandmasses}, {"flood_host_pass1_ms", floodRun.host.pass1Ms},
                      {"flood_host_pass23_ms", floodRun.host.pass23Ms},
-                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"relaxed_full", p->opt.relaxedFull ? 1.0 : 0.0}, {"iterations_replayed_from_graph", (double)graphReplays}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}, {"flood_exchange_received", (double)p->floodX.received}};
+                     {"relaxed_sort_every", (double)p->opt.relaxedSortEvery}, {"relaxed_full", p->opt.relaxedFull ? 1.0 : 0.0}, {"flood_exchange_calls", (double)p->floodX.calls}, {"flood_exchange_gathers", (double)p->floodX.gathers}, {"flood_exchange_whole_planet_floods", (double)p->floodX.globalFloods}, {"flood_exchange_received", (double)p->floodX.received}};
 }
 
 static void jacobi(wo_planet* p, int kind, int32_t iterations, double strength) {
@@ -1353,28 +1105,15 @@ Options Options::from_env() {
     auto set = [](const char* n) { return std::getenv(n) != nullptr; };
     Options o;
     o.layoutIndex = str("WO_LAYOUT") == "index";
-    o.sortLibrary = str("WO_SORT") == "hipcub";
-    o.noLandListCache = on("WO_NO_LAND_LIST_CACHE");
-    o.basinBarrierKernel = str("WO_BASIN_KERNEL") == "barrier";
-    o.basinStats = on("WO_BASIN_STATS"); o.basinStatsNoDepth = str("WO_BASIN_STATS") == "2";
-    o.basinScramble = on("WO_BASIN_SCRAMBLE");
     o.tileLds = on("WO_TILE_LDS");
-    o.noSolvePatch = set("WO_NO_SOLVE_PATCH");
-    o.noEventLists = set("WO_NO_EVENT_LISTS");
-    if (set("WO_FLOW_CLIMB")) o.flowClimbCap = std::max(0, std::atoi(std::getenv("WO_FLOW_CLIMB")));
-    o.flowEventsStream = on("WO_FLOW_EVENTS_STREAM");
-    o.flowClimbOnly = str("WO_FLOW") == "climb";
-    o.iceRounds = on("WO_ICE_ROUNDS");
-    if (set("WO_CARVE_FLOW")) o.carveFlow = std::atoi(std::getenv("WO_CARVE_FLOW"));
-    if (set("WO_CARVE_FLOW_BUDGET_MS")) o.carveFlowBudgetMs = std::atoll(std::getenv("WO_CARVE_FLOW_BUDGET_MS"));
-    if (set("WO_CARVE_FLOW_BLOCKS")) o.carveFlowBlocks = std::max(1, std::atoi(std::getenv("WO_CARVE_FLOW_BLOCKS")));
     o.floodDevice = str("WO_FLOOD") == "device";
-    o.floodTiesById = str("WO_FLOOD_TIES") == "id";
     o.floodTiming = set("WO_FLOOD_TIMING");
     o.stageTimingAll = str("WO_STAGE_TIMING") == "all";
-    if (set("WO_GRAPH")) o.graphs = std::atoi(std::getenv("WO_GRAPH")) != 0;
     if (set("WO_RELAXED_SORT_EVERY")) o.relaxedSortEvery = std::max(1, std::atoi(std::getenv("WO_RELAXED_SORT_EVERY")));
     o.relaxedFull = str("WO_RELAXED") == "full";
+    o.basinScramble = test_hook_int("basin_scramble", 0) != 0;
+    o.carveBudgetMs = test_hook_int("carve_budget_ms", 200);
+    o.carveBlocks = (int)std::max<long long>(0, test_hook_int("carve_blocks", 0));
     return o;
 }
 
@@ -1408,8 +1147,7 @@ static void erode_composite_checked(wo_planet* p, int32_t hIters, double K, doub
     } catch (const RedoWithChecks&) {
         WO_HIP(hipStreamSynchronize(s));
         if (p->side) WO_HIP(hipStreamSynchronize(p->side));
-        if (p->side2) WO_HIP(hipStreamSynchronize(p->side2));
-        WO_HIP(hipMemcpyAsync(p->d_e, p->d_redoE, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
+            WO_HIP(hipMemcpyAsync(p->d_e, p->d_redoE, (size_t)p->N * sizeof(float), hipMemcpyDeviceToDevice, s));
         ++p->redoCalls;
         erode_composite(p, hIters, K, m, dt, tIters, talus, kThermal, gIters, gStrength, true);
     }
@@ -1521,9 +1259,6 @@ void wo_planet_destroy(wo_planet* p) {
     if (p->side) { (void)hipStreamSynchronize(p->side); (void)hipStreamDestroy(p->side); p->side = nullptr; }
     if (p->evFork) { (void)hipEventDestroy(p->evFork); p->evFork = nullptr; }
     if (p->evJoin) { (void)hipEventDestroy(p->evJoin); p->evJoin = nullptr; }
-    if (p->side2) { (void)hipStreamSynchronize(p->side2); (void)hipStreamDestroy(p->side2); p->side2 = nullptr; }
-    if (p->evJoin2) { (void)hipEventDestroy(p->evJoin2); p->evJoin2 = nullptr; }
-    dfree(p->d_lateDonor);
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     if (p->d_oceanKnown) { (void)hipFree(p->d_oceanKnown); p->d_oceanKnown = nullptr; } if (p->d_maskDiff) { (void)hipFree(p->d_maskDiff); p->d_maskDiff = nullptr; }
@@ -1532,8 +1267,8 @@ void wo_planet_destroy(wo_planet* p) {
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);
-    dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters); dfree(p->d_level); dfree(p->d_byLevel); dfree(p->d_levelStart);
-    if (p->h_levelStart) (void)hipHostFree(p->h_levelStart);
+    dfree(p->d_listA); dfree(p->d_listB); dfree(p->d_counters);
+    if (p->h_patchTotals) (void)hipHostFree(p->h_patchTotals);
     if (p->d_sortTemp) (void)hipFree(p->d_sortTemp);
     if (p->h_pinned) (void)hipHostFree(p->h_pinned);
     if (p->h_count) (void)hipHostFree(p->h_count);
@@ -2212,21 +1947,12 @@ static void assign_elevation(wo_planet* p, const int32_t* r_plate, const wo_plat
         run_field(BFS_BACKARC, seeds_of([&](int32_t r) { return bt[r] == 1 && has[r] && (double)sub[r] < 0.50; }), b_ba, INFINITY, b_bas, nullptr, nullptr, Qs.baEnd);
         run_field(BFS_ARC, seeds_of([&](int32_t r) { return bt[r] == 1 && both[r] && (double)sub[r] < 0.45; }), b_arc, (float)(Qs.maxArcDist + 1), b_arcs, nullptr, nullptr, Qs.maxArcDist);
     };
-    static const bool bfsHost = std::getenv("WO_ELEV_BFS_HOST") != nullptr;      // the host walks instead (reference for the device version)
-    if (bfsHost) elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
-    else elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes, bfs_on_device);
-    lap(bfsHost ? "Stress, sets, distance fields, BFS fields (host)" : "Stress, sets, distance fields (host) || BFS fields (device)");
+    elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes, bfs_on_device);
+    lap("Stress, sets, distance fields (host) || BFS fields (device)");
 
     // per-cell pass
-    if (bfsHost) {
-        F.isOcean = up(H.isOcean); F.stress = up(H.stress); F.subduct = up(H.subduct); F.btype = up(H.btype);
-        F.dBdry = up(H.dBdry); F.coastStressMax = up(H.coastStressMax); F.coastSubductMax = up(H.coastSubductMax);
-        F.coastConvergent = up(H.coastConvergent); F.riftDist = up(H.riftDist); F.ridgeDist = up(H.ridgeDist); F.fractureDist = up(H.fractureDist);
-        F.backArcDist = up(H.backArcDist); F.backArcStress = up(H.backArcStress); F.arcDist = up(H.arcDist); F.arcStress = up(H.arcStress);
-    } else {
-        F.dBdry = b_dBdry; F.coastStressMax = b_csm; F.coastSubductMax = b_cssm; F.coastConvergent = b_conv; F.riftDist = b_rift; F.ridgeDist = b_ridge;
-        F.fractureDist = b_frac; F.backArcDist = b_ba; F.backArcStress = b_bas; F.arcDist = b_arc; F.arcStress = b_arcs;
-    }
+    F.dBdry = b_dBdry; F.coastStressMax = b_csm; F.coastSubductMax = b_cssm; F.coastConvergent = b_conv; F.riftDist = b_rift; F.ridgeDist = b_ridge;
+    F.fractureDist = b_frac; F.backArcDist = b_ba; F.backArcStress = b_bas; F.arcDist = b_arc; F.arcStress = b_arcs;
     F.distMountain = up(H.distMountain); F.distOcean = up(H.distOcean); F.distCoastline = up(H.distCoastline); F.distCoast = up(H.distCoast);
     F.distCoastLand = up(H.distCoastLand);
     F.elev = p->d_e;

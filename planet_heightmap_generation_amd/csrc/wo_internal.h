@@ -34,14 +34,14 @@ WO_FLOOD_HD inline double flood_cell_noise_of(int32_t r) {
 }
 struct FloodHeapItem { float key; int32_t cell; };
 struct FloodCell { float e; int32_t drain; float surface; int32_t root; };   // one 16-byte record per land cell: a pop touches one line for all four
-// Test hooks and diagnostics of the host flood, read from the environment ONCE per flood call (flood_gather) — never inside a walk.
+// Test hooks (WO_TEST_HOOKS, host_util.h) and diagnostics of the host flood, read ONCE per flood call (flood_gather) — never inside a walk.
 struct FloodHooks {
-    int32_t ringMin = 4096;        // WO_FLOOD_RING_MIN     landmasses of at least this many cells walk on the ring of key buckets
-    int32_t chainsMin = 2048;      // WO_FLOOD_CHAINS_MIN   drainage trees of at least this many cells carve on the chain-ordered copy
-    int32_t forceDirty = -1;       // WO_FLOOD_FORCE_DIRTY  treat this landmass (by rank in size) as undecided
-    bool hasReplayStop = false; float replayStop = 0.0f;     // WO_FLOOD_REPLAY_STOP  the level at which the replay of the single heap stops
-    bool replayPrefix = true;      // WO_FLOOD_PREFIX=0     the replay walks undecided landmasses from their seeds (not from their first contested tie group)
-    int32_t forcePrefixPermille = 0;   // WO_FLOOD_FORCE_PREFIX  how much of the forced landmass's pops counts as its decided prefix
+    int32_t ringMin = 4096;        // hook flood_ring_min     landmasses of at least this many cells walk on the ring of key buckets
+    int32_t chainsMin = 2048;      // hook flood_chains_min   drainage trees of at least this many cells carve on the chain-ordered copy
+    int32_t forceDirty = -1;       // hook flood_force_dirty  treat this landmass (by rank in size) as undecided
+    bool hasReplayStop = false; float replayStop = 0.0f;     // hook flood_replay_stop  the level at which the replay of the single heap stops
+    bool replayPrefix = true;      // hook flood_prefix=0     the replay walks undecided landmasses from their seeds (not from their first contested tie group)
+    int32_t forcePrefixPermille = 0;   // hook flood_force_prefix  how much of the forced landmass's pops counts as its decided prefix
     bool pin = false;              // WO_FLOOD_PIN=1        the walk of the largest landmass keeps its CPU and the other flood workers keep off its L3 (opt-in: the library touches no thread affinity unasked)
     bool timing = false;           // WO_FLOOD_TIMING       laps -> stderr
     void read();
@@ -83,7 +83,8 @@ struct FloodTieReport {
     std::vector<std::pair<int32_t, int32_t>> alt;      // (cell, alternative parent) where only drainTo is undecided
 };
 // (re)builds the mask-dependent tables (Morton-ordered land list `landCell`, compact CSR, seeds)
-void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S);
+// mortonAll (nullable): every cell in the order of morton_order_cells(N, xyz) — the land list is then a filter of it instead of a sort
+void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const float* xyz, const uint8_t* ocean, FloodScratch& S, const int32_t* mortonAll = nullptr);
 // every cell in Morton order of its position (ties: ascending id); restricted to the land cells this is FloodScratch::landCell
 void morton_order_cells(int32_t N, const float* xyz, hvec<int32_t>& cells);
 // xyz (3*N floats) orders the compact land arrays spatially; may be nullptr (index order)

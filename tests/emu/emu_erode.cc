@@ -483,6 +483,7 @@ extern "C" void emu_set_lookahead(int v) { LOOKAHEAD = v; }
 // ---- assignElevation: the same host stage as the product plus the per-cell bodies driven on the CPU ----
 #include "../../planet_heightmap_generation_amd/csrc/elevation_host.h"
 #include "../../planet_heightmap_generation_amd/csrc/elevation_bfs.h"
+#include "emu_fifo_bfs.h"
 
 // The device formulation of the FIFO BFS fields (elevation_bfs.h), kernel by kernel with the atomics executed one
 // "thread" at a time: level-synchronous claims for the fields without attributes; push / count / scan / assign per level
@@ -605,7 +606,8 @@ extern "C" int emu_assign_elevation(int32_t N, const int32_t* off, const int32_t
     if (g_bfsDevice)
         elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes,
                              [&](const ElevParams& Qs, int32_t maxCD, double maxStress) { emu_bfs_fields(M, I, H, Qs, maxCD, maxStress); });
-    else elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes);
+    else elevation_host_stage(M, I, hS, hasSuper ? &hP : nullptr, H, Q, domes,
+                              [&](const ElevParams& Qs, int32_t maxCD, double maxStress) { fifo_bfs_fields(M, I, H, Qs, maxCD, maxStress); });
     ElevFields F{};
     F.xyz = xyz; F.plate = r_plate; F.isOcean = H.isOcean.data(); F.stress = H.stress.data(); F.subduct = H.subduct.data(); F.btype = H.btype.data();
     F.distMountain = H.distMountain.data(); F.distOcean = H.distOcean.data(); F.distCoastline = H.distCoastline.data(); F.distCoast = H.distCoast.data();

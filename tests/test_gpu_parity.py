@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import POST_TAGS, golden_cases, load_golden
+from hooks import del_hook, set_hook
 
 pytestmark = pytest.mark.gpu
 
@@ -233,8 +234,7 @@ def test_full_size_properties(TP):
 def test_headline_size_properties(TP):
     """BASELINE config 3 size (10 M cells, the bench workload): size-independent properties — bit-deterministic run
     to run (two different schedules of the same dataflow: the launch-count prediction differs between the runs),
-    ocean cells never written, land stays >= 0 and finite, zero iterations leave the field alone, and the patch
-    solve equals the level-round solve (same DAG, other schedule) on the first iterations."""
+    ocean cells never written, land stays >= 0 and finite, zero iterations leave the field alone."""
     import os
     from planet_heightmap_generation_amd import sphere_mesh as S
     mesh, xyz, nd = S.build_sphere(10_000_000, 0.75, 1)
@@ -260,17 +260,6 @@ def test_headline_size_properties(TP):
     st = pl.last_erode_stats()
     assert st["solve_patch_launches_total"] > 0 and st["land_cells"] == float((oc == 0).sum())
     pl.close()
-    os.environ["WO_NO_SOLVE_PATCH"] = "1"                        # level-synchronous rounds instead of Morton patches
-    try:
-        pl2 = TP.Planet(mesh, xyz, nd)
-        pl2.upload(e0, oc)
-        pl2.erode_composite_resident(6, 3e-4, 0.5, 1.0, 6, 1.16, 0.015, 2, 0.5)
-        pl2.apply_soil_creep_resident(3, 0.1125)
-        assert np.array_equal(pl2.download(), out)
-        assert pl2.last_erode_stats()["solve_patch_launches_total"] == 0
-        pl2.close()
-    finally:
-        del os.environ["WO_NO_SOLVE_PATCH"]
 
 
 @pytest.mark.isolated
@@ -368,12 +357,11 @@ def test_mirror_layout_is_invisible(TP, oracle, monkeypatch):
 
 
 def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
-    """Flow accumulation (js/terrain-post.js:604-611) = subtree sizes of the drainage forest.  Default: two levels — the same
-    last-arriver climb inside every tile of 1 024 cells on LDS atomics, a climb over the tiles' local roots, and the tile sums
-    again with the inflows (k_flow_tiles); WO_FLOW=climb: one launch over all cells in which the
-    thread that completes a receiver carries on with it (k_flow_climb); WO_FLOW_CLIMB=n caps a thread's walk and leaves the rest
-    to the pointer doubling; WO_FLOW_CLIMB=0 is the synchronous rake + pointer doubling.  Integer sums: all routes must give the
-    oracle's field bit for bit, on ordinary and on quantised (flat-heavy: long unbranched chains) terrain."""
+    """Flow accumulation (js/terrain-post.js:604-611) has two forms: under the land-first mirror (default) two levels — the last-arriver climb
+    inside every tile of 1 024 cells on LDS atomics, a climb over the tiles' local roots, and the tile sums again with the inflows (k_flow_tiles) —
+    and on the planet's own cell order (WO_LAYOUT=index) one launch over all cells in which the thread that completes a receiver carries on
+    with it (k_flow_climb).  Integer sums: both must give the oracle's field bit for bit, on ordinary and on quantised (flat-heavy: long
+    unbranched chains) terrain."""
     from planet_heightmap_generation_amd import sphere_mesh as S
     mesh, xyz, nd = S.build_sphere(250000, 0.75, 9)
     pl = TP.Planet(mesh, xyz, nd)
@@ -385,31 +373,17 @@ def test_flow_accumulation_routes_agree(TP, oracle, monkeypatch):
     for field in (e0, eq):
         oc = (field <= 0).astype(np.uint8)
         ref = oracle.erode_composite(om, field, xyz, oc, *args, nd)
-        for route in (None, "climb", "3", "40", "0", "events"):
-            monkeypatch.delenv("WO_FLOW_EVENTS_STREAM", raising=False)
-            monkeypatch.delenv("WO_FLOW", raising=False)
-            if route is None:                           # two levels: tile-local climbs in LDS + a climb over the tiles' local roots (k_flow_tiles)
-                monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
-            elif route == "climb":                      # the one-launch climb over all cells
-                monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
-                monkeypatch.setenv("WO_FLOW", "climb")
-            elif route == "events":                     # the solve's event lists on a third stream beside the accumulation, totals pass with late-donor flags
-                monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
-                monkeypatch.setenv("WO_FLOW_EVENTS_STREAM", "1")
+        for route in (None, "index"):
+            if route:
+                monkeypatch.setenv("WO_LAYOUT", route)
             else:
-                monkeypatch.setenv("WO_FLOW_CLIMB", route)
+                monkeypatch.delenv("WO_LAYOUT", raising=False)
             got = field.copy()
             pl.erode_composite(got, oc, *args)
             st = pl.last_erode_stats()
             assert np.array_equal(got, ref), (route, int((got != ref).sum()))
-            assert st["flow_two_level"] == (1.0 if route in (None, "events") else 0.0), (route, st["flow_two_level"])
-            if route in (None, "climb", "events"):
-                assert st["flow_rounds_total"] == 0, st["flow_rounds_total"]          # nothing left for the pointer doubling
-            elif route in ("3", "0"):
-                assert st["flow_rounds_total"] > 0, (route, st["flow_rounds_total"])  # the doubling really ran
-    monkeypatch.delenv("WO_FLOW_CLIMB", raising=False)
-    monkeypatch.delenv("WO_FLOW_EVENTS_STREAM", raising=False)
-    monkeypatch.delenv("WO_FLOW", raising=False)
+            assert st["flow_two_level"] == (1.0 if route is None else 0.0), (route, st["flow_two_level"])
+    monkeypatch.delenv("WO_LAYOUT", raising=False)
     pl.close()
 
 
@@ -777,7 +751,7 @@ def test_exchange_behind_the_c_abi_single_rank(TP):
 def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch):
     """The basin-local solve never leaves a task pending on real layouts (`solve_basin_passes_with_leftovers` is 0 in every run),
     so the path that finishes pending tasks — blocker hints made from the records, then k_solve_patch launches over the same
-    store order — is exercised with a layout that is wrong on purpose (WO_BASIN_SCRAMBLE: every third cell in its neighbour's
+    store order — is exercised with a layout that is wrong on purpose (test hook basin_scramble: every third cell in its neighbour's
     group).  The solve is a single-assignment dataflow: the result must be the oracle's bit for bit all the same."""
     from planet_heightmap_generation_amd import sphere_mesh as S
     mesh, xyz, nd = S.build_sphere(200000, 0.75, 4)
@@ -788,11 +762,11 @@ def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch)
     om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
     args = (12, 3e-4, 0.5, 1.0, 12, 1.16, 0.015, 0, 0.0)
     ref = oracle.erode_composite(om, e0, xyz, oc, *args, nd)
-    monkeypatch.setenv("WO_BASIN_SCRAMBLE", "1")
+    set_hook(monkeypatch, "basin_scramble", 1)
     got = e0.copy()
     pl.erode_composite(got, oc, *args)
     st = pl.last_erode_stats()
-    monkeypatch.delenv("WO_BASIN_SCRAMBLE")
+    del_hook(monkeypatch, "basin_scramble")
     assert st["solve_basin_passes_with_leftovers"] > 0, st
     # the pending count is not looked at after every pass any more: the call notices at its next host synchronisation that a launch
     # left tasks behind, restores the field and runs again with the check (and the k_solve_patch finisher) after every pass
@@ -806,13 +780,12 @@ def test_basin_leftovers_are_finished_by_patch_launches(TP, oracle, monkeypatch)
     pl.close()
 
 
-def test_glacial_step_routes_agree(TP, oracle, monkeypatch):
+def test_glacial_step_one_launch_and_its_finisher(TP, oracle, monkeypatch):
     """The glacial step's two dependency walks run as ONE launch each: the ice accumulation by last-arriver climb (k_ice_climb),
-    the carve turns by agent-scope hand-offs between the tasks' own threads (k_carve_granules: heights as
-    self-validating granules; k_carve_flow: done words).  Both must give the oracle's
-    field bit for bit, and so must (i) the synchronous rounds they replace (WO_ICE_ROUNDS=1 WO_CARVE_FLOW=0) and (ii) the mixed
-    case in which the one-launch carve gives up at once (budget 0 ms: every lane that finds a dependency open leaves its task)
-    and the rounds finish from whatever state it left."""
+    the carve turns by agent-scope hand-offs between the tasks' own threads (k_carve_granules: heights as self-validating granules).
+    Both must give the oracle's field bit for bit, and so must (i) the mixed case in which the one-launch carve gives up at once (test hook
+    carve_budget_ms=0: every lane that finds a dependency open leaves its task) and the synchronous rounds (k_carve_round_static) finish from
+    whatever state it left, and (ii) a launch of two workgroups for thousands of tasks (hook carve_blocks)."""
     from planet_heightmap_generation_amd import sphere_mesh as S
     mesh, xyz, nd = S.build_sphere(300000, 0.75, 6)
     pl = TP.Planet(mesh, xyz, nd)
@@ -828,41 +801,28 @@ def test_glacial_step_routes_agree(TP, oracle, monkeypatch):
     assert st["carve_flow_launches_with_leftovers"] == 0, st
     assert st["carve_rounds_total"] == 4 and st["ice_rounds_total"] == 4, st      # one launch per glacial step
     assert np.array_equal(got, ref), int((got != ref).sum())
-    monkeypatch.setenv("WO_ICE_ROUNDS", "1"); monkeypatch.setenv("WO_CARVE_FLOW", "0")
+    set_hook(monkeypatch, "carve_budget_ms", 0)
     got = e0.copy(); pl.erode_composite(got, oc, *args)
     st = pl.last_erode_stats()
-    assert st["carve_rounds_total"] > 4 and st["ice_rounds_total"] > 4, st
+    assert st["carve_flow_launches_with_leftovers"] > 0 and st["carve_rounds_total"] > 4, st
     assert np.array_equal(got, ref), int((got != ref).sum())
-    monkeypatch.delenv("WO_ICE_ROUNDS")
-    for mode in ("1", "2"):                # 1: done words (k_carve_flow), 2 (default): heights as self-validating granules (k_carve_granules)
-        monkeypatch.setenv("WO_CARVE_FLOW", mode)
-        monkeypatch.delenv("WO_CARVE_FLOW_BUDGET_MS", raising=False)
-        got = e0.copy(); pl.erode_composite(got, oc, *args)
-        st = pl.last_erode_stats()
-        assert st["carve_flow_launches_with_leftovers"] == 0 and st["carve_rounds_total"] == 4, (mode, st)
-        assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
-        monkeypatch.setenv("WO_CARVE_FLOW_BUDGET_MS", "0")
-        got = e0.copy(); pl.erode_composite(got, oc, *args)
-        st = pl.last_erode_stats()
-        assert st["carve_flow_launches_with_leftovers"] > 0, (mode, st)
-        assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
-        # two workgroups for thousands of tasks: every thread takes many positions of the (rank-ordered) activation list in turn, which is
-        # how a planet with more active tasks than resident threads runs (40 M cells); the launch must still finish everything itself
-        monkeypatch.delenv("WO_CARVE_FLOW_BUDGET_MS")
-        monkeypatch.setenv("WO_CARVE_FLOW_BLOCKS", "2")
-        got = e0.copy(); pl.erode_composite(got, oc, *args)
-        st = pl.last_erode_stats()
-        assert st["carve_flow_launches_with_leftovers"] == 0 and st["carve_rounds_total"] == 4, (mode, st)
-        assert np.array_equal(got, ref), (mode, int((got != ref).sum()))
-        monkeypatch.delenv("WO_CARVE_FLOW_BLOCKS")
+    del_hook(monkeypatch, "carve_budget_ms")
+    # two workgroups for thousands of tasks: every thread takes many positions of the (rank-ordered) activation list in turn, which is
+    # how a planet with more active tasks than resident threads runs (40 M cells); the launch must still finish everything itself
+    set_hook(monkeypatch, "carve_blocks", 2)
+    got = e0.copy(); pl.erode_composite(got, oc, *args)
+    st = pl.last_erode_stats()
+    assert st["carve_flow_launches_with_leftovers"] == 0 and st["carve_rounds_total"] == 4, st
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    del_hook(monkeypatch, "carve_blocks")
     pl.close()
 
 
-def test_sort_routes_agree_under_ties(TP, oracle, monkeypatch):
+def test_sorts_are_stable_under_ties(TP, oracle):
     """Both sorts of an iteration (landCells by elevation; the basin-local solve's group-major store order) run on the in-tree
     stable radix sort (csrc/radix.hip: count + scatter launch per 8-bit digit, the last pass writes rank[] / slotOf[]).  On a
     heavily quantised field — thousands of equal keys, whose order is the previous iteration's, as V8's stable sort keeps it —
-    it must give the oracle's field bit for bit, and so must the library sort it replaces (WO_SORT=hipcub).  300 k cells: 21 tiles
+    it must give the oracle's field bit for bit.  300 k cells: 21 tiles
     of 4096 pairs, so the prefix over earlier tiles (group totals + tile counts) and a partly filled last tile are exercised."""
     from planet_heightmap_generation_amd import sphere_mesh as S
     mesh, xyz, nd = S.build_sphere(300000, 0.75, 9)
@@ -875,10 +835,6 @@ def test_sort_routes_agree_under_ties(TP, oracle, monkeypatch):
     pl = TP.Planet(mesh, xyz, nd)
     got = eq.copy(); pl.erode_composite(got, oc, *args)
     assert np.array_equal(got, ref), int((got != ref).sum())
-    monkeypatch.setenv("WO_SORT", "hipcub")
-    got = eq.copy(); pl.erode_composite(got, oc, *args)
-    assert np.array_equal(got, ref), int((got != ref).sum())
-    monkeypatch.delenv("WO_SORT")
     # so few distinct heights that a single key holds a fifth of the land
     e4 = (np.round(e0 * 4) / 4).astype(np.float32)
     oc4 = (e4 <= 0).astype(np.uint8)
@@ -889,11 +845,10 @@ def test_sort_routes_agree_under_ties(TP, oracle, monkeypatch):
     pl.close()
 
 
-def test_solve_kernel_and_tile_staging_routes_agree(TP, oracle, monkeypatch):
-    """Two routes kept beside the default: WO_BASIN_KERNEL=barrier (k_solve_coop: the basin walk with one barrier per super-chunk;
-    default k_solve_flowing lets a wave run ahead) and WO_TILE_LDS=1 (north_star's "neighbour cells staged into LDS": the
-    neighbour window of a workgroup's tile copied into LDS for the receivers and thermal passes; measured no faster, off by
-    default).  Same dataflow, same operations: every route must give the oracle's field bit for bit, ties included."""
+def test_tile_staging_route_agrees(TP, oracle, monkeypatch):
+    """WO_TILE_LDS=1 (north_star's "neighbour cells staged into LDS": the neighbour window of a workgroup's tile copied into LDS for the
+    receivers and thermal passes; measured no faster, off by default).  Same dataflow, same operations: the route must give the oracle's
+    field bit for bit, ties included."""
     from planet_heightmap_generation_amd import sphere_mesh as S
     mesh, xyz, nd = S.build_sphere(300000, 0.75, 11)
     pl = TP.Planet(mesh, xyz, nd)
@@ -905,7 +860,7 @@ def test_solve_kernel_and_tile_staging_routes_agree(TP, oracle, monkeypatch):
     for field in (e0, eq):
         oc = (field <= 0).astype(np.uint8)
         ref = oracle.erode_composite(om, field, xyz, oc, *args, nd)
-        for env in ({}, {"WO_BASIN_KERNEL": "barrier"}, {"WO_TILE_LDS": "1"}):
+        for env in ({}, {"WO_TILE_LDS": "1"}):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             got = field.copy()
@@ -968,29 +923,6 @@ def test_land_count_shrinks_and_grows_on_one_planet(TP, oracle):
         got = e0.copy()
         pl.erode_composite(got, mask, *args)
         assert np.array_equal(got, ref), (int((mask == 0).sum()), int((got != ref).sum()))
-    pl.close()
-
-
-def test_graph_replay_route_agrees(TP, oracle, monkeypatch):
-    """WO_GRAPH=1: the steady composite iteration (no glacial step, no flood) captured once per call as a hipGraph — main and
-    side stream — and replayed.  Measured slower than plain launches on this stack, so it is off by default; as a route it must
-    give the oracle's field bit for bit, and it must really have replayed."""
-    from planet_heightmap_generation_amd import sphere_mesh as S
-    mesh, xyz, nd = S.build_sphere(200000, 0.75, 14)
-    pl = TP.Planet(mesh, xyz, nd)
-    pl.synthetic_terrain(14)
-    e0 = pl.download()
-    oc = (e0 <= 0).astype(np.uint8)
-    om = oracle.Mesh(mesh.adjOffset, mesh.adjList)
-    args = (24, 3e-4, 0.5, 1.0, 24, 1.16, 0.015, 2, 0.5)
-    ref = oracle.erode_composite(om, e0, xyz, oc, *args, nd)
-    monkeypatch.setenv("WO_GRAPH", "1")
-    got = e0.copy()
-    pl.erode_composite(got, oc, *args)
-    st = pl.last_erode_stats()
-    monkeypatch.delenv("WO_GRAPH")
-    assert st["iterations_replayed_from_graph"] >= 10, st
-    assert np.array_equal(got, ref), int((got != ref).sum())
     pl.close()
 
 
