@@ -37,7 +37,10 @@ namespace wo {
 namespace {
 
 constexpr int32_t WO_RANGE_NONE = 0x7f7f7f7f;
-constexpr int WO_BASIN_RANGE = 256;                 // slots per workgroup range (a range = the groups that start in one stretch of this many slots)
+#ifndef WO_BASIN_RANGE_SLOTS
+#define WO_BASIN_RANGE_SLOTS 256
+#endif
+constexpr int WO_BASIN_RANGE = WO_BASIN_RANGE_SLOTS;                 // slots per workgroup range (a range = the groups that start in one stretch of this many slots)
 constexpr int WO_BASIN_KEY_BITS = 16;               // bits of a group key (two radix passes)
 constexpr int WO_BASIN_CHASE_CAP = 1 << 16;         // pointer-jumping steps of one thread before it gives up (never reached: chains and rings are shorter)
 

@@ -30,7 +30,10 @@
 namespace wo {
 
 namespace {
-constexpr int RS_THREADS = 256, RS_WAVES = 4, RS_ITEMS = 16, RS_TILE = RS_THREADS * RS_ITEMS, RS_DIGITS = 256;
+#ifndef WO_RS_ITEMS
+#define WO_RS_ITEMS 16
+#endif
+constexpr int RS_THREADS = 256, RS_WAVES = 4, RS_ITEMS = WO_RS_ITEMS, RS_TILE = RS_THREADS * RS_ITEMS, RS_DIGITS = 256;
 
 constexpr int RS_GROUP = 32;          // tiles per group of the two-level prefix
 
