@@ -62,7 +62,7 @@ ONE_OFF = {"soil_creep": (82.0 * 0.8, 4.0), "warp_terrain": (0.0, 20.0 + 100.0 *
 GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend")      # ice_round: k_ice_climb, carve_round: k_carve_granules (one launch each per glacial step)
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload at the full iteration count (separate passes;
 # profiles/collect_pmc.sh); used for roofline.traffic of the dominant kernel unless WO_BENCH_PMC=1 asks for a live collection.
-PMC_FILE = REPO / "profiles" / "r05_pmc_fetch_write_per_kernel_10m_200iters.json"
+PMC_FILE = REPO / "profiles" / "r06_pmc_fetch_write_per_kernel_10m_200iters.json"
 FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": ("void wo::k_solve_setup_batched<true>", "wo::k_solve_setup"), "sort_radix": ("wo::k_rs_scatter", "wo::k_rs_count"),
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
                  "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_climb": "wo::k_flow_climb", "flow_tiles": ("void wo::k_flow_tiles", "wo::k_flow_root_climb", "wo::k_flow_root_links"), "carve_round": "wo::k_carve_granules",
