@@ -47,10 +47,9 @@ sys.path.insert(0, str(REPO))
 PASSES = {
     "sort":      {"budget": (8.0, 0.0),   "kernels": {"sort_keys": (2.0, 0.0), "sort_radix": (6.0, 0.0), "rank_scatter": (0.0, 0.0)}},
     "receivers": {"budget": (68.0, 4.0),  "kernels": {"receivers": (68.0, 4.0)}},
-    "flow":      {"budget": (16.0, 4.0),  "kernels": {"flow_tiles": (8.0, 0.0), "flow_climb": (8.0, 0.0), "flow_final": (8.0, 4.0), "flow_init": (0.0, 0.0), "flow_apply": (0.0, 0.0)}},
+    "flow":      {"budget": (16.0, 4.0),  "kernels": {"flow_tiles": (8.0, 0.0), "flow_climb": (8.0, 0.0), "flow_final": (8.0, 4.0)}},
     "solve":     {"budget": (45.0, 0.0),  "kernels": {"solve_setup": (33.0, 0.0), "solve_basin": (8.0, 0.0), "solve_patch": (8.0, 0.0), "solve_round": (8.0, 0.0),
-                                                       "solve_tail": (0.0, 0.0), "solve_final": (4.0, 0.0), "basin_layout": (0.0, 0.0), "basin_sort": (0.0, 0.0),
-                                                       "level_sort": (0.0, 0.0), "river_order": (0.0, 0.0)}},
+                                                       "solve_final": (4.0, 0.0), "basin_layout": (0.0, 0.0), "basin_sort": (0.0, 0.0)}},
     "thermal":   {"budget": (106.0, 4.0), "kernels": {"thermal_excess": (45.0, 0.0), "thermal_apply": (61.0, 4.0)}},
 }
 assert sum(v["budget"][0] for v in PASSES.values()) == 243.0 and sum(v["budget"][1] for v in PASSES.values()) == 12.0
@@ -63,10 +62,10 @@ GLACIAL_KERNELS = ("glac_index", "ice_receivers", "ice_round", "carve_setup", "c
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel on this workload at the full iteration count (separate passes;
 # profiles/collect_pmc.sh); used for roofline.traffic of the dominant kernel unless WO_BENCH_PMC=1 asks for a live collection.
 PMC_FILE = REPO / "profiles" / "r06_pmc_fetch_write_per_kernel_10m_200iters.json"
-FAMILY_KERNEL = {"solve_round": "wo::k_solve_round", "solve_tail": "wo::k_solve_tail", "solve_setup": ("void wo::k_solve_setup_batched<true>", "wo::k_solve_setup"), "sort_radix": ("wo::k_rs_scatter", "wo::k_rs_count"),
+FAMILY_KERNEL = {"solve_round": "wo::k_affine_jump", "solve_setup": ("void wo::k_solve_setup_batched<true>",), "sort_radix": ("wo::k_rs_scatter", "wo::k_rs_count"),
                  "thermal_apply": "void wo::k_thermal_apply_reg<16>", "solve_patch": "wo::k_solve_patch", "thermal_excess": "wo::k_thermal_excess", "receivers": "wo::k_receivers_flow_init",
-                 "flow_apply": "wo::k_flow_apply", "flow_final": "wo::k_flow_final", "flow_climb": "wo::k_flow_climb", "flow_tiles": ("void wo::k_flow_tiles", "wo::k_flow_root_climb", "wo::k_flow_root_links"), "carve_round": "wo::k_carve_granules",
-                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_flowing", "void wo::k_solve_coop")}
+                 "flow_final": "wo::k_flow_final", "flow_climb": "wo::k_flow_climb", "flow_tiles": ("void wo::k_flow_tiles", "wo::k_flow_root_climb", "wo::k_flow_root_links"), "carve_round": "wo::k_carve_granules",
+                 "warp_terrain": "wo::k_warp", "soil_creep": "wo::k_creep", "solve_final": "wo::k_solve_final", "solve_basin": ("void wo::k_solve_flowing",)}
 KERNEL_GROUPS = {"basin_sort": "sort_radix"}      # profile families that are call sites of the same HIP kernels
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 

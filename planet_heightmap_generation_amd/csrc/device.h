@@ -50,11 +50,11 @@ inline int xcd_grid(int64_t n) {          // block count padded to whole rounds 
 // Kernel families for HIP-event profiling (wo_profile_*) — one entry per distinct kernel of the path.
 enum Family : int {
     FAM_COAST = 0, FAM_SMOOTH, FAM_SHARPEN, FAM_CREEP, FAM_WARP, FAM_NOISE, FAM_SYNTH, FAM_OCEAN,
-    FAM_SORT_KEYS, FAM_SORT_RADIX, FAM_RANK, FAM_RECEIVERS, FAM_FLOW_INIT, FAM_FLOW_SNAP, FAM_FLOW_APPLY, FAM_FLOW_FINAL,
+    FAM_SORT_KEYS, FAM_SORT_RADIX, FAM_RANK, FAM_RECEIVERS, FAM_FLOW_SNAP, FAM_FLOW_FINAL,
     FAM_SOLVE_SETUP, FAM_SOLVE_ROUND, FAM_SOLVE_FINAL, FAM_THERMAL_EXCESS, FAM_THERMAL_APPLY,
     FAM_GLAC_INDEX, FAM_ICE_RECV, FAM_ICE_ROUND, FAM_CARVE_SETUP, FAM_CARVE_ROUND, FAM_MORAINE, FAM_GLAC_BLEND,
-    FAM_LEVEL_SORT, FAM_SOLVE_TAIL, FAM_SOLVE_PATCH, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_PLATE_GRID, FAM_PLATE_PROJECT, FAM_SMOOTH_FIELD,
-    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_CLIMATE, FAM_RIVER, FAM_BASIN, FAM_BASIN_SORT, FAM_SOLVE_BASIN, FAM_FLOW_TILES, FAM_MISC, FAM_EVENT_PAIR, FAM_EVENT_PAIR_NOOP, FAM_EVENT_PAIR_NOOP2, FAM_COUNT
+    FAM_SOLVE_PATCH, FAM_ELEV_COLLISION, FAM_ELEV_MAIN, FAM_PLATE_GRID, FAM_PLATE_PROJECT, FAM_SMOOTH_FIELD,
+    FAM_FLOOD_EVAL, FAM_FLOOD_APPLY, FAM_FLOOD_MISC, FAM_CLIMATE, FAM_BASIN, FAM_BASIN_SORT, FAM_SOLVE_BASIN, FAM_FLOW_TILES, FAM_MISC, FAM_EVENT_PAIR, FAM_EVENT_PAIR_NOOP, FAM_EVENT_PAIR_NOOP2, FAM_COUNT
 };
 extern const char* const kFamilyNames[FAM_COUNT];
 

@@ -24,9 +24,9 @@ namespace wo {
 
 const char* const kFamilyNames[FAM_COUNT] = {
     "coast_flags", "smooth_elevation", "sharpen_ridges", "soil_creep", "warp_terrain", "noise_eval", "synthetic_terrain",
-    "ocean_from_elevation", "sort_keys", "sort_radix", "rank_scatter", "receivers", "flow_init", "flow_climb",
-    "flow_apply", "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
-    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "level_sort", "solve_tail", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "river_order", "basin_layout", "basin_sort", "solve_basin", "flow_tiles", "misc", "event_pair_empty", "event_pair_noop_kernel", "event_pair_two_noop_kernels"};
+    "ocean_from_elevation", "sort_keys", "sort_radix", "rank_scatter", "receivers", "flow_climb",
+    "flow_final", "solve_setup", "solve_round", "solve_final", "thermal_excess", "thermal_apply",
+    "glac_index", "ice_receivers", "ice_round", "carve_setup", "carve_round", "moraine_fjord", "glacial_blend", "solve_patch", "elev_collisions", "elev_uplift_fused", "plate_grid", "plate_project", "smooth_field", "flood_eval", "flood_apply", "flood_misc", "climate_sweeps", "basin_layout", "basin_sort", "solve_basin", "flow_tiles", "misc", "event_pair_empty", "event_pair_noop_kernel", "event_pair_two_noop_kernels"};
 
 hipEvent_t profile_event(wo_planet* p) {
     if (!p->eventPool.empty()) { hipEvent_t e = p->eventPool.back(); p->eventPool.pop_back(); return e; }
