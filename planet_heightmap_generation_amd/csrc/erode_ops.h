@@ -192,7 +192,6 @@ WO_HD inline uint32_t desc_key(float f) {
     uint32_t u = (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
     return ~u;
 }
-WO_HD inline uint32_t asc_key(float f) { return ~desc_key(f); }
 
 // ------------------------------------------------------------------------------------------------
 // Jacobi family (js/terrain-post.js:317-354, 713-751, 758-794, 690-706)
@@ -1237,14 +1236,6 @@ WO_HD inline bool carve_task_rec(const Fields& F, const CarveRec& R, int32_t slo
     return true;
 }
 
-// the cell a task that just failed carve_task() is waiting for (device schedule: carried in the pending-list entry)
-WO_HD inline int32_t carve_current_blocker(const Fields& F, int32_t r) {
-    if (F.carveDeps) {
-        const int32_t slot = F.carveSlot[r];
-        if (F.carveDepCnt[slot] >= 0) return F.carveDeps[(size_t)slot * WO_CARVE_DEPS + F.carveDepPos[slot]];
-    }
-    return F.blocker[r];
-}
 
 // moraine (js/terrain-post.js:529-537) gathered per target, then fjord (540-551) and clamp (554-556)
 WO_HD inline void moraine_fjord_cell(const Fields& F, int32_t t, double gDepositAmount, double gFjordCarve) {

@@ -912,23 +912,6 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_records(Fields F, const int3
     const int32_t n = *count;
     WO_GRID_STRIDE(i, n) { carve_record_cell(F, list[i], i, recs, gCarve, gConv, gStrength, withDeps); if (resetDone) slotDone[i] = WO_NOT_DONE; }
 }
-// Carve rounds on {task, blocker} entries: a round is as long as its longest chain of dependent loads, and a parked task
-// only needs list entry -> doneAt[blocker]; the task's own records are touched when that blocker has finished.
-__device__ inline void block_append2(bool flag, int2 v, int2* out, int32_t* outCount) {
-    __shared__ int32_t s_base2, s_wave2[WO_BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(flag);
-    if (lane == 0) s_wave2[wave] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int32_t tot = 0;
-        for (int w = 0; w < WO_BLOCK / 64; ++w) { const int32_t c = s_wave2[w]; s_wave2[w] = tot; tot += c; }
-        s_base2 = tot ? atomicAdd(outCount, tot) : 0;
-    }
-    __syncthreads();
-    if (flag) out[s_base2 + s_wave2[wave] + __popcll(m & ((1ull << lane) - 1ull))] = v;
-    __syncthreads();
-}
 // Carve rounds over the STATIC activation list: one thread per active task in every round, no pending lists, no counters on the
 // chain.  A finished task leaves after one load; an open one issues all its loads at once (carve_task_eager) and runs when its
 // dependencies finished in earlier launches.  done: tasks finished so far (one atomic per wave that finished any), read back
@@ -949,11 +932,11 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const
     const unsigned long long m = __ballot(ran);
     if (m && (threadIdx.x & 63) == 0) atomicAdd(done, __popcll(m));
 }
-// ---- the carve rounds as ONE launch -----------------------------------------------------------------------------------------------
+// ---- the carve turns as ONE launch, the heights as self-validating granules ------------------------------------------------------
 // A carve turn (js/terrain-post.js:506-526) may run once every lower-ranked active cell within two hops has had its turn; the DAG of
 // those waits is ~330 turns deep on a 10 M-cell planet, and as synchronous rounds every level cost a launch (11 us each, 3.7 ms
-// per glacial step for ~3 us of actual work per level).  Here every active task has its own thread, polls its dependencies' done
-// words at agent scope and takes its turn as soon as the last one is set: a level costs a flag hand-off between CUs (~2 us).
+// per glacial step for ~3 us of actual work per level).  Here every active task has its own thread and takes its turn as soon as what
+// it waits for is there: a level costs a hand-off between CUs (~2 us).
 //  * The activation list is in RANK order (select_active_by_rank), so a task's dependencies all sit at lower positions; thread g
 //    takes positions g, g + G, g + 2G, ... in turn with G = all the launch's threads.  The lowest unfinished position then always
 //    belongs to a thread that has nothing earlier left, so some task can always run provided the G threads are resident: the grid
@@ -962,52 +945,19 @@ __global__ __launch_bounds__(WO_BLOCK) void k_carve_round_static(Fields F, const
 //    the turn inside the loop body, so no lane ever sits at a reconvergence point waiting for another lane's poll (whose task may
 //    depend on it).
 //  * Every spin is bounded: a lane that has waited `budget` ticks of the 100 MHz wall clock gives up and leaves its task to the
-//    synchronous rounds, which take over from whatever state the launch left (done words and slot tags are the rounds' own).
-//  * Heights are read and written at agent scope (they cross between CUs inside the launch); everything else a turn reads is
-//    static during the glacial step.  Any two turns that touch a common cell are within two hops of each other, hence ordered by
-//    the waits: reads-after-writes, writes-after-writes and writes-after-reads alike.
-// The arithmetic is carve_task_rec's / carve_task's, statement for statement.
-__device__ inline bool carve_flow_open_scan(const Fields& F, int32_t r) {     // tasks whose dependency list did not fit: the two-hop scan
-    const int32_t myRank = F.arank[r];
-    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
-        const int32_t n = F.adj[j];
-        if (F.arank[n] < myRank && ld_agent(&F.doneAt[n]) == WO_NOT_DONE) return true;
-        for (int32_t q = F.off[n]; q < F.off[n + 1]; ++q) {
-            const int32_t m = F.adj[q];
-            if (m != r && F.arank[m] < myRank && ld_agent(&F.doneAt[m]) == WO_NOT_DONE) return true;
-        }
-    }
-    return false;
-}
-__device__ inline void carve_flow_turn_rows(const Fields& F, int32_t r, double deepening, double bonus, int32_t up) {   // rows longer than WO_EAGER_ROW
-    const float er = (float)((double)ld_agent(&F.e[r]) - deepening);
-    st_agent(&F.e[r], er);
-    for (int32_t j = F.off[r]; j < F.off[r + 1]; ++j) {
-        const int32_t nb = F.adj[j];
-        if (F.ocean[nb]) continue;
-        const double d = nd_or_eps(F.dist[j]);
-        const float en = ld_agent(&F.e[nb]);
-        const double slope = fabs((double)er - (double)en) / d;
-        double f = 1 - slope;
-        if (!(f > 0)) f = (f != f) ? f : 0;
-        st_agent(&F.e[nb], (float)((double)en - deepening * 0.4 * f));
-    }
-    if (up >= 2) st_agent(&F.e[r], (float)((double)ld_agent(&F.e[r]) - bonus));
-}
-// ---- the same launch with the heights as self-validating granules ------------------------------------------------------------------
-// k_carve_flow pays four memory round trips per level of the DAG: the finished task's stores must be acknowledged before its done
-// word goes out, the waiting task's poll must see the word, then it loads the heights, then it stores.  Here a height travels
-// WITH its validity: during the carve every cell's height lives in an 8-byte granule {height, tag}, written by one store, where
-// tag = 1 + rank of the task that wrote it (0: not written yet in this glacial step).  Which task writes a cell x last before task
-// T's turn is static — the highest-ranked active cell below T among x and x's neighbours (the turns that touch x are the active
-// cells of that set, and they touch x in rank order) — so T knows, for each of the <=13 cells it reads, the tag it must see
-// (k_carve_expect).  T polls those granules; when all carry their expected tags it already HAS the values, takes its turn and
-// stores the new granules: no done word, no drain, no second load — a level is one store seen by one poll.
-//  * nothing can overwrite a granule before T has read it: a task U that writes x after T is an active cell of the same set with
+//    synchronous rounds (k_carve_round_static), which take over from whatever state the launch left.
+//  * WHAT a task waits for is the heights themselves (round 3's first form polled per-task done words and paid four memory round trips per
+//    level: the finished task's stores acknowledged, the word seen, the heights loaded, the new ones stored; removed in round 6).  During the
+//    carve every cell's height lives in an 8-byte granule {height, tag}, written by one store, where tag = 1 + rank of the task that wrote it
+//    (0: not written yet in this glacial step).  Which task writes a cell x last before task T's turn is static — the highest-ranked active
+//    cell below T among x and x's neighbours (the turns that touch x are the active cells of that set, and they touch x in rank order) —
+//    so T knows, for each of the <= 13 cells it reads, the tag it must see (k_carve_expect).  T polls those granules; when all carry their
+//    expected tags it already HAS the values, takes its turn and stores the new granules: a level is one store seen by one poll.
+//  * Nothing can overwrite a granule before T has read it: a task U that writes x after T is an active cell of the same set with
 //    a higher rank, so U itself waits for x to carry T's tag (or a later one) — and T writes x only after reading it.
-//  * an 8-byte naturally aligned store is seen whole (MI355X_MICROARCH.md: hand-off granules), so no ordering is needed at all.
-//  * progress, residency, the wave-uniform loop and the bounded spin are k_carve_flow's; a task that gives up leaves its done word
-//    unset, the heights go back into the field (k_carve_unpack) and the synchronous rounds finish the step.
+//  * An 8-byte naturally aligned store is seen whole (MI355X_MICROARCH.md: hand-off granules), so no ordering is needed at all.
+//  * A task that gives up leaves its slot open, the heights go back into the field (k_carve_unpack) and the synchronous rounds finish the step.
+// The arithmetic is carve_task_rec's / carve_task's, statement for statement.
 __device__ inline unsigned long long granule_pack(float v, int32_t tag) { return ((unsigned long long)(uint32_t)tag << 32) | (unsigned long long)__float_as_uint(v); }
 __device__ inline float granule_value(unsigned long long g) { return __uint_as_float((uint32_t)g); }
 __device__ inline int32_t granule_tag(unsigned long long g) { return (int32_t)(g >> 32); }
