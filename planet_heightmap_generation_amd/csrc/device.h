@@ -134,7 +134,7 @@ struct wo_planet {
     bool landIdentity = false;          // erode_composite under the land-first mirror: landIdx[i] == i
     int64_t floodPrefixMirror = -1, floodPrefixStatic = -1;      // (mirror version, flood static version) for which the mirror's first L ids were checked to be the flood's land order
     bool floodPrefixOk = false;
-    int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr, *d_target = nullptr;
+    int32_t *d_landIdx = nullptr, *d_land[2] = {nullptr, nullptr}, *d_rank = nullptr;
     // the initial land list (ascending r, js/terrain-post.js:384-390) and the index-order list are functions of the ocean mask alone: kept while it stays
     int32_t* d_landInit = nullptr; int64_t oceanVersion = 0, landListsOcean = -1; bool landListsMirror = false; int32_t landListsL = -1;
     uint32_t* d_keys[2] = {nullptr, nullptr};
@@ -142,7 +142,7 @@ struct wo_planet {
     wo::SolveTask* d_task = nullptr; wo::SolveOut* d_out = nullptr; int32_t *d_haloSend = nullptr, *d_haloRecv = nullptr; float *d_haloBuf = nullptr, *h_haloBuf = nullptr; int32_t nHaloSend = 0, nHaloRecv = 0;   // banded Jacobi passes
     int32_t* d_flowCnt = nullptr; wo::TargetRank* d_tr = nullptr; wo::EventList* d_ev = nullptr; float* d_me = nullptr;
     int32_t *d_carveSlot = nullptr, *d_carveDeps = nullptr, *d_carveDepCnt = nullptr, *d_carveDepPos = nullptr; uint32_t* d_rs[2] = {nullptr, nullptr}; int rsFlip[2] = {0, 0};   /* radix.hip scratch: elevation sort, basin sort */ wo::CarveRec* d_carveRecs = nullptr; wo::CarveExpect* d_carveExpect = nullptr; unsigned long long* d_carveG = nullptr;   /* k_carve_granules: expected tags per task, height granules per cell */ int32_t* d_carveSlotDone = nullptr; int64_t carveCap = 0;   // carve dependency lists
-    uint32_t *d_acc = nullptr, *d_snap = nullptr; unsigned long long* d_accCnt = nullptr;
+    unsigned long long* d_accCnt = nullptr;
     int32_t *d_ftLr = nullptr, *d_ftParent = nullptr, *d_ftExtCnt = nullptr; uint32_t* d_ftInflow = nullptr; unsigned long long* d_ftRootAcc = nullptr;      // two-level flow accumulation (kernels_impl.h: FlowTiles)
     int32_t *d_jump = nullptr, *d_nj = nullptr;
     int32_t* d_doneAt = nullptr;

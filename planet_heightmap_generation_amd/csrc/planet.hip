@@ -57,7 +57,7 @@ static void ensure_scratch(wo_planet* p) {
     p->d_keys[0] = dalloc<uint32_t>(N); p->d_keys[1] = dalloc<uint32_t>(N);
     p->d_rank = dalloc<int32_t>(N);
     p->d_cellDist = dalloc<float>(N); p->d_flow = dalloc<float>(N); p->d_task = dalloc<SolveTask>(N); p->d_out = dalloc<SolveOut>(N); WO_HIP(hipMemset(p->d_out, 0, N * sizeof(SolveOut)));   /* tags of the unchecked basin passes count up from here: no stale tag may look like a coming one */ p->d_flowCnt = dalloc<int32_t>(N); WO_HIP(hipMemset(p->d_flowCnt, 0, (size_t)N * 4)); p->d_tr = dalloc<TargetRank>(N); p->d_ev = dalloc<EventList>(N); p->d_me = dalloc<float>(N); p->d_carveSlot = dalloc<int32_t>(N);
-    p->d_acc = dalloc<uint32_t>(N); p->d_snap = dalloc<uint32_t>(N); p->d_accCnt = dalloc<unsigned long long>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
+    p->d_accCnt = dalloc<unsigned long long>(N); p->d_jump = dalloc<int32_t>(N); p->d_nj = dalloc<int32_t>(N);
     p->d_doneAt = dalloc<int32_t>(N);
     p->d_totalExcess = dalloc<double>(N);
     p->d_glac = dalloc<float>(N); p->d_iceFlow = dalloc<float>(N); p->d_iceTarget = dalloc<int32_t>(N); p->d_arank = dalloc<int32_t>(N);
@@ -77,7 +77,7 @@ wo::Fields wo_planet::fields() const {
     wo::Fields F{};
     F.N = N; F.xcdTile = wo::xcd_tile(N); F.tileLds = opt.tileLds ? 1 : 0; F.off = d_off; F.adj = d_adj; F.dist = d_dist; F.xyz = d_xyz; F.ocean = d_ocean; F.coast = d_coast;
     F.e = d_e; F.e2 = d_e2; F.L = L; F.land = d_land[landCur]; F.landIdx = landIdentity ? nullptr : d_landIdx; F.xcdTileL = wo::xcd_tile(L > 0 ? L : 1); F.rank = d_rank; F.target = nullptr; F.tr = d_tr; F.ev = d_ev; F.me = d_me; F.carveSlot = d_carveSlot; F.carveDeps = nullptr; F.carveDepCnt = d_carveDepCnt; F.carveDepPos = d_carveDepPos; F.cellDist = d_cellDist;
-    F.flow = d_flow; F.accA = d_acc; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
+    F.flow = d_flow; F.accA = nullptr; F.accB = nullptr; F.accCnt = d_accCnt; F.jumpA = d_jump; F.jumpB = nullptr;
     F.task = d_task; F.out = d_out; F.slotOf = (patchVersion >= 0) ? d_slotOf : nullptr; F.blk = d_patchBlk; F.doneAt = d_doneAt;
     F.totalExcess = d_totalExcess; F.glac = d_glac; F.iceTarget = d_iceTarget; F.iceFlow = d_iceFlow; F.iceUp = d_iceUp; F.arank = d_arank; F.blocker = d_nj;
     return F;
@@ -880,7 +880,6 @@ static void erode_composite(wo_planet* p, int32_t hIters, double K, double m, do
             const bool slotIdentity = mir.on && p->mirror.h_mask.size() == (size_t)N;          // land-first mirror: a land cell's Morton slot is its id
             // the receivers pass also leaves the start state of the layout's component search
             if (basin) { basin_alloc(p); F.basinJ = p->d_basinJ; F.basinMslot = slotIdentity ? nullptr : p->d_slotOf; }
-            F.accA = nullptr;                          // (the accumulator of round 2's pointer doubling: not written any more)
             // two-level accumulation (k_flow_tiles): needs the land cells to be the ids 0 .. L-1 in Morton order (land-first mirror); on the planet's
             // own cell order (WO_LAYOUT=index) the one-launch climb over all cells (k_flow_climb)
             const bool flowTiles = p->landIdentity;
@@ -1262,8 +1261,8 @@ void wo_planet_destroy(wo_planet* p) {
     mirror_free(p);
     dfree(p->d_ocean); dfree(p->d_coast); dfree(p->d_tables); dfree(p->d_savedE); dfree(p->d_savedOcean);
     if (p->d_oceanKnown) { (void)hipFree(p->d_oceanKnown); p->d_oceanKnown = nullptr; } if (p->d_maskDiff) { (void)hipFree(p->d_maskDiff); p->d_maskDiff = nullptr; }
-    dfree(p->d_landInit); dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank); dfree(p->d_target);
-    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_acc); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_affine[0]); dfree(p->d_affine[1]); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_snap); dfree(p->d_jump); dfree(p->d_nj);
+    dfree(p->d_landInit); dfree(p->d_landIdx); dfree(p->d_land[0]); dfree(p->d_land[1]); dfree(p->d_keys[0]); dfree(p->d_keys[1]); dfree(p->d_rank);
+    dfree(p->d_cellDist); dfree(p->d_flow); dfree(p->d_task); dfree(p->d_out); dfree(p->d_flowCnt); dfree(p->d_tr); dfree(p->d_ev); dfree(p->d_me); dfree(p->d_haloSend); dfree(p->d_haloRecv); dfree(p->d_haloBuf); if (p->h_haloBuf) { (void)hipHostFree(p->h_haloBuf); p->h_haloBuf = nullptr; } dfree(p->d_carveSlot); dfree(p->d_redoE); dfree(p->d_pendingEver); for (auto& r : p->d_rs) { if (r) (void)hipFree(r); r = nullptr; } dfree(p->d_carveG); dfree(p->d_carveExpect); dfree(p->d_carveRecs); dfree(p->d_carveSlotDone); dfree(p->d_carveDeps); dfree(p->d_carveDepCnt); dfree(p->d_carveDepPos); dfree(p->d_ftLr); dfree(p->d_ftParent); dfree(p->d_affine[0]); dfree(p->d_affine[1]); dfree(p->d_ftExtCnt); dfree(p->d_ftInflow); dfree(p->d_ftRootAcc); dfree(p->d_accCnt); dfree(p->d_jump); dfree(p->d_nj);
     dfree(p->d_doneAt); dfree(p->d_totalExcess);
     dfree(p->d_glac); dfree(p->d_iceFlow); dfree(p->d_iceTarget); dfree(p->d_arank); dfree(p->d_iceUp);
     dfree(p->d_patchOrder); dfree(p->d_slotOf); dfree(p->d_patchPending); dfree(p->d_patchTotals); dfree(p->d_patchBlk);
