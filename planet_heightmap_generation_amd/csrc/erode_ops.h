@@ -604,62 +604,19 @@ WO_HD inline void solve_setup_cell_plain(const Fields& F, int32_t r) {
     if (F.blk && !F.solveLean) F.blk[si] = T.predT >= 0 ? T.predT : (T.predSelf >= 0 ? T.predSelf : T.predT2);
 }
 
-// ---- divisions by per-task constants, taken off the dependency chain ----
-// The compiler expands an f64 division x / y into: v_div_scale of both operands, v_rcp of the divisor, two Newton steps on the
-// reciprocal (4 fma), then q0 = x * r, e = fma(-y, q0, x), q = fma(e, r, q0) (v_div_fmas) and v_div_fixup for the special
-// cases.  When neither operand needs scaling (both far from the ends of the exponent range) the scales are identities, the
-// v_div_fmas is a plain fma and the fix-up passes q through, so everything before q0 depends on the divisor alone:
-// div_prepare() runs that part once per task, before the task starts to wait for its predecessors, and div_by_prepared()
-// is the three-instruction tail: the same instructions on the same values as the full sequence, hence the same bits (the
-// parity tests and the CRC of the benched field compare the result with the oracle's plain divisions).  Operands outside the
-// safe window take the plain division.  MEASURED SLOWER (10 M cells, 200 iterations: patch solve 345 ms with plain divisions, 361 ms
-// with the first divisor prepared, 391 ms with both; results identical, profiles/r02x_prepared_division_ab.txt): a visit pays the
-// preparation for every task it hands out, and that sits before the first poll.  Compiled only with -DWO_PREPARED_DIV.
-struct PreparedDivisor { double y, r; bool ok; };
-WO_HD inline bool div_safe_exponent(double v) {             // 2^-500 <= |v| < 2^501: no scaling in v_div_scale, quotient normal
-    unsigned long long b; memcpy(&b, &v, 8);
-    return (uint32_t)((uint32_t)(b >> 52) & 0x7ffu) - 523u <= 1000u;
-}
-WO_HD inline PreparedDivisor div_prepare(double y) {
-    PreparedDivisor P; P.y = y; P.r = 0; P.ok = false;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(WO_PREPARED_DIV)
-    P.ok = y > 0 && div_safe_exponent(y);
-    const double r0 = __builtin_amdgcn_rcp(y);
-    const double f0 = __builtin_fma(-y, r0, 1.0);
-    const double r1 = __builtin_fma(r0, f0, r0);
-    const double f1 = __builtin_fma(-y, r1, 1.0);
-    P.r = __builtin_fma(r1, f1, r1);
-#endif
-    return P;
-}
-WO_HD inline double div_by_prepared(double x, const PreparedDivisor& P) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(WO_PREPARED_DIV)
-    unsigned long long b; memcpy(&b, &x, 8);
-    if (P.ok && (long long)b >= 0) {                         // sign bit clear (-0, negative x: plain division)
-        if (b == 0) return 0.0;                              // +0 / y, y > 0
-        if ((uint32_t)(b >> 52) - 523u <= 1000u) {           // 2^-500 <= x < 2^501 (inf / NaN fall outside)
-            const double q0 = x * P.r;
-            const double e = __builtin_fma(-P.y, q0, x);
-            return __builtin_fma(e, P.r, q0);
-        }
-    }
-#endif
-    return x / P.y;
-}
-
+// (Divisions by per-task constants taken off the dependency chain by preparing the divisor's reciprocal before the task starts to wait — the hardware division
+// sequence split at the point where it stops depending on the divisor alone — were built for the patch solve in round 2: same bits, measured slower, 345 -> 361-391 ms
+// per step, profiles/r02x_prepared_division_ab.txt; removed in round 6.  The basin walk's own form of the idea — reciprocals refined while the record arrives,
+// the turn keeps the three dependent operations of each division — is in basin.hip: recip_refined / div_tail.)
 // one turn of the implicit solve + deposition (js/terrain-post.js:616-640) given its three inputs.
 // solve_prepare is the part that does not depend on the predecessors (callers on a dependency chain hoist it).
-struct SolvePrepared { double factor; PreparedDivisor onePlusFactor, cellDistT; };
+struct SolvePrepared { double factor, onePlusFactor, cellDistT; };
 WO_HD inline double solve_factor(const SolveTask& T, double, double, double) { return T.factor; }
 WO_HD inline SolvePrepared solve_prepare(const SolveTask& T, double K, double m, double dt) {
     SolvePrepared S;
     S.factor = solve_factor(T, K, m, dt);
-    S.onePlusFactor = div_prepare(1 + S.factor);
-#ifdef WO_DIV_FIRST_ONLY
-    S.cellDistT.y = (double)T.cellDistT; S.cellDistT.r = 0; S.cellDistT.ok = false;
-#else
-    S.cellDistT = div_prepare((double)T.cellDistT);
-#endif
+    S.onePlusFactor = 1 + S.factor;
+    S.cellDistT = (double)T.cellDistT;
     return S;
 }
 WO_HD inline SolveOut solve_apply(const SolveTask& T, const SolvePrepared& S, double er, double et, double et2, int32_t tag) {
@@ -669,14 +626,14 @@ WO_HD inline SolveOut solve_apply(const SolveTask& T, const SolvePrepared& S, do
         o.self.v = (float)er; o.dep.v = 0; return o;
     }
     const double hr = et > 0 ? et : 0;
-    double hn = div_by_prepared(er + S.factor * hr, S.onePlusFactor);
+    double hn = (er + S.factor * hr) / S.onePlusFactor;
     if (hn < hr) hn = hr;
     if (hn < 0) hn = 0;
     const double eroded = er - hn;
     float tval = (float)et;
     if (eroded > 0 && !(T.flags & 1u)) {
         double slope = 0;
-        if (T.flags & 8u) slope = div_by_prepared(fabs(et - et2), S.cellDistT);
+        if (T.flags & 8u) slope = fabs(et - et2) / S.cellDistT;
         const double depositFrac = 0.5 / (1 + slope * 50);
         const double deposit = eroded * depositFrac;
         tval = (float)(et + deposit);
@@ -691,11 +648,11 @@ WO_HD inline SolveOut solve_apply(const SolveTask& T, const SolvePrepared& S, do
 WO_HD inline SolveOut solve_apply_flat(const SolveTask& T, const SolvePrepared& S, double er, double et, double et2, int32_t tag) {
     const bool hasT = (T.flags & 4u) != 0, tOcean = (T.flags & 1u) != 0, hasT2 = (T.flags & 8u) != 0;
     const double hr = et > 0 ? et : 0;
-    double hn = div_by_prepared(er + S.factor * hr, S.onePlusFactor);
+    double hn = (er + S.factor * hr) / S.onePlusFactor;
     hn = hn < hr ? hr : hn;
     hn = hn < 0 ? 0 : hn;
     const double eroded = er - hn;
-    const double sl = div_by_prepared(fabs(et - et2), S.cellDistT);
+    const double sl = fabs(et - et2) / S.cellDistT;
     const double slope = hasT2 ? sl : 0.0;
     const double depositFrac = 0.5 / (1 + slope * 50);
     const double deposit = eroded * depositFrac;
