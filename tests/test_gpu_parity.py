@@ -648,6 +648,20 @@ def test_config5_seeds_full_length_checksum(TP, seed):
     assert stats["flood_host_serial_pass1"] == 0
 
 
+@pytest.mark.isolated
+@pytest.mark.parametrize("seed", [16, 24, 32, 40, 48, 56, 64])
+def test_config5_every_eighth_of_the_64_seeds_full_length_checksum(TP, seed):
+    """BASELINE config 5 names 64 seeds; tests/golden/crc_config3.json pins ALL of them at the full 200 iterations (round 6: seeds 16-64 added,
+    12-30 minutes of one core each) and `bench.py --gpus N` checks every planet it erodes against that file.  Here: every eighth of the new ones."""
+    import json
+    from conftest import GOLDEN
+    key = f"10000000_seed{seed}_iters200"
+    if key not in json.loads((GOLDEN / "crc_config3.json").read_text()):
+        pytest.skip(f"{key} is not in tests/golden/crc_config3.json")
+    stats = _checksum_case(TP, key, 10_000_000, seed, 200, 10)
+    assert stats["flood_host_serial_pass1"] == 0
+
+
 @pytest.mark.parametrize("world,cells,iters,engine", [(3, 200000, (8, 8, 3), "planet"), (2, 1000000, (6, 6, 2), "planet"), (3, 200000, (8, 8, 3), "planet-device")])
 def test_landmass_decomposition_on_the_device(TP, oracle, tmp_path, world, cells, iters, engine):
     """One planet eroded by `world` ranks (processes sharing this box's GPU, gloo for the merge): every rank runs the HIP
