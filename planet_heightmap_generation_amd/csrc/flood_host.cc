@@ -286,7 +286,7 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
     // first label winning ties — i.e. among the largest components the one holding the smallest cell id.  Only that
     // choice is observable, so the components come from a concurrent union-find whose roots are the smallest id of
     // each component (link the larger root under the smaller with a CAS; path halving on the way up).
-    std::vector<int32_t> parentStore(N);
+    hvec<int32_t> parentStore((size_t)N);               // (not zero-filled: mesh_components writes every entry)
     int32_t* parent = parentStore.data();
     mesh_components(N, off, adj, [&](int32_t r) { return ocean[r] != 0; }, [](int32_t, int32_t) { return true; }, parent);
     // component sizes per thread as (root, count) runs, merged afterwards
@@ -400,10 +400,21 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
         // "visited" from the start, :119), so every landmass floods from its own seeds and pass 1 can give each its own
         // heap (flood_pass1_landmasses).  Seeds are grouped by landmass (ascending original id inside, the order the
         // reference pushes them in); landmasses are taken largest first.
-        std::vector<int32_t> comp(L);
+        hvec<int32_t> comp((size_t)L);
         mesh_components(L, S.offL.data(), S.adjL.data(), [](int32_t) { return true; }, [](int32_t, int32_t) { return true; }, comp.data());
-        std::vector<int32_t> size(L, 0);
-        for (int32_t i = 0; i < L; ++i) ++size[comp[i]];
+        // cells per component root: runs of equal roots (Morton order keeps a landmass's cells together) added with one atomic each
+        hvec<int32_t> size((size_t)L);
+        parallel_ranges(L, [&](int64_t b, int64_t e, int) { std::memset(size.data() + b, 0, sizeof(int32_t) * (size_t)(e - b)); });
+        parallel_ranges(L, [&](int64_t b, int64_t e, int) {
+            int32_t last = -1, run = 0;
+            for (int64_t i = b; i < e; ++i) {
+                const int32_t c = comp[i];
+                if (c == last) { ++run; continue; }
+                if (run) __atomic_fetch_add(&size[last], run, __ATOMIC_RELAXED);
+                last = c; run = 1;
+            }
+            if (run) __atomic_fetch_add(&size[last], run, __ATOMIC_RELAXED);
+        });
         const int32_t nS = (int32_t)S.seedCell.size();
         std::vector<int32_t> ord(nS);
         for (int32_t k = 0; k < nS; ++k) ord[k] = k;
@@ -420,7 +431,8 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
         // per seeded landmass: its cells in ascending original id (the order pass 2 is defined in), and each seed's position
         // among its landmass's seeds (= local tree number)
         const int32_t nComp = (int32_t)S.compSize.size();
-        std::vector<int32_t> compIndex(L, -1);               // by component root
+        hvec<int32_t>& compIndex = size;                     // by component root: the landmass's number, -1 for an unseeded one (the sizes are in compSize now)
+        parallel_ranges(L, [&](int64_t b, int64_t e, int) { for (int64_t i = b; i < e; ++i) compIndex[i] = -1; });
         S.seedLocal.assign(nS, 0);
         for (int32_t k = 0; k < nComp; ++k) {
             compIndex[comp[S.seedCell[ord[S.compSeedStart[k]]]]] = k;
@@ -429,8 +441,25 @@ void flood_build_static(int32_t N, const int32_t* off, const int32_t* adj, const
         S.compCellStart.assign(nComp + 1, 0);
         for (int32_t k = 0; k < nComp; ++k) S.compCellStart[k + 1] = S.compCellStart[k] + S.compSize[k];
         S.compCells.resize(S.compCellStart[nComp]);
-        std::vector<int32_t> pos(S.compCellStart.begin(), S.compCellStart.end() - 1);
-        for (int32_t q = 0; q < L; ++q) { const int32_t i = S.landByR[q]; const int32_t k = compIndex[comp[i]]; if (k >= 0) S.compCells[pos[k]++] = i; }
+        // the cells of every landmass in ascending original id: per range of that order the count per landmass, then every range writes behind the ranges before it
+        {
+            const int nt = host_threads() + 2;
+            std::vector<int32_t> cnt((size_t)nt * (size_t)std::max(nComp, 1), 0);
+            int usedRanges = 0;
+            parallel_ranges(L, [&](int64_t b, int64_t e, int t) {
+                int32_t* c = cnt.data() + (size_t)t * (size_t)nComp;
+                for (int64_t q = b; q < e; ++q) { const int32_t k = compIndex[comp[S.landByR[q]]]; if (k >= 0) ++c[k]; }
+                int cur = usedRanges; while (cur < t + 1 && !__atomic_compare_exchange_n(&usedRanges, &cur, t + 1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+            });
+            for (int32_t k = 0; k < nComp; ++k) {                // exclusive scan over the ranges, per landmass
+                int32_t at = S.compCellStart[k];
+                for (int t = 0; t < usedRanges; ++t) { int32_t& c = cnt[(size_t)t * (size_t)nComp + k]; const int32_t n = c; c = at; at += n; }
+            }
+            parallel_ranges(L, [&](int64_t b, int64_t e, int t) {
+                int32_t* c = cnt.data() + (size_t)t * (size_t)nComp;
+                for (int64_t q = b; q < e; ++q) { const int32_t i = S.landByR[q]; const int32_t k = compIndex[comp[i]]; if (k >= 0) S.compCells[c[k]++] = i; }
+            });
+        }
     }
     lap("landmasses");
     S.staticValid = true;
