@@ -603,6 +603,9 @@ def main():
                          "N = 1 with 'decomposed': the partitioned code path, --shares landmass shares one after the other")
     ap.add_argument("--seeds-per-rank", type=int, default=0, help="N > 1, ensemble: distinct planets (seeds 1 + rank + k x N) a rank cycles through, one per step; "
                                                                    "0 = min(steps, 64 / N) (BASELINE config 5: 64 seeds per job), 1 = the same planet every step")
+    ap.add_argument("--planets-in-flight", type=int, default=3, help="N > 1, ensemble: planets a rank keeps in flight (one host thread, context and stream each): a config-5 planet's host flood "
+                                                                      "(median 349 ms of its step over the 64 seeds) then hides behind the other planets' device work — 1.75x with 3, 1.99x with 6 "
+                                                                      "on one GPU (profiles/r06s_*); 1 = one planet after the other")
     ap.add_argument("--shares", type=int, default=8, help="N = 1, --mode decomposed: number of landmass shares")
     ap.add_argument("--one-planet-cells", type=int, default=40_000_000, help="N > 1, default mode: after the ensemble region, ONE planet of this many cells over all GPUs "
                                                                               "(BASELINE config 4; nested object `one_planet` of the line); 0 = skip")
@@ -681,7 +684,7 @@ def main():
         for k in range(1, want):
             sk = 1 + rank + k * world
             mk, xk, nk, tk = build_inputs(args.cells, sk)
-            q = TP.Planet(mk, xk, nk, ctx=pl.ctx)
+            q = TP.Planet(mk, xk, nk, ctx=pl.ctx if args.planets_in_flight <= 1 else TP.Context(local_rank))
             fleet.append(q); fleet_seeds.append(sk)
             t_mesh += tk
             del mk, xk, nk
@@ -709,11 +712,35 @@ def main():
             if w == 0:
                 pl.sync()
                 cold_ms = (time.perf_counter() - tc) * 1e3       # first step: mask-dependent tables, scratch allocation, launch-count prediction
+    in_flight = min(max(1, args.planets_in_flight), len(fleet)) if len(fleet) > 1 else 1
     barrier()
     t0 = time.perf_counter()
     pl.timer_start()
-    for _ in range(args.steps):
-        step()
+    if in_flight > 1:
+        # K planets in flight: worker j owns the planets j, j + K, ... of the rank's cycle and runs their turns of the job's `steps` planet-steps in order
+        # (no planet is ever in two hands); the step count and what a step is are unchanged, only the host no longer waits for one planet's flood
+        # before it feeds the device with the next planet's work
+        import threading
+        turns = [[t % len(fleet) for t in range(args.steps) if (t % len(fleet)) % in_flight == j] for j in range(in_flight)]
+        failures = []
+
+        def worker(mine):
+            try:
+                for i in mine:
+                    one_step(fleet[i], fleet_seeds[i], params)
+                    fleet[i].sync()
+            except BaseException as ex:      # noqa: BLE001 — re-raised below, in the rank's main thread
+                failures.append(ex)
+        th = [threading.Thread(target=worker, args=(mine,)) for mine in turns if mine]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if failures:
+            raise failures[0]
+    else:
+        for _ in range(args.steps):
+            step()
     ev_ms = pl.timer_stop_ms()
     barrier()
     wall = time.perf_counter() - t0
@@ -731,7 +758,10 @@ def main():
         dist.all_gather_object(allr, mine)
         seeds_run = sorted((e for lst in allr for e in lst), key=lambda e: e["seed"])
     for q in fleet[1:]:
+        own_ctx = q.ctx is not pl.ctx
         q.close()
+        if own_ctx:
+            q.ctx.close()
     # What a NEW planet costs on a resident mesh: the timed steps above re-run one terrain, whose mask-dependent tables (land-first
     # mirror, flood tables, land lists, launch-count prediction) are cached after the first step.  Three other terrains on the same mesh, one step each,
     # with those tables rebuilt inside the clock; then the benched terrain again (untimed) for the legs below.
@@ -911,7 +941,8 @@ def main():
             "value_with_transfers": transfers["value_with_transfers"] if transfers else None, "with_transfers": transfers, "one_planet": one_planet, "relaxed_mode": relaxed,
             "roofline": roofline, "cpu_baseline": cpu, "ensemble_in_flight": ensemble,
             "parity": crc, "ensemble_seeds": seeds_run, "cold_first_step_ms": cold_ms, "new_terrain_step_ms": new_terrain["mean_ms"] if new_terrain else None, "new_terrain": new_terrain,
-            "ensemble_steps_are_new_terrain": (len(fleet_seeds) > 1 and args.steps <= len(fleet_seeds)) if world > 1 and not decomposed_mode else None, "host_threads": host_threads,
+            "ensemble_steps_are_new_terrain": (len(fleet_seeds) > 1 and args.steps <= len(fleet_seeds)) if world > 1 and not decomposed_mode else None,
+            "ensemble_planets_in_flight_per_rank": in_flight if world > 1 and not decomposed_mode else None, "host_threads": host_threads,
             "hbm_d2d_copy_GBs_measured": d2d_GBs,
             "stage_ms_last_step": {k: round(v, 2) for k, v in stages.items()},
             "erode_stats": stats, "mesh_build_s": round(t_mesh, 1), "host_numa_node": numa_node, "hip_event_ms_per_step": ev_ms / args.steps,
