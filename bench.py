@@ -603,9 +603,10 @@ def main():
                          "N = 1 with 'decomposed': the partitioned code path, --shares landmass shares one after the other")
     ap.add_argument("--seeds-per-rank", type=int, default=0, help="N > 1, ensemble: distinct planets (seeds 1 + rank + k x N) a rank cycles through, one per step; "
                                                                    "0 = min(steps, 64 / N) (BASELINE config 5: 64 seeds per job), 1 = the same planet every step")
-    ap.add_argument("--planets-in-flight", type=int, default=3, help="N > 1, ensemble: planets a rank keeps in flight (one host thread, context and stream each): a config-5 planet's host flood "
-                                                                      "(median 349 ms of its step over the 64 seeds) then hides behind the other planets' device work — 1.75x with 3, 1.99x with 6 "
-                                                                      "on one GPU (profiles/r06s_*); 1 = one planet after the other")
+    ap.add_argument("--planets-in-flight", type=int, default=1, help="N > 1, ensemble: planets a rank keeps in flight (one host thread, context and stream each; the rank's flood / host "
+                                                                      "threads are divided among them).  A config-5 planet's host flood (median 349 ms of its step over the 64 seeds) can hide "
+                                                                      "behind other planets' device work — 1.75x with 3, 1.99x with 6 warm planets in ONE process on one GPU (profiles/r06s_*) — "
+                                                                      "but with new terrains and ranks that share cores it was 4x SLOWER in the two-rank rehearsal (profiles/r06t_*): default 1")
     ap.add_argument("--shares", type=int, default=8, help="N = 1, --mode decomposed: number of landmass shares")
     ap.add_argument("--one-planet-cells", type=int, default=40_000_000, help="N > 1, default mode: after the ensemble region, ONE planet of this many cells over all GPUs "
                                                                               "(BASELINE config 4; nested object `one_planet` of the line); 0 = skip")
@@ -636,8 +637,9 @@ def main():
             mine = len(os.sched_getaffinity(0))
             nodes = max(1, len(list(Path("/sys/devices/system/node").glob("node[0-9]*")))) if numa_node is not None else 1
             per_rank = max(4, mine * nodes // world)
-            os.environ.setdefault("WO_FLOOD_THREADS", str(min(24, per_rank)))
-            os.environ.setdefault("WO_HOST_THREADS", str(min(64, per_rank)))
+            per_planet = max(4, per_rank // max(1, args.planets_in_flight))          # planets in flight share the rank's cores
+            os.environ.setdefault("WO_FLOOD_THREADS", str(min(24, per_planet)))
+            os.environ.setdefault("WO_HOST_THREADS", str(min(64, per_planet)))
         except Exception:
             pass
     from planet_heightmap_generation_amd import terrain_post as TP

@@ -2,7 +2,7 @@
 # Round 6, session t: the N > 1 ensemble leg at full size with planets in flight, as a rehearsal (two gloo ranks sharing the one GPU; not a measurement): config 5's planets are NEW terrains inside the timed region.
 cd /root/repo; OUT=/root/repo/gpurun_out/r06t; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --backend gloo --share-gpu --steps 6 --warmup 1 --seeds-per-rank 6 --one-planet-cells 0 --no-cpu --no-profile --in-flight 0 > $OUT/bench_gpus2_rehearsal.json 2> $OUT/bench_gpus2_rehearsal.err; echo "rc=$?"
+timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --backend gloo --share-gpu --steps 6 --warmup 1 --seeds-per-rank 6 --planets-in-flight 3 --one-planet-cells 0 --no-cpu --no-profile --in-flight 0 > $OUT/bench_gpus2_rehearsal.json 2> $OUT/bench_gpus2_rehearsal.err; echo "rc=$?"
 tail -3 $OUT/bench_gpus2_rehearsal.err
 python - <<'PY'
 import json
